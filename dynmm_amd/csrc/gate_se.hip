@@ -1,0 +1,317 @@
+// The two "tiny" pieces of the hot path that sit between the big feature-map passes:
+//   * SE excitation MLPs + gate blend coefficients  (one workgroup per sample, C <= 1024)
+//   * the global-gate head: 1x1 fc, DiffSoftmax (temperature softmax + straight-through arg-max),
+//     cumulative stage weights and the FLOP regulariser (single workgroup, latency-bound).
+// They are latency-bound, so each is ONE launch forward and ONE backward.
+#include "common.h"
+
+namespace dynmm {
+
+constexpr int kMaxC = 1024;
+constexpr int kMaxHid = 64;
+
+struct SeParams { const float* p[8]; };   // W1r b1r W2r b2r W1d b1d W2d b2d
+struct SeGrads { float* p[8]; };
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// one modality: s[C] (LDS) -> h[Hd] (LDS, also saved) -> g[C] (saved)
+__device__ void se_mlp_fwd(const float* s, const float* W1, const float* b1, const float* W2,
+                           const float* b2, float* h_lds, float* h_out, float* g_out, int C, int Hd) {
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        float acc = b1[j];
+        for (int c = 0; c < C; ++c) acc += W1[j * C + c] * s[c];
+        acc = acc > 0.f ? acc : 0.f;
+        h_lds[j] = acc;
+        h_out[j] = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = b2[c];
+        for (int j = 0; j < Hd; ++j) acc += W2[c * Hd + j] * h_lds[j];
+        g_out[c] = sigmoidf_(acc);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) se_coeff_fwd_kernel(
+    const float* __restrict__ sr, const float* __restrict__ sd, SeParams P,
+    const float* __restrict__ wc, int wc_stride, float* __restrict__ a, float* __restrict__ b,
+    float* __restrict__ hr, float* __restrict__ hd, float* __restrict__ gr, float* __restrict__ gd,
+    int C, int use_se) {
+    __shared__ float s_lds[kMaxC];
+    __shared__ float h_lds[kMaxHid];
+    const int n = blockIdx.x;
+    const int Hd = C / 16;
+    const float w = wc ? wc[(size_t)n * wc_stride] : 0.f;
+    if (use_se) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) s_lds[c] = sr[(size_t)n * C + c];
+        __syncthreads();
+        se_mlp_fwd(s_lds, P.p[0], P.p[1], P.p[2], P.p[3], h_lds, hr + (size_t)n * Hd, gr + (size_t)n * C, C, Hd);
+        for (int c = threadIdx.x; c < C; c += blockDim.x) s_lds[c] = sd[(size_t)n * C + c];
+        __syncthreads();
+        se_mlp_fwd(s_lds, P.p[4], P.p[5], P.p[6], P.p[7], h_lds, hd + (size_t)n * Hd, gd + (size_t)n * C, C, Hd);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float g_r = use_se ? gr[(size_t)n * C + c] : 1.f;
+        const float g_d = use_se ? gd[(size_t)n * C + c] : 1.f;
+        // out = w*rgb + (1-w)*(rgb*g_r + depth*g_d)
+        a[(size_t)n * C + c] = w + (1.f - w) * g_r;
+        b[(size_t)n * C + c] = (1.f - w) * g_d;
+    }
+}
+
+// backward of one modality's MLP for one sample.  dg[C] in LDS (grad wrt g), produces ds[C].
+__device__ void se_mlp_bwd(const float* dg, const float* s, const float* h, const float* g,
+                           const float* W1, const float* W2, float* dW1, float* db1, float* dW2,
+                           float* db2, float* dz2_lds, float* dh_lds, float* ds_out, int C, int Hd) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float gg = g[c];
+        const float dz = dg[c] * gg * (1.f - gg);
+        dz2_lds[c] = dz;
+        atomicAdd(&db2[c], dz);
+        for (int j = 0; j < Hd; ++j) atomicAdd(&dW2[c * Hd + j], dz * h[j]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += W2[c * Hd + j] * dz2_lds[c];
+        acc = h[j] > 0.f ? acc : 0.f;
+        dh_lds[j] = acc;
+        atomicAdd(&db1[j], acc);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        const float sc = s[c];
+        for (int j = 0; j < Hd; ++j) {
+            const float dh = dh_lds[j];
+            acc += W1[j * C + c] * dh;
+            atomicAdd(&dW1[j * C + c], dh * sc);
+        }
+        ds_out[c] = acc;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) se_coeff_bwd_kernel(
+    const float* __restrict__ da, const float* __restrict__ db, const float* __restrict__ sr,
+    const float* __restrict__ sd, SeParams P, const float* __restrict__ wc, int wc_stride,
+    const float* __restrict__ hr, const float* __restrict__ hd, const float* __restrict__ gr,
+    const float* __restrict__ gd, SeGrads G, float* __restrict__ dsr, float* __restrict__ dsd,
+    float* __restrict__ dwc, int dwc_stride, int C, int use_se) {
+    __shared__ float dg_lds[kMaxC];
+    __shared__ float dz_lds[kMaxC];
+    __shared__ float dh_lds[kMaxHid];
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const int Hd = C / 16;
+    const float w = wc ? wc[(size_t)n * wc_stride] : 0.f;
+    const float* dan = da + (size_t)n * C;
+    const float* dbn = db + (size_t)n * C;
+    // dw = sum_c da*(1-g_r) - db*g_d
+    if (dwc) {
+        float acc = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float g_r = use_se ? gr[(size_t)n * C + c] : 1.f;
+            const float g_d = use_se ? gd[(size_t)n * C + c] : 1.f;
+            acc += dan[c] * (1.f - g_r) - dbn[c] * g_d;
+        }
+        const float t = block_reduce_sum_256<float>(acc, red);
+        if (threadIdx.x == 0) dwc[(size_t)n * dwc_stride] = t;
+    }
+    if (!use_se) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dg_lds[c] = dan[c] * (1.f - w);
+    __syncthreads();
+    se_mlp_bwd(dg_lds, sr + (size_t)n * C, hr + (size_t)n * Hd, gr + (size_t)n * C, P.p[0], P.p[2],
+               G.p[0], G.p[1], G.p[2], G.p[3], dz_lds, dh_lds, dsr + (size_t)n * C, C, Hd);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dg_lds[c] = dbn[c] * (1.f - w);
+    __syncthreads();
+    se_mlp_bwd(dg_lds, sd + (size_t)n * C, hd + (size_t)n * Hd, gd + (size_t)n * C, P.p[4], P.p[6],
+               G.p[4], G.p[5], G.p[6], G.p[7], dz_lds, dh_lds, dsd + (size_t)n * C, C, Hd);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate head (single workgroup; N samples looped by the threads)
+// ------------------------------------------------------------------------------------------------
+constexpr int kBranches = 5;
+
+__global__ void __launch_bounds__(256) gate_head_fwd_kernel(
+    const float* __restrict__ pooled, const float* __restrict__ fc, float* __restrict__ weight,
+    float* __restrict__ wcum, float* __restrict__ soft, float* __restrict__ flop_loss,
+    const float* __restrict__ flop_table, int N, int J, float temp, int hard, int mode) {
+    __shared__ float red[4];
+    float col[kBranches] = {0.f, 0.f, 0.f, 0.f, 0.f};   // this thread's partial column sums of weight
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float w[kBranches];
+        if (mode == 0) {
+            float z[kBranches];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < kBranches; ++k) {
+                float acc = 0.f;
+                for (int j = 0; j < J; ++j) acc += fc[k * J + j] * pooled[(size_t)n * J + j];
+                z[k] = acc / temp;
+                zmax = fmaxf(zmax, z[k]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < kBranches; ++k) { z[k] = expf(z[k] - zmax); den += z[k]; }
+            int arg = 0;
+            float best = -1.f;
+#pragma unroll
+            for (int k = 0; k < kBranches; ++k) {
+                z[k] = z[k] / den;
+                soft[(size_t)n * kBranches + k] = z[k];
+                if (z[k] > best) { best = z[k]; arg = k; }   // first maximum, as torch.max
+            }
+#pragma unroll
+            for (int k = 0; k < kBranches; ++k) {
+                // straight-through value: (y_hard - y_soft) + y_soft, evaluated in that order
+                w[k] = hard ? ((k == arg ? 1.f : 0.f) - z[k]) + z[k] : z[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kBranches; ++k) {
+                w[k] = weight[(size_t)n * kBranches + k];
+                soft[(size_t)n * kBranches + k] = w[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kBranches; ++k) {
+            if (mode == 0) weight[(size_t)n * kBranches + k] = w[k];
+            col[k] += w[k];
+        }
+        const float c1 = w[0], c2 = w[0] + w[1], c3 = c2 + w[2];
+        wcum[(size_t)n * 4 + 0] = c1;
+        wcum[(size_t)n * 4 + 1] = c2;
+        wcum[(size_t)n * 4 + 2] = c3;
+        wcum[(size_t)n * 4 + 3] = 1.f - w[4];
+    }
+    float loss = 0.f;
+#pragma unroll
+    for (int k = 0; k < kBranches; ++k) {
+        const float t = block_reduce_sum_256<float>(col[k], red);
+        if (threadIdx.x == 0) loss += (t / (float)N) * flop_table[k];
+    }
+    if (threadIdx.x == 0) flop_loss[0] = loss / (float)kBranches;
+}
+
+__global__ void __launch_bounds__(256) gate_head_bwd_kernel(
+    const float* __restrict__ d_weight, const float* __restrict__ d_wcum,
+    const float* __restrict__ d_loss, const float* __restrict__ pooled, const float* __restrict__ fc,
+    const float* __restrict__ soft, const float* __restrict__ flop_table,
+    float* __restrict__ d_pooled, float* __restrict__ d_fc, int N, int J, float temp) {
+    const float dl = d_loss ? d_loss[0] : 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float dw[kBranches];
+#pragma unroll
+        for (int k = 0; k < kBranches; ++k) {
+            dw[k] = (d_weight ? d_weight[(size_t)n * kBranches + k] : 0.f) +
+                    dl * flop_table[k] / ((float)kBranches * (float)N);
+        }
+        if (d_wcum) {
+            const float c1 = d_wcum[(size_t)n * 4 + 0], c2 = d_wcum[(size_t)n * 4 + 1];
+            const float c3 = d_wcum[(size_t)n * 4 + 2], c4 = d_wcum[(size_t)n * 4 + 3];
+            dw[0] += c1 + c2 + c3;
+            dw[1] += c2 + c3;
+            dw[2] += c3;
+            dw[4] -= c4;
+        }
+        // through (y_hard - sg(y_soft)) + y_soft : d y_soft = dw ; softmax backward, /temp
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < kBranches; ++k) dot += soft[(size_t)n * kBranches + k] * dw[k];
+        float dz[kBranches];
+#pragma unroll
+        for (int k = 0; k < kBranches; ++k)
+            dz[k] = soft[(size_t)n * kBranches + k] * (dw[k] - dot) / temp;
+        for (int j = 0; j < J; ++j) {
+            float acc = 0.f;
+            const float pj = pooled[(size_t)n * J + j];
+#pragma unroll
+            for (int k = 0; k < kBranches; ++k) {
+                acc += dz[k] * fc[k * J + j];
+                atomicAdd(&d_fc[k * J + j], dz[k] * pj);
+            }
+            d_pooled[(size_t)n * J + j] = acc;
+        }
+    }
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+extern "C" int dynmm_se_coeff_fwd(const float* sr, const float* sd, const float* const* params,
+                                  const float* wc, int wc_stride, float* a, float* b, float* hr,
+                                  float* hd, float* gr, float* gd, int N, int C, int use_se,
+                                  void* stream) {
+    if (!a || !b || N <= 0 || C <= 0 || C > kMaxC) return DYNMM_EINVAL;
+    SeParams P{};
+    if (use_se) {
+        if (!sr || !sd || !params || !hr || !hd || !gr || !gd) return DYNMM_EINVAL;
+        if (C % 16 != 0 || C / 16 > kMaxHid) return DYNMM_EUNSUPPORTED;
+        for (int i = 0; i < 8; ++i) {
+            if (!params[i]) return DYNMM_EINVAL;
+            P.p[i] = params[i];
+        }
+    }
+    hipLaunchKernelGGL(se_coeff_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, sr, sd, P, wc,
+                       wc_stride, a, b, hr, hd, gr, gd, C, use_se);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_se_coeff_bwd(const float* da, const float* db, const float* sr, const float* sd,
+                                  const float* const* params, const float* wc, int wc_stride,
+                                  const float* hr, const float* hd, const float* gr, const float* gd,
+                                  float* const* dparams, float* dsr, float* dsd, float* dwc,
+                                  int dwc_stride, int N, int C, int use_se, void* stream) {
+    if (!da || !db || N <= 0 || C <= 0 || C > kMaxC) return DYNMM_EINVAL;
+    SeParams P{};
+    SeGrads G{};
+    hipStream_t st = (hipStream_t)stream;
+    if (use_se) {
+        if (!sr || !sd || !params || !dparams || !hr || !hd || !gr || !gd || !dsr || !dsd)
+            return DYNMM_EINVAL;
+        if (C % 16 != 0 || C / 16 > kMaxHid) return DYNMM_EUNSUPPORTED;
+        const int Hd = C / 16;
+        const size_t sizes[4] = {(size_t)Hd * C, (size_t)Hd, (size_t)C * Hd, (size_t)C};
+        for (int i = 0; i < 8; ++i) {
+            if (!params[i] || !dparams[i]) return DYNMM_EINVAL;
+            P.p[i] = params[i];
+            G.p[i] = dparams[i];
+            DYNMM_HIP_TRY(hipMemsetAsync(dparams[i], 0, sizeof(float) * sizes[i % 4], st));
+        }
+    }
+    hipLaunchKernelGGL(se_coeff_bwd_kernel, dim3(N), dim3(256), 0, st, da, db, sr, sd, P, wc,
+                       wc_stride, hr, hd, gr, gd, G, dsr, dsd, dwc, dwc_stride, C, use_se);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_gate_head_fwd(const float* pooled, const float* fc, float* weight, float* wcum,
+                                   float* soft, float* flop_loss, const float* flop_table, int N,
+                                   int J, float temp, int hard, int mode, void* stream) {
+    if (!weight || !wcum || !soft || !flop_loss || !flop_table || N <= 0) return DYNMM_EINVAL;
+    if (mode == 0 && (!pooled || !fc || J <= 0 || !(temp > 0.f))) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(gate_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pooled, fc,
+                       weight, wcum, soft, flop_loss, flop_table, N, J, temp, hard, mode);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, const float* d_loss,
+                                   const float* pooled, const float* fc, const float* soft,
+                                   const float* flop_table, float* d_pooled, float* d_fc, int N,
+                                   int J, float temp, void* stream) {
+    if (!pooled || !fc || !soft || !flop_table || !d_pooled || !d_fc || N <= 0 || J <= 0)
+        return DYNMM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DYNMM_HIP_TRY(hipMemsetAsync(d_fc, 0, sizeof(float) * kBranches * J, st));
+    hipLaunchKernelGGL(gate_head_bwd_kernel, dim3(1), dim3(256), 0, st, d_weight, d_wcum, d_loss,
+                       pooled, fc, soft, flop_table, d_pooled, d_fc, N, J, temp);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}

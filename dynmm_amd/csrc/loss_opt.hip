@@ -1,0 +1,138 @@
+// Callers immediately either side of the hot path: the class-weighted 2-D cross
+// entropy that reads the 49 MB/img logits (one fused log-softmax + NLL pass, fp64 accumulation of the
+// two scalars) and a flat fused SGD-Nesterov update.  Both are pure HBM streaming.
+#include "common.h"
+#include "vec.h"
+
+namespace dynmm {
+
+constexpr int kMaxClasses = 64;
+
+__global__ void __launch_bounds__(256) ce2d_fwd_kernel(const float* __restrict__ x,
+                                                       const unsigned char* __restrict__ target,
+                                                       const float* __restrict__ cw,
+                                                       double* __restrict__ out2, int C, int HW) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const float* xn = x + (size_t)n * C * HW;
+    const unsigned char* tn = target + (size_t)n * HW;
+    float ls = 0.f, ws = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const int t = (int)tn[p] - 1;
+        if (t < 0 || t >= C) continue;   // void (ignore_index = -1 after the shift)
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, xn[(size_t)c * HW + p]);
+        float den = 0.f;
+        for (int c = 0; c < C; ++c) den += expf(xn[(size_t)c * HW + p] - mx);
+        const float lse = logf(den) + mx;
+        const float w = cw[t];
+        ls += w * (lse - xn[(size_t)t * HW + p]);
+        ws += w;
+    }
+    const float tl = block_reduce_sum_256<float>(ls, red);
+    const float tw = block_reduce_sum_256<float>(ws, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&out2[0], (double)tl);
+        atomicAdd(&out2[1], (double)tw);
+    }
+}
+
+__global__ void __launch_bounds__(256) ce2d_bwd_kernel(const float* __restrict__ x,
+                                                       const unsigned char* __restrict__ target,
+                                                       const float* __restrict__ cw,
+                                                       const float* __restrict__ gscale,
+                                                       float* __restrict__ dx, int C, int HW) {
+    const int n = blockIdx.y;
+    const float* xn = x + (size_t)n * C * HW;
+    float* dn = dx + (size_t)n * C * HW;
+    const unsigned char* tn = target + (size_t)n * HW;
+    const float gs = gscale[0];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const int t = (int)tn[p] - 1;
+        if (t < 0 || t >= C) {
+            for (int c = 0; c < C; ++c) dn[(size_t)c * HW + p] = 0.f;
+            continue;
+        }
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, xn[(size_t)c * HW + p]);
+        float den = 0.f;
+        for (int c = 0; c < C; ++c) den += expf(xn[(size_t)c * HW + p] - mx);
+        const float k = cw[t] * gs;
+        const float inv = 1.f / den;
+        for (int c = 0; c < C; ++c) {
+            const float sm = expf(xn[(size_t)c * HW + p] - mx) * inv;
+            dn[(size_t)c * HW + p] = k * (sm - (c == t ? 1.f : 0.f));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) sgd_nesterov_kernel(float* __restrict__ p,
+                                                           const float* __restrict__ g,
+                                                           float* __restrict__ buf, size_t n,
+                                                           const float* __restrict__ lr,
+                                                           float momentum, float wd, float gscale) {
+    const float l = lr[0];
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            float pv[4], gv[4], bv[4];
+            vload<4>(p + i, pv);
+            vload<4>(g + i, gv);
+            vload<4>(buf + i, bv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = gv[j] * gscale + wd * pv[j];
+                bv[j] = momentum * bv[j] + d;
+                pv[j] -= l * (d + momentum * bv[j]);
+            }
+            vstore<4>(p + i, pv);
+            vstore<4>(buf + i, bv);
+        } else {
+            for (size_t k = i; k < n; ++k) {
+                const float d = g[k] * gscale + wd * p[k];
+                buf[k] = momentum * buf[k] + d;
+                p[k] -= l * (d + momentum * buf[k]);
+            }
+        }
+    }
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+extern "C" int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
+                              double* loss_sum_wsum, int N, int C, int HW, void* stream) {
+    if (!x || !target || !cw || !loss_sum_wsum || N <= 0 || C <= 0 || C > kMaxClasses || HW <= 0)
+        return DYNMM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DYNMM_HIP_TRY(hipMemsetAsync(loss_sum_wsum, 0, 2 * sizeof(double), st));
+    int bx = ceil_div(HW, 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(ce2d_fwd_kernel, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
+                              const float* gscale, float* dx, int N, int C, int HW, void* stream) {
+    if (!x || !target || !cw || !gscale || !dx || N <= 0 || C <= 0 || C > kMaxClasses || HW <= 0)
+        return DYNMM_EINVAL;
+    int bx = ceil_div(HW, 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(ce2d_bwd_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, target, cw,
+                       gscale, dx, C, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const float* lr,
+                                  float momentum, float weight_decay, float grad_scale, void* stream) {
+    if (!p || !g || !buf || !lr || n == 0) return DYNMM_EINVAL;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(buf)) return DYNMM_EUNSUPPORTED;
+    size_t blocks = ceil_div_sz(n, 1024);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       p, g, buf, n, lr, momentum, weight_decay, grad_scale);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}

@@ -1,0 +1,324 @@
+// BatchNorm2d (train + eval, forward + backward) and the activation/bias backward pass.
+// All of these are HBM-bound streaming passes over NCHW planes: one workgroup owns whole (n,c)
+// planes (so the channel is uniform per workgroup), lanes walk the contiguous HW axis with 16-byte
+// accesses, per-channel reductions are wave-shuffle -> LDS -> one fp64 atomic per workgroup.
+#include "common.h"
+#include "vec.h"
+
+namespace dynmm {
+
+static inline int reduce_splits(int N, int C) {
+    int s = 2048 / (C > 0 ? C : 1);
+    if (s < 1) s = 1;
+    if (s > N) s = N;
+    return s;
+}
+
+// sums[c] += sum x ; sums[C+c] += sum x^2
+template <int V>
+__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x,
+                                                       double* __restrict__ sums,
+                                                       int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, S = gridDim.y;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = blockIdx.y; n < N; n += S) {
+        const float* p = x + ((size_t)n * C + c) * HW;
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+            float v[V];
+            vload<V>(p + i, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { a1 += v[j]; a2 += v[j] * v[j]; }
+        }
+        s1 += a1; s2 += a2;
+    }
+    const float t1 = block_reduce_sum_256<float>(s1, red);
+    const float t2 = block_reduce_sum_256<float>(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], (double)t1);
+        atomicAdd(&sums[C + c], (double)t2);
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) bn_apply_kernel(
+    const float* __restrict__ x, const double* __restrict__ sums, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, const float* __restrict__ residual,
+    float* __restrict__ y, int N, int C, int HW, float eps, float momentum, int training, int act,
+    int chunk) {
+    const int plane = blockIdx.x;
+    const int c = plane % C;
+    float mean, invstd;
+    if (training) {
+        const double M = (double)N * HW;
+        const double mu = sums[c] / M;
+        double var = sums[C + c] / M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean = (float)mu;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
+            if (save_mean) save_mean[c] = mean;
+            if (save_invstd) save_invstd[c] = invstd;
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            if (running_var) {
+                const double unb = var * (M / (M - 1.0));
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.f / sqrtf(running_var[c] + eps);
+        if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
+            if (save_mean) save_mean[c] = mean;
+            if (save_invstd) save_invstd[c] = invstd;
+        }
+    }
+    const float sc = gamma[c] * invstd;
+    const float sh = beta[c] - mean * sc;
+    const size_t base = (size_t)plane * HW;
+    const int beg = blockIdx.y * chunk;
+    const int end = min(HW, beg + chunk);
+    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
+        float v[V], r[V];
+        vload<V>(x + base + i, v);
+        if (residual) vload<V>(residual + base + i, r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float o = v[j] * sc + sh;
+            if (residual) o += r[j];
+            v[j] = act_fwd(o, act);
+        }
+        vstore<V>(y + base + i, v);
+    }
+}
+
+// sums[c] += sum g_eff ; sums[C+c] += sum g_eff * xhat
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ sums,
+    int N, int C, int HW, int act) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, S = gridDim.y;
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = blockIdx.y; n < N; n += S) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+            float gv[V], yv[V], xv[V];
+            vload<V>(g + base + i, gv);
+            vload<V>(x + base + i, xv);
+            if (act != DYNMM_ACT_NONE) vload<V>(y + base + i, yv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float ge = (act != DYNMM_ACT_NONE) ? act_bwd(gv[j], yv[j], act) : gv[j];
+                a1 += ge;
+                a2 += ge * (xv[j] - mu) * is;
+            }
+        }
+        s1 += a1; s2 += a2;
+    }
+    const float t1 = block_reduce_sum_256<float>(s1, red);
+    const float t2 = block_reduce_sum_256<float>(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], (double)t1);
+        atomicAdd(&sums[C + c], (double)t2);
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dres,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int HW, int training,
+    int act, int chunk) {
+    const int plane = blockIdx.x;
+    const int c = plane % C;
+    const float mu = mean[c], is = invstd[c];
+    const float sg = (float)sums[c], sgx = (float)sums[C + c];
+    if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = sgx;
+        if (dbeta) dbeta[c] = sg;
+    }
+    const float invM = 1.f / ((float)N * (float)HW);
+    const float k0 = gamma[c] * is;
+    const float m1 = training ? sg * invM : 0.f;
+    const float m2 = training ? sgx * invM : 0.f;
+    const size_t base = (size_t)plane * HW;
+    const int beg = blockIdx.y * chunk;
+    const int end = min(HW, beg + chunk);
+    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
+        float gv[V], yv[V], xv[V], o[V];
+        vload<V>(g + base + i, gv);
+        vload<V>(x + base + i, xv);
+        if (act != DYNMM_ACT_NONE) vload<V>(y + base + i, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float ge = (act != DYNMM_ACT_NONE) ? act_bwd(gv[j], yv[j], act) : gv[j];
+            gv[j] = ge;
+            o[j] = k0 * (ge - m1 - (xv[j] - mu) * is * m2);
+        }
+        vstore<V>(dx + base + i, o);
+        if (dres) vstore<V>(dres + base + i, gv);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_fold_kernel(
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+    const float* __restrict__ rv, const float* __restrict__ cbias, float* __restrict__ scale,
+    float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    const float b = cbias ? cbias[c] : 0.f;
+    scale[c] = sc;
+    shift[c] = beta[c] + (b - rm[c]) * sc;
+}
+
+// g_out = act'(y) * g ; dbias[c] += sum g_out   (fp32 atomics: <= 2048/C partials per channel)
+template <int V>
+__global__ void __launch_bounds__(256) act_bwd_bias_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ gout,
+    float* __restrict__ dbias, int N, int C, int HW, int act) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, S = gridDim.y;
+    float s1 = 0.f;
+    for (int n = blockIdx.y; n < N; n += S) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        float a1 = 0.f;
+        for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+            float gv[V], yv[V];
+            vload<V>(g + base + i, gv);
+            if (act != DYNMM_ACT_NONE) {
+                vload<V>(y + base + i, yv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) gv[j] = act_bwd(gv[j], yv[j], act);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) a1 += gv[j];
+            if (gout) vstore<V>(gout + base + i, gv);
+        }
+        s1 += a1;
+    }
+    if (dbias) {
+        const float t1 = block_reduce_sum_256<float>(s1, red);
+        if (threadIdx.x == 0) atomicAdd(&dbias[c], t1);
+    }
+}
+
+static inline int plane_chunk(int HW, int* nchunks) {
+    const int chunk = 8192;   // floats per workgroup pass: 8 x dwordx4 per lane
+    *nchunks = (HW + chunk - 1) / chunk;
+    return chunk;
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+extern "C" int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, void* stream) {
+    if (!x || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
+    dim3 grid(C, reduce_splits(N, C));
+    if (can_vec4(HW, {x}))
+        hipLaunchKernelGGL(bn_stats_kernel<4>, grid, dim3(256), 0, st, x, sums, N, C, HW);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<1>, grid, dim3(256), 0, st, x, sums, N, C, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              float* save_mean, float* save_invstd, const float* residual, float* y,
+                              int N, int C, int HW, float eps, float momentum, int training, int act,
+                              void* stream) {
+    if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
+    if (training && (!sums || (long long)N * HW <= 1)) return DYNMM_EINVAL;
+    if (!training && (!running_mean || !running_var)) return DYNMM_EINVAL;
+    int nchunks;
+    const int chunk = plane_chunk(HW, &nchunks);
+    dim3 grid(N * C, nchunks);
+    hipStream_t st = (hipStream_t)stream;
+    if (can_vec4(HW, {x, residual, y}))
+        hipLaunchKernelGGL(bn_apply_kernel<4>, grid, dim3(256), 0, st, x, sums, gamma, beta,
+                           running_mean, running_var, save_mean, save_invstd, residual, y, N, C, HW,
+                           eps, momentum, training, act, chunk);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, st, x, sums, gamma, beta,
+                           running_mean, running_var, save_mean, save_invstd, residual, y, N, C, HW,
+                           eps, momentum, training, act, chunk);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x, const float* mean,
+                                   const float* invstd, double* sums, int N, int C, int HW, int act,
+                                   void* stream) {
+    if (!g || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
+    dim3 grid(C, reduce_splits(N, C));
+    if (can_vec4(HW, {g, y, x}))
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
+                           sums, N, C, HW, act);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
+                           sums, N, C, HW, act);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x, const float* mean,
+                                  const float* invstd, const float* gamma, const double* sums,
+                                  float* dx, float* d_residual, float* dgamma, float* dbeta, int N,
+                                  int C, int HW, int training, int act, void* stream) {
+    if (!g || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || HW <= 0)
+        return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
+    int nchunks;
+    const int chunk = plane_chunk(HW, &nchunks);
+    dim3 grid(N * C, nchunks);
+    hipStream_t st = (hipStream_t)stream;
+    if (can_vec4(HW, {g, y, x, dx, d_residual}))
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
+                           gamma, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
+                           gamma, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, const float* conv_bias, float* scale,
+                             float* shift, int C, float eps, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0)
+        return DYNMM_EINVAL;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, running_mean, running_var, conv_bias, scale, shift, C, eps);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias,
+                                  int N, int C, int HW, int act, void* stream) {
+    if (!g || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
+    if (!g_out && !dbias) return DYNMM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dbias) DYNMM_HIP_TRY(hipMemsetAsync(dbias, 0, sizeof(float) * C, st));
+    dim3 grid(C, reduce_splits(N, C));
+    if (can_vec4(HW, {g, y, g_out}))
+        hipLaunchKernelGGL(act_bwd_bias_kernel<4>, grid, dim3(256), 0, st, g, y, g_out, dbias, N, C, HW, act);
+    else
+        hipLaunchKernelGGL(act_bwd_bias_kernel<1>, grid, dim3(256), 0, st, g, y, g_out, dbias, N, C, HW, act);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}

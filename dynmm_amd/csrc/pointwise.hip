@@ -1,0 +1,527 @@
+// HBM-bound streaming kernels of the hot path: max-pool, adaptive average pool, nearest resize into
+// a concat buffer (PPM), learned 2x upsample (nearest + depthwise 3x3 [+ skip add]), global average
+// pool, and the per-(n,c)-coefficient blend  out = a*rgb + b*depth  that implements SE fusion and
+// the gate blend in ONE pass over the feature maps (instead of the reference's 6 ATen launches per
+// site).  One workgroup owns (a chunk of) one NCHW plane; lanes walk the
+// contiguous HW axis with 16-byte accesses wherever size/alignment allow.
+#include "common.h"
+#include "vec.h"
+
+namespace dynmm {
+
+static inline int plane_chunks(int HW, int chunk) { return (HW + chunk - 1) / chunk; }
+constexpr int kChunk = 8192;
+
+// ------------------------------------------------------------------------------------------------
+// F.max_pool2d(kernel 3, stride 2, pad 1): first maximum in row-major window order wins (strict >),
+// NaN propagates — the tie rule matters because the inputs are post-ReLU (many exact zeros).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ y,
+                                                          signed char* __restrict__ idx, int H,
+                                                          int W, int Ho, int Wo) {
+    const size_t plane = blockIdx.x;
+    const float* xp = x + plane * H * W;
+    const int HoWo = Ho * Wo;
+    const int beg = blockIdx.y * kChunk, end = min(HoWo, beg + kChunk);
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        const int oh = i / Wo, ow = i - oh * Wo;
+        float best = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = 2 * oh - 1 + r;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int iw = 2 * ow - 1 + s;
+                if (iw < 0 || iw >= W) continue;
+                const float v = xp[ih * W + iw];
+                if (bi < 0 || v > best || v != v) { best = v; bi = r * 3 + s; }
+            }
+        }
+        y[plane * HoWo + i] = best;
+        if (idx) idx[plane * HoWo + i] = (signed char)bi;
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ g,
+                                                          const signed char* __restrict__ idx,
+                                                          float* __restrict__ dx, int H, int W,
+                                                          int Ho, int Wo) {
+    const size_t plane = blockIdx.x;
+    const float* gp = g + plane * Ho * Wo;
+    const signed char* ip = idx + plane * Ho * Wo;
+    const int HW = H * W;
+    const int beg = blockIdx.y * kChunk, end = min(HW, beg + kChunk);
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        const int ih = i / W, iw = i - ih * W;
+        float acc = 0.f;
+        const int oh_lo = ih / 2, oh_hi = min(Ho - 1, (ih + 1) / 2);
+        const int ow_lo = iw / 2, ow_hi = min(Wo - 1, (iw + 1) / 2);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int r = ih - (2 * oh - 1), s = iw - (2 * ow - 1);
+                if (ip[oh * Wo + ow] == r * 3 + s) acc += gp[oh * Wo + ow];
+            }
+        dx[plane * HW + i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive average pool (windows [floor(o*I/O), ceil((o+1)*I/O)) ) — tiny maps only (PPM).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ap_start(int o, int I, int O) { return (o * I) / O; }
+__device__ __forceinline__ int ap_end(int o, int I, int O) { return ((o + 1) * I + O - 1) / O; }
+
+__global__ void __launch_bounds__(256) adaptive_avgpool_fwd_kernel(const float* __restrict__ x,
+                                                                   float* __restrict__ y, int NC,
+                                                                   int H, int W, int OH, int OW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC * OH * OW) return;
+    const int ow = i % OW, oh = (i / OW) % OH, p = i / (OW * OH);
+    const int hs = ap_start(oh, H, OH), he = ap_end(oh, H, OH);
+    const int ws = ap_start(ow, W, OW), we = ap_end(ow, W, OW);
+    const float* xp = x + (size_t)p * H * W;
+    float s = 0.f;
+    for (int h = hs; h < he; ++h)
+        for (int w = ws; w < we; ++w) s += xp[h * W + w];
+    y[i] = s / (float)((he - hs) * (we - ws));
+}
+
+__global__ void __launch_bounds__(256) adaptive_avgpool_bwd_kernel(const float* __restrict__ g,
+                                                                   float* __restrict__ dx, int NC,
+                                                                   int H, int W, int OH, int OW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC * H * W) return;
+    const int w = i % W, h = (i / W) % H, p = i / (W * H);
+    const float* gp = g + (size_t)p * OH * OW;
+    float s = 0.f;
+    for (int oh = 0; oh < OH; ++oh) {
+        const int hs = ap_start(oh, H, OH), he = ap_end(oh, H, OH);
+        if (h < hs || h >= he) continue;
+        for (int ow = 0; ow < OW; ++ow) {
+            const int ws = ap_start(ow, W, OW), we = ap_end(ow, W, OW);
+            if (w < ws || w >= we) continue;
+            s += gp[oh * OW + ow] / (float)((he - hs) * (we - ws));
+        }
+    }
+    dx[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// nearest resize of y[N,C,h,w] into channels [c_off, c_off+C) of out[N,Ctot,H,W]  (PPM cat).
+// src index = min(floor(dst * (float)in/out), in-1), exactly ATen's nearest rule.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+__global__ void __launch_bounds__(256) nearest_into_fwd_kernel(const float* __restrict__ y,
+                                                               float* __restrict__ out, int N, int C,
+                                                               int h, int w, int Ctot, int c_off,
+                                                               int H, int W) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C * H * W) return;
+    const int x = i % W, yy = (i / W) % H, c = (i / (W * H)) % C, n = i / (W * H * C);
+    const int sy = nearest_src(yy, h, H), sx = nearest_src(x, w, W);
+    out[(((size_t)n * Ctot + c_off + c) * H + yy) * W + x] = y[(((size_t)n * C + c) * h + sy) * w + sx];
+}
+
+__global__ void __launch_bounds__(256) nearest_into_bwd_kernel(const float* __restrict__ g,
+                                                               float* __restrict__ dy, int N, int C,
+                                                               int h, int w, int Ctot, int c_off,
+                                                               int H, int W) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C * h * w) return;
+    const int q = i % w, p = (i / w) % h, c = (i / (w * h)) % C, n = i / (w * h * C);
+    const float* gp = g + ((size_t)n * Ctot + c_off + c) * H * W;
+    if (h == H && w == W) {   // identity resize: plain strided copy (the `x` branch of the PPM cat)
+        dy[i] = gp[p * W + q];
+        return;
+    }
+    float s = 0.f;
+    for (int yy = 0; yy < H; ++yy) {
+        if (nearest_src(yy, h, H) != p) continue;
+        for (int x = 0; x < W; ++x)
+            if (nearest_src(x, w, W) == q) s += gp[yy * W + x];
+    }
+    dy[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// learned 2x upsample: y = dwconv3x3(nearest2x(x)) + bias (+ skip)   — write-bandwidth bound
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) upsample_fwd_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ wgt,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ skip,
+                                                           float* __restrict__ y, int C, int H,
+                                                           int W) {
+    const size_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const int H2 = 2 * H, W2 = 2 * W, HW2 = H2 * W2;
+    const float* xp = x + plane * H * W;
+    float k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = wgt[c * 9 + j];
+    const float b = bias ? bias[c] : 0.f;
+    const int beg = blockIdx.y * kChunk, end = min(HW2, beg + kChunk);
+    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
+        const int oh = i / W2, ow0 = i - oh * W2;
+        float o[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) o[v] = b;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int uy = oh + r - 1;
+            if (uy < 0 || uy >= H2) continue;
+            const float* row = xp + (uy >> 1) * W;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ux = ow0 + v + s - 1;
+                    if (ux >= 0 && ux < W2) o[v] += k[r * 3 + s] * row[ux >> 1];
+                }
+            }
+        }
+        if (skip) {
+            float sk[V];
+            vload<V>(skip + plane * HW2 + i, sk);
+#pragma unroll
+            for (int v = 0; v < V; ++v) o[v] += sk[v];
+        }
+        vstore<V>(y + plane * HW2 + i, o);
+    }
+}
+
+__global__ void __launch_bounds__(256) upsample_bwd_dx_kernel(const float* __restrict__ g,
+                                                              const float* __restrict__ wgt,
+                                                              float* __restrict__ dx, int C, int H,
+                                                              int W) {
+    const size_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* gp = g + plane * H2 * W2;
+    float k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = wgt[c * 9 + j];
+    // effective 4x4 stencil on g: taps a,b in {-1,0,1,2}; R(-1)={2}, R(0)={1,2}, R(1)={0,1}, R(2)={0}
+    float e[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bool rin = (a == 0) ? (r == 2) : (a == 1) ? (r >= 1) : (a == 2) ? (r <= 1) : (r == 0);
+                if (!rin) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const bool qin = (bb == 0) ? (q == 2) : (bb == 1) ? (q >= 1) : (bb == 2) ? (q <= 1) : (q == 0);
+                    if (qin) s += k[r * 3 + q];
+                }
+            }
+            e[a][bb] = s;
+        }
+    const int HW = H * W;
+    const int beg = blockIdx.y * kChunk, end = min(HW, beg + kChunk);
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        const int ih = i / W, iw = i - ih * W;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oh = 2 * ih + a - 1;
+            if (oh < 0 || oh >= H2) continue;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int ow = 2 * iw + bb - 1;
+                if (ow >= 0 && ow < W2) s += e[a][bb] * gp[oh * W2 + ow];
+            }
+        }
+        dx[plane * HW + i] = s;
+    }
+}
+
+// dw[c][r][s] += sum g*U ; db[c] += sum g.  grid (C, splits over n)
+__global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ x,
+                                                             float* __restrict__ dw,
+                                                             float* __restrict__ db, int N, int C,
+                                                             int H, int W) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, S = gridDim.y;
+    const int H2 = 2 * H, W2 = 2 * W, HW2 = H2 * W2;
+    float acc[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) acc[j] = 0.f;
+    for (int n = blockIdx.y; n < N; n += S) {
+        const float* gp = g + ((size_t)n * C + c) * HW2;
+        const float* xp = x + ((size_t)n * C + c) * H * W;
+        for (int i = threadIdx.x; i < HW2; i += 256) {
+            const int oh = i / W2, ow = i - oh * W2;
+            const float gv = gp[i];
+            acc[9] += gv;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int uy = oh + r - 1;
+                if (uy < 0 || uy >= H2) continue;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ux = ow + s - 1;
+                    if (ux >= 0 && ux < W2) acc[r * 3 + s] += gv * xp[(uy >> 1) * W + (ux >> 1)];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const float t = block_reduce_sum_256<float>(acc[j], red);
+        if (threadIdx.x == 0) {
+            if (j < 9) atomicAdd(&dw[c * 9 + j], t);
+            else if (db) atomicAdd(&db[c], t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// global average pool of two tensors; blend out = a*xr + b*xd and its backward passes
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) gap2_kernel(const float* __restrict__ xr,
+                                                   const float* __restrict__ xd,
+                                                   float* __restrict__ sr, float* __restrict__ sd,
+                                                   int HW) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * HW;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+        float v[V];
+        vload<V>(xr + base + i, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a += v[j];
+        if (xd) {
+            vload<V>(xd + base + i, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) b += v[j];
+        }
+    }
+    const float ta = block_reduce_sum_256<float>(a, red);
+    const float tb = block_reduce_sum_256<float>(b, red);
+    if (threadIdx.x == 0) {
+        sr[blockIdx.x] = ta / (float)HW;
+        if (xd) sd[blockIdx.x] = tb / (float)HW;
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) axpby_fwd_kernel(const float* __restrict__ xr,
+                                                        const float* __restrict__ xd,
+                                                        const float* __restrict__ a,
+                                                        const float* __restrict__ b,
+                                                        float* __restrict__ out, int HW) {
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float ca = a[blockIdx.x], cb = b[blockIdx.x];
+    const int beg = blockIdx.y * kChunk, end = min(HW, beg + kChunk);
+    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
+        float r[V], d[V];
+        vload<V>(xr + base + i, r);
+        vload<V>(xd + base + i, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) r[j] = ca * r[j] + cb * d[j];
+        vstore<V>(out + base + i, r);
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) axpby_bwd_reduce_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ xr,
+                                                               const float* __restrict__ xd,
+                                                               float* __restrict__ da,
+                                                               float* __restrict__ db, int HW) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * HW;
+    float sa = 0.f, sb = 0.f;
+    for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+        float gv[V], r[V], d[V];
+        vload<V>(g + base + i, gv);
+        vload<V>(xr + base + i, r);
+        vload<V>(xd + base + i, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { sa += gv[j] * r[j]; sb += gv[j] * d[j]; }
+    }
+    const float ta = block_reduce_sum_256<float>(sa, red);
+    const float tb = block_reduce_sum_256<float>(sb, red);
+    if (threadIdx.x == 0) { da[blockIdx.x] = ta; db[blockIdx.x] = tb; }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) axpby_bwd_apply_kernel(
+    const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ ca, const float* __restrict__ cb, float cscale,
+    float* __restrict__ dxr, float* __restrict__ dxd, int HW) {
+    const size_t base = (size_t)blockIdx.x * HW;
+    const float fa = a[blockIdx.x], fb = b[blockIdx.x];
+    const float oa = ca ? ca[blockIdx.x] * cscale : 0.f, ob = cb ? cb[blockIdx.x] * cscale : 0.f;
+    const int beg = blockIdx.y * kChunk, end = min(HW, beg + kChunk);
+    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
+        float gv[V], r[V], d[V];
+        vload<V>(g + base + i, gv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { r[j] = fa * gv[j] + oa; d[j] = fb * gv[j] + ob; }
+        vstore<V>(dxr + base + i, r);
+        vstore<V>(dxd + base + i, d);
+    }
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int dynmm_maxpool3x3s2_fwd(const float* x, float* y, signed char* idx, int N, int C, int H,
+                                      int W, int Ho, int Wo, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
+    if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return DYNMM_EINVAL;
+    dim3 grid(N * C, plane_chunks(Ho * Wo, kChunk));
+    hipLaunchKernelGGL(maxpool_fwd_kernel, grid, dim3(256), 0, ST, x, y, idx, H, W, Ho, Wo);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_maxpool3x3s2_bwd(const float* g, const signed char* idx, float* dx, int N, int C,
+                                      int H, int W, int Ho, int Wo, void* stream) {
+    if (!g || !idx || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
+    dim3 grid(N * C, plane_chunks(H * W, kChunk));
+    hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_adaptive_avgpool_fwd(const float* x, float* y, int NC, int H, int W, int OH,
+                                          int OW, void* stream) {
+    if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, dim3(ceil_div(NC * OH * OW, 256)), dim3(256), 0,
+                       ST, x, y, NC, H, W, OH, OW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_adaptive_avgpool_bwd(const float* g, float* dx, int NC, int H, int W, int OH,
+                                          int OW, void* stream) {
+    if (!g || !dx || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(ceil_div(NC * H * W, 256)), dim3(256), 0,
+                       ST, g, dx, NC, H, W, OH, OW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_nearest_into_fwd(const float* y, float* out, int N, int C, int h, int w,
+                                      int Ctot, int c_off, int H, int W, void* stream) {
+    if (!y || !out || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
+    if (c_off < 0 || c_off + C > Ctot) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(nearest_into_fwd_kernel, dim3(ceil_div(N * C * H * W, 256)), dim3(256), 0, ST,
+                       y, out, N, C, h, w, Ctot, c_off, H, W);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_nearest_into_bwd(const float* g_out, float* dy, int N, int C, int h, int w,
+                                      int Ctot, int c_off, int H, int W, void* stream) {
+    if (!g_out || !dy || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
+    if (c_off < 0 || c_off + C > Ctot) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(nearest_into_bwd_kernel, dim3(ceil_div(N * C * h * w, 256)), dim3(256), 0, ST,
+                       g_out, dy, N, C, h, w, Ctot, c_off, H, W);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const float* b,
+                                          const float* skip, float* y, int N, int C, int H, int W,
+                                          void* stream) {
+    if (!x || !w || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
+    dim3 grid(N * C, plane_chunks(4 * H * W, kChunk));
+    // V=4: four consecutive outputs of one row per lane (2W % 4 == 0 keeps a quad inside its row)
+    if ((2 * W) % 4 == 0 && can_vec4(4 * H * W, {skip, y}))
+        hipLaunchKernelGGL(upsample_fwd_kernel<4>, grid, dim3(256), 0, ST, x, w, b, skip, y, C, H, W);
+    else
+        hipLaunchKernelGGL(upsample_fwd_kernel<1>, grid, dim3(256), 0, ST, x, w, b, skip, y, C, H, W);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const float* w, float* dx,
+                                          float* dw, float* db, int N, int C, int H, int W,
+                                          void* stream) {
+    if (!g || !w || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
+    if (dx) {
+        dim3 grid(N * C, plane_chunks(H * W, kChunk));
+        hipLaunchKernelGGL(upsample_bwd_dx_kernel, grid, dim3(256), 0, ST, g, w, dx, C, H, W);
+        DYNMM_LAUNCH_CHECK();
+    }
+    if (dw) {
+        if (!x) return DYNMM_EINVAL;
+        DYNMM_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * 9 * C, ST));
+        if (db) DYNMM_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, ST));
+        int S = 2048 / C;
+        if (S < 1) S = 1;
+        if (S > N) S = N;
+        hipLaunchKernelGGL(upsample_bwd_w_kernel, dim3(C, S), dim3(256), 0, ST, g, x, dw, db, N, C, H, W);
+        DYNMM_LAUNCH_CHECK();
+    }
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_gap2_fwd(const float* xr, const float* xd, float* sr, float* sd, int NC, int HW,
+                              void* stream) {
+    if (!xr || !sr || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
+    if (xd && !sd) return DYNMM_EINVAL;
+    if (can_vec4(HW, {xr, xd}))
+        hipLaunchKernelGGL(gap2_kernel<4>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW);
+    else
+        hipLaunchKernelGGL(gap2_kernel<1>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_axpby_fwd(const float* xr, const float* xd, const float* a, const float* b,
+                               float* out, int NC, int HW, void* stream) {
+    if (!xr || !xd || !a || !b || !out || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
+    dim3 grid(NC, plane_chunks(HW, kChunk));
+    if (can_vec4(HW, {xr, xd, out}))
+        hipLaunchKernelGGL(axpby_fwd_kernel<4>, grid, dim3(256), 0, ST, xr, xd, a, b, out, HW);
+    else
+        hipLaunchKernelGGL(axpby_fwd_kernel<1>, grid, dim3(256), 0, ST, xr, xd, a, b, out, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_axpby_bwd_reduce(const float* g, const float* xr, const float* xd, float* da,
+                                      float* db, int NC, int HW, void* stream) {
+    if (!g || !xr || !xd || !da || !db || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
+    if (can_vec4(HW, {g, xr, xd}))
+        hipLaunchKernelGGL(axpby_bwd_reduce_kernel<4>, dim3(NC), dim3(256), 0, ST, g, xr, xd, da, db, HW);
+    else
+        hipLaunchKernelGGL(axpby_bwd_reduce_kernel<1>, dim3(NC), dim3(256), 0, ST, g, xr, xd, da, db, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_axpby_bwd_apply(const float* g, const float* a, const float* b, const float* ca,
+                                     const float* cb, float cscale, float* dxr, float* dxd, int NC,
+                                     int HW, void* stream) {
+    if (!g || !a || !b || !dxr || !dxd || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
+    dim3 grid(NC, plane_chunks(HW, kChunk));
+    if (can_vec4(HW, {g, dxr, dxd}))
+        hipLaunchKernelGGL(axpby_bwd_apply_kernel<4>, grid, dim3(256), 0, ST, g, a, b, ca, cb, cscale, dxr, dxd, HW);
+    else
+        hipLaunchKernelGGL(axpby_bwd_apply_kernel<1>, grid, dim3(256), 0, ST, g, a, b, ca, cb, cscale, dxr, dxd, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}

@@ -1,0 +1,111 @@
+"""ctypes binding of libdynmm_hip.so (the C ABI declared in include/dynmm_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, this module raises.
+The product path never routes through PyTorch ops or the CPU oracle for the work the HIP kernels do.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdynmm_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2}
+
+c_f = C.c_void_p       # device pointers travel as void* (tensor.data_ptr() or None)
+c_i = C.c_int
+c_fl = C.c_float
+c_sz = C.c_size_t
+
+
+class ConvGeom(C.Structure):
+    """dynmm_conv_geom (include/dynmm_hip.h)."""
+    _fields_ = [(n, C.c_int) for n in ('N', 'Ci', 'H', 'W', 'Co', 'Ho', 'Wo',
+                                       'KH', 'KW', 'SH', 'SW', 'PH', 'PW', 'c_split')]
+
+
+_GP = C.POINTER(ConvGeom)
+_PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/dynmm_hip.h one to one
+SIGNATURES = {
+    'dynmm_abi_version': (c_i, []),
+    'dynmm_build_info': (C.c_char_p, []),
+    'dynmm_pack_weight': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_conv2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
+    'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
+    'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),
+    'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
+    'dynmm_act_bwd_bias': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_stats': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_apply': (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f]),
+    'dynmm_bn_bwd_reduce': (c_i, [c_f] * 6 + [c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_bwd_apply': (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_fold': (c_i, [c_f] * 7 + [c_i, c_fl, c_f]),
+    'dynmm_maxpool3x3s2_fwd': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
+    'dynmm_maxpool3x3s2_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
+    'dynmm_adaptive_avgpool_fwd': (c_i, [c_f, c_f] + [c_i] * 5 + [c_f]),
+    'dynmm_adaptive_avgpool_bwd': (c_i, [c_f, c_f] + [c_i] * 5 + [c_f]),
+    'dynmm_nearest_into_fwd': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f]),
+    'dynmm_nearest_into_bwd': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f]),
+    'dynmm_upsample2x_dw3x3_fwd': (c_i, [c_f] * 5 + [c_i] * 4 + [c_f]),
+    'dynmm_upsample2x_dw3x3_bwd': (c_i, [c_f] * 6 + [c_i] * 4 + [c_f]),
+    'dynmm_gap2_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_f]),
+    'dynmm_se_coeff_fwd': (c_i, [c_f, c_f, _PP, c_f, c_i] + [c_f] * 6 + [c_i, c_i, c_i, c_f]),
+    'dynmm_se_coeff_bwd': (c_i, [c_f] * 4 + [_PP, c_f, c_i] + [c_f] * 4 + [_PP, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_axpby_fwd': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
+    'dynmm_axpby_bwd_reduce': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
+    'dynmm_axpby_bwd_apply': (c_i, [c_f] * 5 + [c_fl, c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_gate_head_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_fl, c_i, c_i, c_f]),
+    'dynmm_gate_head_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_fl, c_f]),
+    'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_f]),
+    'dynmm_ce2d_bwd': (c_i, [c_f] * 5 + [c_i, c_i, c_i, c_f]),
+    'dynmm_reduce_slabs': (c_i, [c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_sgd_nesterov': (c_i, [c_f, c_f, c_f, c_sz, c_f, c_fl, c_fl, c_fl, c_f]),
+}
+
+_lib = None
+
+
+class DynmmHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libdynmm_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(['make', '-C', CSRC, '-j8'], check=True)
+    if not os.path.exists(LIB_PATH):
+        raise DynmmHipError(f'build did not produce {LIB_PATH}')
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once) and set ctypes prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DynmmHipError(
+            f'{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). '
+            'Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C dynmm_amd/csrc`.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dynmm_abi_version() != 1:
+        raise DynmmHipError('libdynmm_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        if status <= -1000:
+            raise DynmmHipError(f'{what}: HIP error {-(status + 1000)}')
+        raise DynmmHipError(f'{what}: status {status} '
+                            f'({ {-1: "EINVAL", -2: "EUNSUPPORTED", -3: "EWORKSPACE"}.get(status, "?") })')

@@ -1,0 +1,134 @@
+"""Encoder building blocks.  Modules here are *parameter containers* (ordinary nn.Conv2d /
+nn.BatchNorm2d children so that state_dict keys and shapes equal the reference's,
+FusionDynMM/src/models/resnet.py and model_utils.py) — their own forward is never called; the
+block-level forward below drives the HIP kernels through dynmm_amd.ops.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None):
+    """act(BN(conv(x|x2)) + residual).
+
+    inference (eval, no grad): ONE kernel — BN folded into the implicit-GEMM epilogue.
+    training: conv(+bias) kernel, batch statistics pass, normalise(+residual+act) pass.
+    """
+    if not bn.training and not torch.is_grad_enabled():
+        return ops.conv2d_fused_eval(x, conv.weight, conv.bias, bn, act, residual,
+                                     conv.stride, conv.padding, x2)
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2)
+    return ops.batch_norm_act(y, bn, act, residual)
+
+
+class ConvBNAct(nn.Sequential):
+    """conv (no bias) -> BN -> ReLU; keys '<p>.conv.weight', '<p>.bn.*' (model_utils.py:11-23)."""
+
+    def __init__(self, cin, cout, kernel_size):
+        super().__init__()
+        self.add_module('conv', nn.Conv2d(cin, cout, kernel_size, padding=kernel_size // 2, bias=False))
+        self.add_module('bn', nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        return conv_bn_act(x, self.conv, self.bn, 'relu')
+
+
+class NonBottleneck1D(nn.Module):
+    """ERFNet factorised residual block (resnet.py:87-147): 3x1 -> ReLU -> 1x3 -> BN(eps 1e-3) ->
+    ReLU -> 3x1 -> ReLU -> 1x3 -> BN -> (+identity) -> ReLU; stride is split (s,1)/(1,s)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv3x1_1 = nn.Conv2d(inplanes, planes, (3, 1), stride=(stride, 1), padding=(1, 0))
+        self.conv1x3_1 = nn.Conv2d(planes, planes, (1, 3), stride=(1, stride), padding=(0, 1))
+        self.bn1 = nn.BatchNorm2d(planes, eps=1e-3)
+        self.conv3x1_2 = nn.Conv2d(planes, planes, (3, 1), padding=(1, 0))
+        self.conv1x3_2 = nn.Conv2d(planes, planes, (1, 3), padding=(0, 1))
+        self.bn2 = nn.BatchNorm2d(planes, eps=1e-3)
+        self.downsample = downsample
+
+    def forward(self, x):
+        c = self.conv3x1_1
+        y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu')
+        y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu')
+        c = self.conv3x1_2
+        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu')
+        idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt)
+
+
+class BasicBlock(nn.Module):
+    """Two 3x3 conv + BN, residual, ReLU (resnet.py:42-84)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = conv_bn_act(x, self.conv1, self.bn1, 'relu')
+        idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        return conv_bn_act(y, self.conv2, self.bn2, 'relu', residual=idt)
+
+
+BLOCKS = {'NonBottleneck1D': NonBottleneck1D, 'BasicBlock': BasicBlock}
+LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3)}
+
+
+class ResNetEncoder(nn.Module):
+    """ResNet-18/34 trunk with stage-wise entry points (resnet.py:195-379)."""
+
+    def __init__(self, name, block, input_channels=3):
+        super().__init__()
+        if name not in LAYERS:
+            raise NotImplementedError(f'Only {sorted(LAYERS)} encoders are implemented on the HIP path. Got {name}')
+        if block not in BLOCKS:
+            raise NotImplementedError(f'Block {block} is not implemented')
+        blk = BLOCKS[block]
+        self.conv1 = nn.Conv2d(input_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for j, (planes, n) in enumerate(zip((64, 128, 256, 512), LAYERS[name]), start=1):
+            stride = 1 if j == 1 else 2
+            down = None
+            if stride != 1 or inplanes != planes:
+                down = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False),
+                                     nn.BatchNorm2d(planes))
+            stage = [blk(inplanes, planes, stride, down)] + [blk(planes, planes) for _ in range(n - 1)]
+            setattr(self, f'layer{j}', nn.Sequential(*stage))
+            inplanes = planes
+        self.down_2_channels_out = 64
+        self.down_4_channels_out, self.down_8_channels_out = 64, 128
+        self.down_16_channels_out, self.down_32_channels_out = 256, 512
+        for m in self.modules():           # resnet.py:264-270
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward_first_conv(self, x):
+        return conv_bn_act(x, self.conv1, self.bn1, 'relu')
+
+    def _stage(self, x, j):
+        for blk in getattr(self, f'layer{j}'):
+            x = blk(x)
+        return x
+
+    def forward_layer1(self, x):
+        return self._stage(x, 1)
+
+    def forward_layer2(self, x):
+        return self._stage(x, 2)
+
+    def forward_layer3(self, x):
+        return self._stage(x, 3)
+
+    def forward_layer4(self, x):
+        return self._stage(x, 4)

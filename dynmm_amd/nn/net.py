@@ -1,0 +1,198 @@
+"""Fusion-level DynMM network on the HIP path.
+
+Drop-in for FusionDynMM/src/models/model_skip_mod_globalgate.py: same constructor signature, same
+forward contract `(rgb, depth, test=False, return_weight=False)`, same caller-visible attributes
+(`baseline, ini_stage, hard_gate, temp, save_weight_info, weight_list, flop, depth_enc_flop,
+total_flop`), same methods (`freeze, start_weight, end_weight`) and an identical state_dict
+(907 entries for ResNet-34/NonBottleneck1D/SE-add).  Unlike the reference (…globalgate.py:218-223)
+construction does not touch a GPU; forward requires a HIP device and libdynmm_hip.so.
+"""
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .blocks import ConvBNAct, ResNetEncoder, conv_bn_act
+from .context import get_context_module
+from .decoder import Decoder
+from .fusion import SqueezeAndExciteFusionAdd
+
+
+def DiffSoftmax(logits, tau=1.0, hard=False, dim=-1):
+    """Temperature softmax with optional straight-through arg-max (…globalgate.py:20-30) for callers
+    that use it stand-alone on [N,5,1,1]/[N,5] logits; the model itself uses the fused gate head."""
+    n = logits.shape[0]
+    if logits.dim() < 2 or logits.shape[1] != 5 or logits.numel() != 5 * n or dim not in (1, 1 - logits.dim()):
+        raise NotImplementedError('HIP DiffSoftmax handles [N,5] / [N,5,1,1] logits along dim 1')
+    eye = torch.eye(5, device=logits.device, dtype=torch.float32)
+    tab = torch.zeros(5, device=logits.device, dtype=torch.float32)
+    w, _, _ = ops.gate_head(logits.reshape(n, 5), eye, tab, tau, hard)
+    return w.reshape(logits.shape)
+
+
+class GlobalGate(nn.Module):
+    """cat(rgb, depth) -> conv5x5 s2 -> BN -> tanh -> conv5x5 s2 -> BN -> tanh -> GAP -> 1x1 fc ->
+    DiffSoftmax (…globalgate.py:375-394).  The cat is never materialised (dual-input conv)."""
+
+    def __init__(self, branch_num, hidden_dim=8):
+        super().__init__()
+        if branch_num != 5:
+            raise NotImplementedError('the fused gate head implements the 5-branch global gate')
+        self.bnum = branch_num
+        self.conv = nn.Sequential(
+            nn.Conv2d(128, hidden_dim, 5, stride=2), nn.BatchNorm2d(hidden_dim), nn.Identity(),
+            nn.Conv2d(hidden_dim, hidden_dim, 5, stride=2), nn.BatchNorm2d(hidden_dim), nn.Identity())
+        self.fc = nn.Conv2d(hidden_dim, branch_num, 1, bias=False)
+
+    def features(self, rgb, depth):
+        y = conv_bn_act(rgb, self.conv[0], self.conv[1], 'tanh', x2=depth)
+        y = conv_bn_act(y, self.conv[3], self.conv[4], 'tanh')
+        return ops.adaptive_avg_pool(y, 1)
+
+    def forward(self, rgb, depth, temp=1.0, hard=False, flop_table=None):
+        if flop_table is None:
+            flop_table = torch.zeros(5, device=rgb.device, dtype=torch.float32)
+        weight, _, _ = ops.gate_head(self.features(rgb, depth), self.fc.weight, flop_table, temp, hard)
+        return weight
+
+
+R34_FLOP = [0, 3.27, 7.27, 13.15, 16.02]
+R34_DEPTH_ENC_FLOP = [0.2506752, 3.1113216, 6.9470208, 12.66432, 15.538944]
+R34_TOTAL_FLOP = [22.37101509, 25.23166149, 29.06736069, 34.78465989, 37.65928389]
+OTHER_DEPTH_ENC_FLOP = [0.2506752, 4.39420573, 10.72382115, 19.71582947, 24.679084]
+OTHER_TOTAL_FLOP = [32.5854654, 36.728995928, 43.058611352, 52.050619672, 57.0138742]
+
+
+class SkipGateESANet(nn.Module):
+    def __init__(self, height=480, width=640, num_classes=40, encoder_rgb='resnet34',
+                 encoder_depth='resnet34', encoder_block='NonBottleneck1D',
+                 channels_decoder=None, pretrained_on_imagenet=False,
+                 pretrained_dir='./trained_models/imagenet', activation='relu',
+                 encoder_decoder_fusion='add', context_module='ppm', nr_decoder_blocks=None,
+                 fuse_depth_in_rgb_encoder='add', upsampling='learned-3x3-zeropad', temp=1,
+                 block_rule=None):
+        super().__init__()
+        channels_decoder = [128, 128, 128] if channels_decoder is None else list(channels_decoder)
+        nr_decoder_blocks = [3, 3, 3] if nr_decoder_blocks is None else list(nr_decoder_blocks)
+        if activation.lower() != 'relu':
+            raise NotImplementedError('Only relu is implemented as activation on the HIP path. '
+                                      'Got {}'.format(activation))
+        if upsampling != 'learned-3x3-zeropad':
+            raise NotImplementedError('Only learned-3x3-zeropad upsampling is implemented. Got {}'.format(upsampling))
+        if encoder_decoder_fusion != 'add':
+            raise NotImplementedError('Only encoder_decoder_fusion="add" is implemented')
+        if fuse_depth_in_rgb_encoder not in ('add', 'SE-add'):
+            raise NotImplementedError('fuse_depth_in_rgb_encoder must be "add" or "SE-add"')
+        if pretrained_on_imagenet:
+            warnings.warn('ImageNet weights are not available offline; load a checkpoint with load_state_dict')
+        self.fuse_depth_in_rgb_encoder = fuse_depth_in_rgb_encoder
+        self.block_rule = block_rule if block_rule else [1, 1, 1, 1]
+        self.height, self.width = height, width
+
+        self.encoder_rgb = ResNetEncoder(encoder_rgb, encoder_block, input_channels=3)
+        self.encoder_depth = ResNetEncoder(encoder_depth, encoder_block, input_channels=1)
+        enc = self.encoder_rgb
+        self.channels_decoder_in = enc.down_32_channels_out
+
+        if fuse_depth_in_rgb_encoder == 'SE-add':
+            for j, ch in enumerate((64, enc.down_4_channels_out, enc.down_8_channels_out,
+                                    enc.down_16_channels_out, enc.down_32_channels_out)):
+                setattr(self, f'se_layer{j}', SqueezeAndExciteFusionAdd(ch))
+
+        for j, (cin, cout) in enumerate(((enc.down_4_channels_out, channels_decoder[2]),
+                                         (enc.down_8_channels_out, channels_decoder[1]),
+                                         (enc.down_16_channels_out, channels_decoder[0])), start=1):
+            setattr(self, f'skip_layer{j}', nn.Sequential(*([ConvBNAct(cin, cout, 1)] if cin != cout else [])))
+
+        self.context_module, ch_ctx = get_context_module(context_module, self.channels_decoder_in,
+                                                         channels_decoder[0])
+        self.decoder = Decoder(ch_ctx, channels_decoder, nr_decoder_blocks, num_classes)
+
+        self.temp = temp
+        self.gate_layer = GlobalGate(branch_num=5)
+        self.baseline = False
+        self.ini_stage = False
+        self.hard_gate = False
+        self.save_weight_info = False
+        self.weight_list = torch.Tensor()
+        r34 = encoder_rgb == 'resnet34'
+        # plain attributes, not buffers (…globalgate.py:217-223) — kept out of the state_dict
+        if r34:
+            self.flop = torch.tensor(R34_FLOP)
+        self.depth_enc_flop = torch.tensor(R34_DEPTH_ENC_FLOP if r34 else OTHER_DEPTH_ENC_FLOP)
+        self.total_flop = torch.tensor(R34_TOTAL_FLOP if r34 else OTHER_TOTAL_FLOP)
+        self._tab_cache = {}
+
+    # ---- caller protocol (train.py:141,190-197,284,351; eval.py:64-68) -------------------------
+    def freeze(self):
+        for name, param in self.named_parameters():
+            if 'gate' not in name:
+                param.requires_grad = False
+
+    def start_weight(self):
+        self.save_weight_info = True
+        self.weight_list = torch.Tensor()
+
+    def end_weight(self, print_each=False, print_flop=False):
+        self.save_weight_info = False
+        if print_each:
+            print(self.weight_list)
+        if print_flop and self.weight_list.numel():
+            counts = np.array([(self.weight_list[:, i] == 1).sum().item() for i in range(5)], dtype=float)
+            frac = torch.from_numpy(counts / max(counts.sum(), 1.0)).float()
+            flop1 = (self.depth_enc_flop.cpu() * frac).sum()
+            flop2 = (self.total_flop.cpu() * frac).sum()
+            print(f'Depth Encoder Flop {flop1:.4f}G | Total Flop {flop2:.4f}G')
+        self.weight_list = torch.Tensor()
+
+    def _flop_table(self, device):
+        key = str(device)
+        if key not in self._tab_cache:
+            self._tab_cache[key] = self.depth_enc_flop.detach().to(device=device, dtype=torch.float32).contiguous()
+        return self._tab_cache[key]
+
+    def _se(self, j):
+        return getattr(self, f'se_layer{j}').params8() if self.fuse_depth_in_rgb_encoder == 'SE-add' else None
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, rgb, depth, test=False, return_weight=False):
+        er, ed = self.encoder_rgb, self.encoder_depth
+        tab = self._flop_table(rgb.device)
+        r = er.forward_first_conv(rgb)
+        d = ed.forward_first_conv(depth)
+        fuse = ops.se_fuse_blend(r, d, self._se(0))                 # stem fusion is always on
+        r = ops.max_pool_3x3_s2(fuse)
+        d = ops.max_pool_3x3_s2(d)
+
+        bs = r.shape[0]
+        if self.baseline:                                            # …globalgate.py:264-266
+            onehot = torch.zeros(bs, 5, device=rgb.device)
+            onehot[:, 4] = 1
+            weight, wcum, loss = ops.gate_from_weight(onehot, tab)
+        elif self.ini_stage:                                         # …globalgate.py:267-270 (CPU RNG)
+            onehot = torch.zeros(bs, 5)
+            onehot[torch.arange(bs), torch.randint(0, 5, (bs,))] = 1
+            weight, wcum, loss = ops.gate_from_weight(onehot.to(rgb.device), tab)
+        else:
+            pooled = self.gate_layer.features(r, d)
+            weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate)
+        if self.save_weight_info:
+            self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
+
+        skips = []
+        for j in (1, 2, 3, 4):
+            r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
+            d = getattr(ed, f'forward_layer{j}')(d)
+            # stage j<4: w*rgb + (1-w)*fused with w = sum_{k<j} weight[:,k];  stage 4: w = 1-weight[:,4]
+            fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
+            if j < 4:
+                sk = getattr(self, f'skip_layer{j}')
+                skips.append(sk[0](fuse) if len(sk) else fuse)
+        out = self.context_module(fuse)
+        out = self.decoder([out, skips[2], skips[1], skips[0]])
+
+        if test:
+            return (out, weight) if return_weight else out
+        return out, loss

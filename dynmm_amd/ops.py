@@ -1,0 +1,517 @@
+"""torch.autograd.Function shells over the C ABI (include/dynmm_hip.h).
+
+PyTorch supplies device memory (caching allocator), the current HIP stream and the autograd tape;
+every FLOP and every byte moved on the hot path is done by the kernels in libdynmm_hip.so.  All
+functions require contiguous fp32 tensors on a HIP device and raise otherwise — there is no eager
+fallback.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+
+ACT = L.ACT
+
+
+def _lib():
+    return L.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, name='tensor'):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.DynmmHipError(f'{name} is on {t.device}: the DynMM HIP path needs a HIP (cuda) device; '
+                              'there is no CPU fallback')
+    if t.dtype != torch.float32:
+        raise L.DynmmHipError(f'{name} must be float32, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _geom(x, x2, weight, stride, padding):
+    N, C0, H, W = x.shape
+    Ci = C0 + (x2.shape[1] if x2 is not None else 0)
+    Co, Ciw, KH, KW = weight.shape
+    if Ciw != Ci:
+        raise L.DynmmHipError(f'conv2d: weight expects {Ciw} input channels, got {Ci}')
+    SH, SW = stride
+    PH, PW = padding
+    Ho = (H + 2 * PH - KH) // SH + 1
+    Wo = (W + 2 * PW - KW) // SW + 1
+    g = L.ConvGeom(N, Ci, H, W, Co, Ho, Wo, KH, KW, SH, SW, PH, PW, C0)
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, stride, padding, act):
+        lib = _lib()
+        st = _stream()
+        x, x2, weight, bias = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight'), _chk(bias, 'bias')
+        g = _geom(x, x2, weight, stride, padding)
+        K = g.Ci * g.KH * g.KW
+        need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        wp = torch.empty(K * g.Co, device=x.device, dtype=torch.float32)
+        wpd = torch.empty(K * g.Co, device=x.device, dtype=torch.float32) if need_dx else None
+        L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
+        y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=x.device, dtype=torch.float32)
+        L.check(lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
+                                     C.byref(g), act, st), 'conv2d_fwd')
+        ctx.geom = g
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.has_x2 = x2 is not None
+        ctx.save_for_backward(x, x2, wpd, y if act != L.ACT_NONE else None)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        st = _stream()
+        x, x2, wpd, y = ctx.saved_tensors
+        g = ctx.geom
+        gy = _chk(gy, 'grad')
+        dbias = None
+        if ctx.act != L.ACT_NONE or ctx.has_bias:
+            ge = torch.empty_like(gy) if ctx.act != L.ACT_NONE else None
+            dbias = torch.empty(g.Co, device=gy.device, dtype=torch.float32) if ctx.has_bias else None
+            L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), _p(dbias), g.N, g.Co, g.Ho * g.Wo,
+                                           ctx.act, st), 'act_bwd_bias')
+            if ge is not None:
+                gy = ge
+        dx = dx2 = None
+        if wpd is not None:
+            dx = torch.empty_like(x)
+            dx2 = torch.empty_like(x2) if x2 is not None else None
+            L.check(lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), None, _p(dx), _p(dx2), C.byref(g), st),
+                    'conv2d_dgrad')
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty(ctx.wshape, device=gy.device, dtype=torch.float32)
+            nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
+            ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
+            L.check(lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes, C.byref(g), st),
+                    'conv2d_wgrad')
+        return dx, dx2, dw, dbias, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None):
+    """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable."""
+    return _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act])
+
+
+def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=1, padding=0, x2=None):
+    """Inference-only: conv + folded eval-mode BatchNorm + residual + activation in ONE kernel.
+    `bn` is None (plain bias) or an nn.BatchNorm2d holding running statistics."""
+    lib = _lib()
+    st = _stream()
+    x, x2, weight = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight')
+    residual = _chk(residual, 'residual')
+    g = _geom(x, x2, weight, _pair(stride), _pair(padding))
+    K = g.Ci * g.KH * g.KW
+    dev = x.device
+    wp = torch.empty(K * g.Co, device=dev, dtype=torch.float32)
+    L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
+    scale = shift = None
+    if bn is not None:
+        scale = torch.empty(g.Co, device=dev, dtype=torch.float32)
+        shift = torch.empty(g.Co, device=dev, dtype=torch.float32)
+        L.check(lib.dynmm_bn_fold(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                  _p(conv_bias), _p(scale), _p(shift), g.Co, bn.eps, st), 'bn_fold')
+    else:
+        shift = _chk(conv_bias, 'bias')
+    y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=dev, dtype=torch.float32)
+    L.check(lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual), _p(y),
+                                 C.byref(g), ACT[act], st), 'conv2d_fwd')
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm (+ residual + activation)
+# ------------------------------------------------------------------------------------------------
+class _BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act):
+        lib = _lib()
+        st = _stream()
+        x, residual = _chk(x, 'x'), _chk(residual, 'residual')
+        N, Cc, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        sums = None
+        if training:
+            sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
+            L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, st), 'bn_stats')
+        mean = torch.empty(Cc, device=dev, dtype=torch.float32)
+        invstd = torch.empty(Cc, device=dev, dtype=torch.float32)
+        y = torch.empty_like(x)
+        L.check(lib.dynmm_bn_apply(_p(x), _p(sums), _p(gamma), _p(beta), _p(running_mean),
+                                   _p(running_var), _p(mean), _p(invstd), _p(residual), _p(y),
+                                   N, Cc, HW, eps, momentum, int(training), act, st), 'bn_apply')
+        ctx.act = act
+        ctx.training = training
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        st = _stream()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        gy = _chk(gy, 'grad')
+        N, Cc, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
+        L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(sums),
+                                        N, Cc, HW, ctx.act, st), 'bn_bwd_reduce')
+        dx = torch.empty_like(x)
+        need_res = ctx.has_res and ctx.needs_input_grad[5]
+        dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None
+        dgamma = torch.empty(Cc, device=dev, dtype=torch.float32)
+        dbeta = torch.empty(Cc, device=dev, dtype=torch.float32)
+        L.check(lib.dynmm_bn_bwd_apply(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                                       _p(dx), _p(dres), _p(dgamma), _p(dbeta), N, Cc, HW,
+                                       int(ctx.training), ctx.act, st), 'bn_bwd_apply')
+        if need_res and dres is None:
+            dres = gy            # no activation: the residual branch receives the gradient unchanged
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def batch_norm_act(x, bn, act=None, residual=None, training=None):
+    """act(BatchNorm2d(x) + residual) using the parameters/buffers of the nn.BatchNorm2d `bn`."""
+    training = bn.training if training is None else training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
+                               bool(training), float(bn.momentum), float(bn.eps), ACT[act])
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / resampling
+# ------------------------------------------------------------------------------------------------
+class _MaxPool3x3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib()
+        x = _chk(x, 'x')
+        N, Cc, H, W = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty((N, Cc, Ho, Wo), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Cc, Ho, Wo), device=x.device, dtype=torch.int8)
+        L.check(lib.dynmm_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), N, Cc, H, W, Ho, Wo, _stream()), 'maxpool_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, Cc, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        (idx,) = ctx.saved_tensors
+        N, Cc, H, W, Ho, Wo = ctx.shape
+        gy = _chk(gy, 'grad')
+        dx = torch.empty((N, Cc, H, W), device=gy.device, dtype=torch.float32)
+        L.check(lib.dynmm_maxpool3x3s2_bwd(_p(gy), _p(idx), _p(dx), N, Cc, H, W, Ho, Wo, _stream()), 'maxpool_bwd')
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPool3x3s2.apply(x)
+
+
+class _AdaptiveAvgPool(Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        lib = _lib()
+        x = _chk(x, 'x')
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, oh, ow), device=x.device, dtype=torch.float32)
+        if oh == 1 and ow == 1:   # global pool: one workgroup per plane
+            L.check(lib.dynmm_gap2_fwd(_p(x), None, _p(y), None, N * Cc, H * W, _stream()), 'gap_fwd')
+        else:
+            L.check(lib.dynmm_adaptive_avgpool_fwd(_p(x), _p(y), N * Cc, H, W, oh, ow, _stream()), 'aap_fwd')
+        ctx.shape = (N, Cc, H, W, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib()
+        N, Cc, H, W, oh, ow = ctx.shape
+        gy = _chk(gy, 'grad')
+        dx = torch.empty((N, Cc, H, W), device=gy.device, dtype=torch.float32)
+        L.check(lib.dynmm_adaptive_avgpool_bwd(_p(gy), _p(dx), N * Cc, H, W, oh, ow, _stream()), 'aap_bwd')
+        return dx, None, None
+
+
+def adaptive_avg_pool(x, out_hw):
+    oh, ow = _pair(out_hw)
+    return _AdaptiveAvgPool.apply(x, oh, ow)
+
+
+class _NearestConcat(Function):
+    """cat([x, nearest(y_1, size(x)), nearest(y_2, size(x)), ...], dim=1)."""
+
+    @staticmethod
+    def forward(ctx, x, *ys):
+        lib = _lib()
+        st = _stream()
+        x = _chk(x, 'x')
+        ys = [_chk(y, 'y') for y in ys]
+        N, C0, H, W = x.shape
+        Ctot = C0 + sum(y.shape[1] for y in ys)
+        out = torch.empty((N, Ctot, H, W), device=x.device, dtype=torch.float32)
+        off = 0
+        ctx.parts = []
+        for t in [x] + ys:
+            _, Cc, h, w = t.shape
+            L.check(lib.dynmm_nearest_into_fwd(_p(t), _p(out), N, Cc, h, w, Ctot, off, H, W, st), 'nearest_into_fwd')
+            ctx.parts.append((Cc, h, w, off))
+            off += Cc
+        ctx.dims = (N, Ctot, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        st = _stream()
+        g = _chk(g, 'grad')
+        N, Ctot, H, W = ctx.dims
+        outs = []
+        for i, (Cc, h, w, off) in enumerate(ctx.parts):
+            if not ctx.needs_input_grad[i]:
+                outs.append(None)
+                continue
+            d = torch.empty((N, Cc, h, w), device=g.device, dtype=torch.float32)
+            L.check(lib.dynmm_nearest_into_bwd(_p(g), _p(d), N, Cc, h, w, Ctot, off, H, W, st), 'nearest_into_bwd')
+            outs.append(d)
+        return tuple(outs)
+
+
+def nearest_concat(x, *ys):
+    return _NearestConcat.apply(x, *ys)
+
+
+class _Upsample2xDw(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip):
+        lib = _lib()
+        x, weight, bias, skip = _chk(x, 'x'), _chk(weight, 'weight'), _chk(bias, 'bias'), _chk(skip, 'skip')
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        L.check(lib.dynmm_upsample2x_dw3x3_fwd(_p(x), _p(weight), _p(bias), _p(skip), _p(y), N, Cc, H, W,
+                                               _stream()), 'upsample_fwd')
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.has_skip = skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        x, weight = ctx.saved_tensors
+        g = _chk(g, 'grad')
+        N, Cc, H, W = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty(Cc, device=g.device, dtype=torch.float32) if (ctx.has_bias and dw is not None) else None
+        L.check(lib.dynmm_upsample2x_dw3x3_bwd(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), N, Cc, H, W,
+                                               _stream()), 'upsample_bwd')
+        return dx, dw, db, (g if ctx.has_skip else None)
+
+
+def upsample2x_dw3x3(x, weight, bias, skip=None):
+    """Learned 2x upsample (nearest + depthwise 3x3 + bias) fused with the decoder's skip add."""
+    return _Upsample2xDw.apply(x, weight, bias, skip)
+
+
+# ------------------------------------------------------------------------------------------------
+# SE fusion + gated blend
+# ------------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (C.c_void_p * 8)(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+class _SEFuseBlend(Function):
+    """out = wc*rgb + (1-wc)*(SE_rgb(rgb) + SE_depth(depth))   ('add' mode: SE = identity).
+    wc = wcum[:, col] (per-sample scalar) or 0 when wcum is None."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, wcum, col, use_se, *params):
+        lib = _lib()
+        st = _stream()
+        rgb, depth = _chk(rgb, 'rgb'), _chk(depth, 'depth')
+        N, Cc, H, W = rgb.shape
+        HW = H * W
+        dev = rgb.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        wc_ptr, wc_stride = None, 0
+        if wcum is not None:
+            wcum = _chk(wcum, 'wcum')
+            wc_stride = wcum.shape[1]
+            wc_ptr = wcum.data_ptr() + 4 * col
+        sr = sd = hr = hd = gr = gd = None
+        parr = None
+        if use_se:
+            params = [_chk(p, 'se param') for p in params]
+            parr = _ptr_array(params)
+            sr, sd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            L.check(lib.dynmm_gap2_fwd(_p(rgb), _p(depth), _p(sr), _p(sd), N * Cc, HW, st), 'gap2')
+            hr, hd = torch.empty((N, Cc // 16), **f32), torch.empty((N, Cc // 16), **f32)
+            gr, gd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        a, b = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_se_coeff_fwd(_p(sr), _p(sd), parr, wc_ptr, wc_stride, _p(a), _p(b),
+                                       _p(hr), _p(hd), _p(gr), _p(gd), N, Cc, int(use_se), st), 'se_coeff_fwd')
+        out = torch.empty_like(rgb)
+        L.check(lib.dynmm_axpby_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(out), N * Cc, HW, st), 'axpby_fwd')
+        ctx.use_se = use_se
+        ctx.col = col
+        ctx.n_params = len(params)
+        ctx.save_for_backward(rgb, depth, wcum, a, b, sr, sd, hr, hd, gr, gd, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        st = _stream()
+        rgb, depth, wcum, a, b, sr, sd, hr, hd, gr, gd = ctx.saved_tensors[:11]
+        params = list(ctx.saved_tensors[11:])
+        g = _chk(g, 'grad')
+        N, Cc, H, W = rgb.shape
+        HW = H * W
+        f32 = dict(device=g.device, dtype=torch.float32)
+        da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_axpby_bwd_reduce(_p(g), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, HW, st), 'axpby_bwd_reduce')
+        dparams = [None] * ctx.n_params
+        dsr = dsd = None
+        parr = dparr = None
+        if ctx.use_se:
+            dparams = [torch.empty_like(p) for p in params]
+            parr, dparr = _ptr_array(params), _ptr_array(dparams)
+            dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        dwcum = None
+        wc_ptr, wc_stride, dwc_ptr = None, 0, None
+        if wcum is not None:
+            wc_stride = wcum.shape[1]
+            wc_ptr = wcum.data_ptr() + 4 * ctx.col
+            if ctx.needs_input_grad[2]:
+                dwcum = torch.zeros_like(wcum)
+                dwc_ptr = dwcum.data_ptr() + 4 * ctx.col
+        L.check(lib.dynmm_se_coeff_bwd(_p(da), _p(db), _p(sr), _p(sd), parr, wc_ptr, wc_stride,
+                                       _p(hr), _p(hd), _p(gr), _p(gd), dparr, _p(dsr), _p(dsd),
+                                       dwc_ptr, wc_stride, N, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
+        drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
+        L.check(lib.dynmm_axpby_bwd_apply(_p(g), _p(a), _p(b), _p(dsr), _p(dsd), 1.0 / HW,
+                                          _p(drgb), _p(ddepth), N * Cc, HW, st), 'axpby_bwd_apply')
+        return (drgb, ddepth, dwcum, None, None, *dparams)
+
+
+def se_fuse_blend(rgb, depth, se_params=None, wcum=None, col=0):
+    """se_params: None ('add' fusion) or the 8 tensors (W1r,b1r,W2r,b2r,W1d,b1d,W2d,b2d)."""
+    use_se = se_params is not None
+    params = tuple(se_params) if use_se else ()
+    return _SEFuseBlend.apply(rgb, depth, wcum, col, use_se, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# gate head
+# ------------------------------------------------------------------------------------------------
+class _GateHead(Function):
+    @staticmethod
+    def forward(ctx, pooled, fc, flop_table, temp, hard):
+        lib = _lib()
+        pooled, fc = _chk(pooled, 'pooled'), _chk(fc, 'fc')
+        N = pooled.shape[0]
+        J = pooled.numel() // N
+        f32 = dict(device=pooled.device, dtype=torch.float32)
+        weight, wcum, soft = torch.empty((N, 5), **f32), torch.empty((N, 4), **f32), torch.empty((N, 5), **f32)
+        loss = torch.empty((), **f32)
+        L.check(lib.dynmm_gate_head_fwd(_p(pooled), _p(fc), _p(weight), _p(wcum), _p(soft), _p(loss),
+                                        _p(flop_table), N, J, float(temp), int(hard), 0, _stream()), 'gate_head_fwd')
+        ctx.temp = float(temp)
+        ctx.save_for_backward(pooled, fc, soft, flop_table)
+        return weight, wcum, loss
+
+    @staticmethod
+    def backward(ctx, d_weight, d_wcum, d_loss):
+        lib = _lib()
+        pooled, fc, soft, flop_table = ctx.saved_tensors
+        N = pooled.shape[0]
+        J = pooled.numel() // N
+        d_weight, d_wcum, d_loss = _chk(d_weight), _chk(d_wcum), _chk(d_loss)
+        d_pooled = torch.empty_like(pooled)
+        d_fc = torch.empty_like(fc)
+        L.check(lib.dynmm_gate_head_bwd(_p(d_weight), _p(d_wcum), _p(d_loss), _p(pooled), _p(fc), _p(soft),
+                                        _p(flop_table), _p(d_pooled), _p(d_fc), N, J, ctx.temp, _stream()),
+                'gate_head_bwd')
+        return d_pooled, d_fc, None, None, None
+
+
+def gate_head(pooled, fc_weight, flop_table, temp, hard):
+    """(weight[N,5], wcum[N,4], flop_loss) from the pooled gate features."""
+    return _GateHead.apply(pooled, fc_weight, flop_table, temp, hard)
+
+
+def gate_from_weight(weight, flop_table):
+    """baseline / ini_stage: weight is given (constant one-hots); returns (weight, wcum, flop_loss)."""
+    lib = _lib()
+    weight = _chk(weight, 'weight')
+    N = weight.shape[0]
+    f32 = dict(device=weight.device, dtype=torch.float32)
+    wcum, soft, loss = torch.empty((N, 4), **f32), torch.empty((N, 5), **f32), torch.empty((), **f32)
+    L.check(lib.dynmm_gate_head_fwd(None, None, _p(weight), _p(wcum), _p(soft), _p(loss), _p(flop_table),
+                                    N, 0, 1.0, 0, 1, _stream()), 'gate_head_fwd(mode 1)')
+    return weight, wcum, loss
+
+
+# ------------------------------------------------------------------------------------------------
+# weighted 2-D cross entropy (caller of the path)
+# ------------------------------------------------------------------------------------------------
+class _CrossEntropy2d(Function):
+    @staticmethod
+    def forward(ctx, x, target_u8, class_weight):
+        lib = _lib()
+        x, class_weight = _chk(x, 'logits'), _chk(class_weight, 'class_weight')
+        N, Cc, H, W = x.shape
+        acc = torch.empty(2, device=x.device, dtype=torch.float64)
+        L.check(lib.dynmm_ce2d_fwd(_p(x), _p(target_u8), _p(class_weight), _p(acc), N, Cc, H * W, _stream()), 'ce2d_fwd')
+        ctx.save_for_backward(x, target_u8, class_weight, acc)
+        return (acc[0] / acc[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        x, target_u8, class_weight, acc = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        gscale = (g.double() / acc[1]).float().reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        L.check(lib.dynmm_ce2d_bwd(_p(x), _p(target_u8), _p(class_weight), _p(gscale), _p(dx), N, Cc, H * W,
+                                   _stream()), 'ce2d_bwd')
+        return dx, None, None
+
+
+def cross_entropy_2d(logits, target, class_weight):
+    """sum_px w[t]*CE / sum_px w[t] with target 0 = void (FusionDynMM/src/utils.py:34-50)."""
+    t = target if target.dtype == torch.uint8 else target.to(torch.uint8)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return _CrossEntropy2d.apply(logits, t, class_weight)

@@ -1,0 +1,201 @@
+/*
+ * dynmm_hip.h — C ABI of libdynmm_hip.so: the MI355X (gfx950) kernels behind the fusion-level DynMM
+ * hot path (dual ResNet-34 RGB+depth encoders, gated SE fusion, global gate, PPM, ESANet decoder).
+ *
+ * The reference (zihuixue/DynMM, FusionDynMM/src) has no FFI: its device work is issued through
+ * ATen.  Each entry point below therefore cites the *reference operation* (file:line under
+ * /root/reference/FusionDynMM) whose ATen call sequence it replaces; INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - all tensors are fp32, NCHW, contiguous, device pointers owned by the caller (PyTorch's
+ *     caching allocator); the library allocates nothing and keeps no state;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising, so calls are capturable in a hipGraph;
+ *   - return value: 0 on success, a negative DYNMM_E* code on bad arguments, or -(1000+hipError_t)
+ *     if a launch failed.  Nothing throws across the boundary;
+ *   - reduction outputs ("double* sums", dbias, dw of the depthwise conv, SE/gate parameter
+ *     gradients) are zeroed by the callee (hipMemsetAsync on `stream`) before accumulation.
+ */
+#ifndef DYNMM_HIP_H
+#define DYNMM_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYNMM_OK 0
+#define DYNMM_EINVAL (-1)      /* inconsistent dimensions / null pointer            */
+#define DYNMM_EUNSUPPORTED (-2) /* shape outside what the kernels implement        */
+#define DYNMM_EWORKSPACE (-3)   /* workspace too small (see *_workspace_bytes)      */
+
+#define DYNMM_ACT_NONE 0
+#define DYNMM_ACT_RELU 1
+#define DYNMM_ACT_TANH 2
+
+/* ABI version + build info (smoke / loader check). */
+int dynmm_abi_version(void);
+const char* dynmm_build_info(void);
+
+/* Geometry of one convolution, shared by fwd / dgrad / wgrad.
+ * x:[N,Ci,H,W]  w:[Co,Ci,KH,KW]  y:[N,Co,Ho,Wo], Ho = (H+2PH-KH)/SH+1 (same for W). groups = 1.
+ * If x2 != NULL the logical input is cat([x, x2], dim=1) with x holding the first `c_split`
+ * channels (GlobalGate's torch.concat, src/models/model_skip_mod_globalgate.py:389). */
+typedef struct {
+    int N, Ci, H, W;
+    int Co, Ho, Wo;
+    int KH, KW, SH, SW, PH, PW;
+    int c_split; /* == Ci when x2 is NULL */
+} dynmm_conv_geom;
+
+/* Re-layout of a conv weight for the implicit-GEMM kernels (done per step; weights are small).
+ *   wp_fwd  [(tap*Ci+ci)][Co]   (tap = r*KW+s)   — operand of dynmm_conv2d_fwd
+ *   wp_dgrad[(tap*Co+co)][Ci]                     — operand of dynmm_conv2d_dgrad
+ * Either output may be NULL. */
+int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
+                      int Co, int Ci, int KH, int KW, void* stream);
+
+/* y = act( conv(x|x2, w) * scale[co] + shift[co] + residual )      (scale/shift/residual optional)
+ * Replaces nn.Conv2d (+ folded eval BatchNorm2d + ReLU + residual add) of
+ *   ResNet stem src/models/resnet.py:352-358, BasicBlock :66-84, NonBottleneck1D :124-147,
+ *   ConvBNAct src/models/model_utils.py:11-23, Decoder.conv_out / side_output src/models/model.py:286,339,
+ *   GlobalGate convs src/models/model_skip_mod_globalgate.py:380-386.
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM; bias is passed as shift with scale = NULL. */
+int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
+                     const float* scale, const float* shift, const float* residual,
+                     float* y, const dynmm_conv_geom* g, int act, void* stream);
+
+/* dx = conv_transpose(dy, w)  (the autograd "input gradient" of the conv above); if mask != NULL
+ * the result is multiplied by (mask > 0) — the ReLU backward of the producer of x, fused.
+ * dx covers cat([x,x2]) when g->c_split < g->Ci: dx2 receives channels [c_split, Ci). */
+int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
+                       float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
+
+/* dw[Co,Ci,KH,KW] = sum_{n,oh,ow} dy * x(window).  Split over the pixel range into partial slabs in
+ * `workspace` (>= dynmm_conv2d_wgrad_workspace_bytes), reduced deterministically. */
+size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g);
+int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw,
+                       void* workspace, size_t workspace_bytes,
+                       const dynmm_conv_geom* g, void* stream);
+
+/* g_out = g * act'(y) ; dbias[c] = sum_{n,hw} g_out   (either output may be NULL).
+ * ReLU/tanh backward + bias gradient of a conv+bias+act (autograd of resnet.py:125-126 etc.). */
+int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias,
+                       int N, int C, int HW, int act, void* stream);
+
+/* ---- BatchNorm2d (src/models/resnet.py:59,110; model_utils.py:22; …globalgate.py:381,384) ---- */
+/* per-channel sum / sum of squares over (N,HW) into sums[2*C] (double). */
+int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, void* stream);
+/* y = act( (x-mean)*invstd*gamma + beta + residual ).
+ * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
+ *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does.
+ * training=0: uses running_mean/var; sums / save_* may be NULL. */
+int dynmm_bn_apply(const float* x, const double* sums, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                   const float* residual, float* y, int N, int C, int HW,
+                   float eps, float momentum, int training, int act, void* stream);
+/* backward: sums[2*C] <- (sum g_eff, sum g_eff*xhat), g_eff = g*act'(y). */
+int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x,
+                        const float* mean, const float* invstd, double* sums,
+                        int N, int C, int HW, int act, void* stream);
+/* dx = gamma*invstd*(g_eff - sum_g/M - xhat*sum_gx/M) (training) or gamma*invstd*g_eff (eval);
+ * d_residual = g_eff (optional); dgamma/dbeta from sums. */
+int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x,
+                       const float* mean, const float* invstd, const float* gamma,
+                       const double* sums, float* dx, float* d_residual,
+                       float* dgamma, float* dbeta,
+                       int N, int C, int HW, int training, int act, void* stream);
+/* eval-mode folding for the fused conv epilogue: scale = gamma*rsqrt(var+eps),
+ * shift = beta + (conv_bias - mean)*scale   (conv_bias optional). */
+int dynmm_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                  const float* running_var, const float* conv_bias, float* scale, float* shift,
+                  int C, float eps, void* stream);
+
+/* ---- pooling / resampling ---- */
+/* F.max_pool2d(k=3,s=2,p=1) (…globalgate.py:260-261). idx (int8, optional) = argmax tap 0..8. */
+int dynmm_maxpool3x3s2_fwd(const float* x, float* y, signed char* idx,
+                           int N, int C, int H, int W, int Ho, int Wo, void* stream);
+int dynmm_maxpool3x3s2_bwd(const float* g, const signed char* idx, float* dx,
+                           int N, int C, int H, int W, int Ho, int Wo, void* stream);
+/* F.adaptive_avg_pool2d (context_modules.py:56; also GAP when OH=OW=1). */
+int dynmm_adaptive_avgpool_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream);
+int dynmm_adaptive_avgpool_bwd(const float* g, float* dx, int NC, int H, int W, int OH, int OW, void* stream);
+/* out[:, c_off:c_off+C] = nearest_resize(y, (H,W))  — the cat+interpolate of PyramidPoolingModule
+ * (context_modules.py:72-86).  out has Ctot channels. bwd sums the gradient back. */
+int dynmm_nearest_into_fwd(const float* y, float* out, int N, int C, int h, int w,
+                           int Ctot, int c_off, int H, int W, void* stream);
+int dynmm_nearest_into_bwd(const float* g_out, float* dy, int N, int C, int h, int w,
+                           int Ctot, int c_off, int H, int W, void* stream);
+/* Upsample 'learned-3x3-zeropad' (src/models/model.py:404-410) = nearest x2 + depthwise 3x3 + bias,
+ * plus the decoder's `out += encoder_features` (model.py:354-355) when skip != NULL. */
+int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const float* b, const float* skip,
+                               float* y, int N, int C, int H, int W, void* stream);
+int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const float* w,
+                               float* dx, float* dw, float* db,
+                               int N, int C, int H, int W, void* stream);
+
+/* ---- SE fusion + gated blend (rgb_depth_fusion.py:22-26, model_utils.py:47-51, …globalgate.py:282-310) ---- */
+/* s[n,c] = mean_hw x[n,c,:]  for two tensors at once. */
+int dynmm_gap2_fwd(const float* xr, const float* xd, float* sr, float* sd, int NC, int HW, void* stream);
+/* Per-sample SE MLPs and blend coefficients:
+ *   g_m = sigmoid(W2_m relu(W1_m s_m + b1_m) + b2_m)  (m in {rgb, depth});  use_se=0 -> g = 1
+ *   a = wc + (1-wc) g_r ;  b = (1-wc) g_d           (wc[n] optional, NULL -> 0)
+ * so that  out = a*rgb + b*depth  ==  wc*rgb + (1-wc)*(rgb*g_r + depth*g_d).
+ * params: 8 pointers {W1r,b1r,W2r,b2r,W1d,b1d,W2d,b2d}; hidden = C/16.
+ * saves h_r,h_d [N,C/16] and g_r,g_d [N,C] for the backward. */
+int dynmm_se_coeff_fwd(const float* sr, const float* sd, const float* const* params,
+                       const float* wc, int wc_stride, float* a, float* b,
+                       float* hr, float* hd, float* gr, float* gd,
+                       int N, int C, int use_se, void* stream);
+int dynmm_se_coeff_bwd(const float* da, const float* db, const float* sr, const float* sd,
+                       const float* const* params, const float* wc, int wc_stride,
+                       const float* hr, const float* hd, const float* gr, const float* gd,
+                       float* const* dparams, float* dsr, float* dsd, float* dwc, int dwc_stride,
+                       int N, int C, int use_se, void* stream);
+/* out = a[n,c]*xr + b[n,c]*xd */
+int dynmm_axpby_fwd(const float* xr, const float* xd, const float* a, const float* b, float* out,
+                    int NC, int HW, void* stream);
+/* da[n,c] = sum_hw g*xr ; db[n,c] = sum_hw g*xd */
+int dynmm_axpby_bwd_reduce(const float* g, const float* xr, const float* xd, float* da, float* db,
+                           int NC, int HW, void* stream);
+/* dxr = a*g + cscale*ca ; dxd = b*g + cscale*cb   (ca,cb [N,C] optional: the GAP backward terms
+ * ds of the SE squeeze, cscale = 1/HW) */
+int dynmm_axpby_bwd_apply(const float* g, const float* a, const float* b,
+                          const float* ca, const float* cb, float cscale, float* dxr, float* dxd,
+                          int NC, int HW, void* stream);
+
+/* ---- global gate head (…globalgate.py:20-30, 263-272, 314-315, 391-394) ----
+ * mode 0: logits = fc[5,J] . pooled[n,J];  weight = DiffSoftmax(logits, temp, hard)
+ * mode 1: weight given (baseline / ini_stage one-hots), pooled/fc ignored
+ * outputs: weight[N,5]; wcum[N,4] = {w0, w0+w1, w0+w1+w2, 1-w4}; soft[N,5] (saved);
+ *          flop_loss = mean_k( mean_n(weight)[k] * flop_table[k] ). */
+int dynmm_gate_head_fwd(const float* pooled, const float* fc, float* weight, float* wcum,
+                        float* soft, float* flop_loss, const float* flop_table,
+                        int N, int J, float temp, int hard, int mode, void* stream);
+int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, const float* d_loss,
+                        const float* pooled, const float* fc, const float* soft,
+                        const float* flop_table, float* d_pooled, float* d_fc,
+                        int N, int J, float temp, void* stream);
+
+/* ---- weighted multi-scale cross entropy (src/utils.py:34-50), SURVEY §8f-1 ----
+ * loss_sum += sum_px w[t]*(-log softmax(x)[t]);  wsum += sum_px w[t]   (t = target-1, void skipped)
+ * dx = (softmax - onehot) * w[t] * gscale[0]   (gscale = upstream_grad / wsum, device scalar). */
+int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
+                   double* loss_sum_wsum /*[2]*/, int N, int C, int HW, void* stream);
+int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
+                   const float* gscale, float* dx, int N, int C, int HW, void* stream);
+
+/* ---- helpers ---- */
+/* out[i] = sum_s slabs[s][i] */
+int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nslabs, void* stream);
+/* fused SGD-Nesterov step over one flat parameter/grad/momentum buffer (train.py:557-563):
+ * g += wd*p; buf = mom*buf + g; p -= lr*(g + mom*buf). lr is a device scalar (graph-friendly). */
+int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const float* lr,
+                       float momentum, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNMM_HIP_H */

@@ -1,0 +1,238 @@
+"""Generate the golden fixtures in this directory from the REFERENCE ITSELF.
+
+Runs only in the build container, where /root/reference is mounted read-only; it is never run on
+the GPU box (fixtures travel, the reference does not).  The reference is imported unmodified; the
+only accommodation is a process-local `.cuda()` no-op because the reference hard-codes `.cuda()`
+in SkipGateESANet.__init__/forward (FusionDynMM/src/models/model_skip_mod_globalgate.py:218-223,
+265, 268) and this container has no GPU.
+
+    python tests/golden/make_goldens.py          # rewrites tests/golden/*.npz
+
+What is stored (data only: inputs are regenerated from dynmm_amd.synth on both sides):
+  model_<cfg>_<HxW>.npz   per mode: strided logits, per-(n,class) sums, gate weight, flop loss;
+                           train modes add side outputs, per-parameter gradient norms, a few
+                           full small gradients and BN running-stat checksums.
+  nyu8_P_se.npz            BASELINE config[0] restated on 8 synthetic NYUv2-like pairs, 480x640,
+                           eval --baseline: strided logits, argmax histogram, CM and mIoU.
+  ops.npz                  DiffSoftmax cases, Upsample fixed init, CE loss, temperature schedule.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference/FusionDynMM')
+torch.Tensor.cuda = lambda self, *a, **k: self            # no GPU here
+warnings.filterwarnings('ignore')
+
+from src.models.model_skip_mod_globalgate import SkipGateESANet, DiffSoftmax  # noqa: E402
+from src.models.model import Upsample                                          # noqa: E402
+from src import utils as ref_utils                                             # noqa: E402
+
+from dynmm_amd import synth                                                    # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+CFGS = {
+    'P_se': dict(encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add'),
+    'P_add': dict(encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='add'),
+    'S_se': dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='SE-add'),
+    'S_add': dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='add'),
+}
+MODES = ['eval_baseline', 'eval_soft', 'eval_hard', 'eval_ini', 'train_soft', 'train_hard']
+STRIDE = 8
+
+
+def build(cfg, h, w):
+    m = SkipGateESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34',
+                       encoder_depth='resnet34', channels_decoder=[128, 128, 128],
+                       nr_decoder_blocks=[3, 3, 3], pretrained_on_imagenet=False, **CFGS[cfg])
+    synth.fill_state_dict(m.state_dict(), seed=0)
+    return m
+
+
+def ini_index(n):
+    return torch.tensor([(3 * i + 1) % 5 for i in range(n)])
+
+
+def grad_probe(shape, tag):
+    r = np.random.Generator(np.random.PCG64([99, sum(shape), len(tag)]))
+    return torch.from_numpy(r.standard_normal(size=shape).astype(np.float32))
+
+
+def train_loss(outs, loss_flop):
+    """Scalar used for the backward goldens: sum_s mean(out_s * G_s) + 3 * flop_loss."""
+    total = 3.0 * loss_flop
+    for i, o in enumerate(outs):
+        total = total + (o * grad_probe(tuple(o.shape), f's{i}')).mean()
+    return total
+
+
+def summarize_logits(out):
+    o = out.detach()
+    return dict(strided=o[:, :, ::STRIDE, ::STRIDE].contiguous().numpy(),
+                csum=o.sum(dim=(2, 3)).numpy(), cabs=o.abs().sum(dim=(2, 3)).numpy())
+
+
+def run_mode(cfg, h, w, n, mode):
+    m = build(cfg, h, w)                      # fresh weights / running stats for every mode
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    res = {}
+    training = mode.startswith('train')
+    m.train() if training else m.eval()
+    m.baseline = mode == 'eval_baseline'
+    m.ini_stage = mode == 'eval_ini'
+    m.hard_gate = mode in ('eval_hard', 'train_hard')
+    m.temp = 0.5 if mode == 'train_hard' else 1.0
+    if m.ini_stage:
+        real_randint = torch.randint
+        torch.randint = lambda *a, **k: ini_index(n)
+    try:
+        if training:
+            outs, lf = m(rgb, depth)
+            loss = train_loss(outs, lf)
+            loss.backward()
+            for k, v in summarize_logits(outs[0]).items():
+                res[k] = v
+            for i, o in enumerate(outs[1:]):
+                res[f'side{i}'] = o.detach().numpy()
+            res['loss_flop'] = np.float32(lf.item())
+            res['loss'] = np.float32(loss.item())
+            names, norms = [], []
+            for name, p in m.named_parameters():
+                names.append(name)
+                norms.append(0.0 if p.grad is None else p.grad.norm().item())
+            res['grad_names'] = np.array(names)
+            res['grad_norms'] = np.array(norms, np.float64)
+            for name in ('gate_layer.fc.weight', 'gate_layer.conv.0.bias', 'encoder_depth.conv1.weight',
+                         'decoder.upsample2.conv.weight', 'decoder.conv_out.bias',
+                         'encoder_rgb.layer2.0.downsample.0.weight'):
+                res['grad:' + name] = dict(m.named_parameters())[name].grad.numpy()
+            sd = m.state_dict()
+            for name in ('encoder_rgb.bn1', 'encoder_depth.layer3.2.bn2', 'gate_layer.conv.4',
+                         'context_module.features.0.1.bn', 'decoder.decoder_module_3.conv3x3.bn'):
+                res['rm:' + name] = sd[name + '.running_mean'].numpy().copy()
+                res['rv:' + name] = sd[name + '.running_var'].numpy().copy()
+        else:
+            with torch.no_grad():
+                out, weight = m(rgb, depth, test=True, return_weight=True)
+                _, lf = m(rgb, depth)
+            for k, v in summarize_logits(out).items():
+                res[k] = v
+            res['weight'] = weight.numpy()
+            res['loss_flop'] = np.float32(lf.item())
+    finally:
+        if m.ini_stage:
+            torch.randint = real_randint
+    return res
+
+
+def train_weight(cfg, h, w, n, mode):
+    """Gate weights of the train modes (the reference does not return them from forward)."""
+    m = build(cfg, h, w)
+    m.train()
+    m.hard_gate = mode == 'train_hard'
+    m.temp = 0.5 if mode == 'train_hard' else 1.0
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    with torch.no_grad():
+        outs, weight = m(rgb, depth, test=True, return_weight=True)
+    return weight.numpy()
+
+
+def model_fixture(cfg, h, w, n, modes):
+    blob = {}
+    for mode in modes:
+        print(f'  {cfg} {h}x{w} n={n} {mode}', flush=True)
+        for k, v in run_mode(cfg, h, w, n, mode).items():
+            blob[f'{mode}/{k}'] = v
+        if mode.startswith('train'):
+            blob[f'{mode}/weight'] = train_weight(cfg, h, w, n, mode)
+    blob['meta'] = np.array([h, w, n, STRIDE])
+    np.savez_compressed(os.path.join(HERE, f'model_{cfg}_{h}x{w}.npz'), **blob)
+
+
+def nyu8_fixture():
+    """BASELINE.json configs[0]: eval --baseline on 8 (synthetic) NYUv2 RGB-D pairs."""
+    h, w, n = 480, 640, 8
+    m = build('P_se', h, w)
+    m.eval()
+    m.baseline = True
+    rgb, depth = synth.synth_inputs(n, h, w, seed=77, nyu_like=True)
+    label = synth.synth_labels(n, h, w, seed=78)
+    with torch.no_grad():
+        out = m(rgb, depth, test=True)
+    pred = out.argmax(1)
+    mask = label > 0
+    lab, prd = label[mask] - 1, pred[mask]
+    cm = torch.bincount(40 * lab + prd, minlength=1600).reshape(40, 40)
+    cmd = cm.double()
+    iou = cmd.diag() / (cmd.sum(1) + cmd.sum(0) - cmd.diag() + 1e-15)
+    hist = torch.stack([torch.bincount(pred[i].flatten(), minlength=40) for i in range(n)])
+    np.savez_compressed(os.path.join(HERE, 'nyu8_P_se.npz'),
+                        strided=out[:, :, ::32, ::32].contiguous().numpy(),
+                        csum=out.sum(dim=(2, 3)).numpy(), cabs=out.abs().sum(dim=(2, 3)).numpy(),
+                        hist=hist.numpy(), cm=cm.numpy(), miou=np.float64(iou.mean().item()))
+
+
+def ops_fixture():
+    blob = {}
+    r = np.random.Generator(np.random.PCG64(5))
+    logits = torch.from_numpy(r.standard_normal(size=(6, 5, 1, 1)).astype(np.float32))
+    blob['ds/logits'] = logits.numpy()
+    for tau in (1.0, 0.1, 0.001):
+        for hard in (False, True):
+            blob[f'ds/{tau}/{int(hard)}'] = DiffSoftmax(logits, tau=tau, hard=hard, dim=1).numpy()
+    up = Upsample(mode='learned-3x3-zeropad', channels=3)
+    blob['up/weight'] = up.conv.weight.detach().numpy()
+    blob['up/bias'] = up.conv.bias.detach().numpy()
+    x = torch.from_numpy(r.standard_normal(size=(2, 3, 4, 5)).astype(np.float32))
+    blob['up/x'] = x.numpy()
+    blob['up/y'] = up(x).detach().numpy()
+    # weighted multi-scale CE (src/utils.py:18-50)
+    cw = r.uniform(0.5, 2.0, size=40).astype(np.float32)
+    ce = ref_utils.CrossEntropyLoss2d(torch.device('cpu'), cw)
+    xs = [torch.from_numpy(r.standard_normal(size=(2, 40, s, s + 2)).astype(np.float32)) for s in (12, 6)]
+    ts = [torch.from_numpy(r.integers(0, 41, size=(2, s, s + 2)).astype(np.float32)) for s in (12, 6)]
+    losses = ce(xs, ts)
+    blob['ce/weight'] = cw
+    for i in range(2):
+        blob[f'ce/x{i}'] = xs[i].numpy()
+        blob[f'ce/t{i}'] = ts[i].numpy()
+        blob[f'ce/loss{i}'] = np.float32(losses[i].item())
+    sched = ref_utils.ExpDecayTemp(1.0, 0.001, 300)
+    blob['temp/epochs'] = np.array([0, 1, 50, 299, 300, 400])
+    blob['temp/values'] = np.array([sched.get_t(int(e)) for e in blob['temp/epochs']])
+    np.savez_compressed(os.path.join(HERE, 'ops.npz'), **blob)
+
+
+def contract_fixture():
+    """state_dict keys / shapes / dtypes of the reference model (the strict-load contract, eval.py:61)."""
+    blob = {}
+    for cfg in CFGS:
+        sd = build(cfg, 96, 128).state_dict()
+        blob[f'{cfg}/keys'] = np.array(list(sd.keys()))
+        blob[f'{cfg}/shapes'] = np.array([','.join(map(str, v.shape)) for v in sd.values()])
+        blob[f'{cfg}/dtypes'] = np.array([str(v.dtype) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, 'contract.npz'), **blob)
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'contract':
+        contract_fixture()
+        sys.exit(0)
+    contract_fixture()
+    ops_fixture()
+    model_fixture('P_se', 96, 128, 2, MODES)
+    model_fixture('P_add', 96, 128, 2, ['eval_soft', 'train_soft'])
+    model_fixture('S_se', 96, 128, 2, ['eval_hard', 'train_soft'])
+    model_fixture('S_add', 96, 128, 2, ['eval_baseline'])
+    model_fixture('P_se', 160, 192, 3, ['eval_hard', 'train_soft'])
+    nyu8_fixture()
+    print('done')

@@ -1,0 +1,116 @@
+"""CPU: pins the oracle (oracle/dynmm_oracle.py) to fixtures produced by the reference itself
+(tests/golden/make_goldens.py) and to the reference's own known-answer values."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dynmm_amd import synth
+from oracle import dynmm_oracle as O
+from tests import helpers as Hh
+
+TOL = 2e-5   # oracle and reference are the same fp32 ATen ops; only thread-count reduction order differs
+
+MODEL_FIXTURES = [
+    ('P_se', 96, 128), ('P_add', 96, 128), ('S_se', 96, 128), ('S_add', 96, 128), ('P_se', 160, 192),
+]
+
+
+def _modes(g):
+    return sorted({k.split('/')[0] for k in g.files if '/' in k})
+
+
+@pytest.mark.parametrize('cfg,h,w', MODEL_FIXTURES)
+def test_oracle_matches_reference_goldens(golden_dir, cfg, h, w):
+    g = np.load(os.path.join(golden_dir, f'model_{cfg}_{h}x{w}.npz'))
+    hh, ww, n, stride = [int(v) for v in g['meta']]
+    rgb, depth = synth.synth_inputs(n, hh, ww, seed=1234)
+    for mode in _modes(g):
+        sd = Hh.filled_state_dict(Hh.CFGS[cfg])
+        kw = dict(Hh.MODE_KW[mode])
+        if kw.get('ini_stage'):
+            kw['ini_weight'] = Hh.ini_weight(n)
+        if mode.startswith('train'):
+            params = {k: v.requires_grad_(True) for k, v in sd.items()
+                      if v.dtype.is_floating_point and 'running_' not in k}
+            det = {}
+            outs, lf = O.forward(sd, rgb, depth, Hh.CFGS[cfg], detail=det, **kw)
+            loss = Hh.train_loss(outs, lf)
+            loss.backward()
+            out = outs[0].detach()
+            for i, o in enumerate(outs[1:]):
+                assert Hh.rel_err(o.detach(), g[f'{mode}/side{i}']) < TOL
+            assert abs(loss.item() - float(g[f'{mode}/loss'])) < 1e-4 * max(1, abs(float(g[f'{mode}/loss'])))
+            assert Hh.rel_err(det['weight'].detach(), g[f'{mode}/weight']) < TOL
+            names = [str(s) for s in g[f'{mode}/grad_names']]
+            norms = np.array([params[nm].grad.norm().item() for nm in names])
+            ref = g[f'{mode}/grad_norms']
+            assert np.all(np.abs(norms - ref) <= 5e-4 * np.maximum(ref, 1e-3) + 1e-6), \
+                np.max(np.abs(norms - ref) / np.maximum(ref, 1e-3))
+            for k in g.files:
+                if k.startswith(f'{mode}/grad:'):
+                    assert Hh.rel_err(params[k.split('grad:')[1]].grad, g[k]) < 5e-4
+                if k.startswith(f'{mode}/rm:'):
+                    assert Hh.rel_err(sd[k.split('rm:')[1] + '.running_mean'].detach(), g[k]) < TOL
+                if k.startswith(f'{mode}/rv:'):
+                    assert Hh.rel_err(sd[k.split('rv:')[1] + '.running_var'].detach(), g[k]) < TOL
+        else:
+            with torch.no_grad():
+                out, weight = O.forward(sd, rgb, depth, Hh.CFGS[cfg], test=True, return_weight=True, **kw)
+                _, lf = O.forward(sd, rgb, depth, Hh.CFGS[cfg], **kw)
+            assert Hh.rel_err(weight, g[f'{mode}/weight']) < TOL
+        assert abs(lf.item() - float(g[f'{mode}/loss_flop'])) < 1e-5
+        assert Hh.rel_err(out[:, :, ::stride, ::stride], g[f'{mode}/strided']) < TOL
+        assert Hh.rel_err(out.sum(dim=(2, 3)), g[f'{mode}/csum']) < 1e-4
+        assert Hh.rel_err(out.abs().sum(dim=(2, 3)), g[f'{mode}/cabs']) < 1e-4
+
+
+def test_oracle_nyu8_baseline_config0(golden_dir):
+    """BASELINE.json configs[0] on 8 synthetic NYUv2-like pairs: logits, argmax histogram, CM, mIoU."""
+    g = np.load(os.path.join(golden_dir, 'nyu8_P_se.npz'))
+    sd = Hh.filled_state_dict(Hh.CFGS['P_se'])
+    rgb, depth = synth.synth_inputs(8, 480, 640, seed=77, nyu_like=True)
+    label = synth.synth_labels(8, 480, 640, seed=78)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        out = O.forward(sd, rgb, depth, Hh.CFGS['P_se'], test=True, baseline=True)
+    assert Hh.rel_err(out[:, :, ::32, ::32], g['strided']) < TOL
+    lab, prd = O.eval_postprocess(out, label)
+    cm = O.confusion_matrix(lab, prd, 40)
+    assert (cm.numpy() != g['cm']).sum() <= 4          # argmax ties at fp32 rounding level
+    _, miou = O.iou_from_cm(cm)
+    assert abs(miou.item() - float(g['miou'])) < 1e-6
+
+
+def test_ops_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ops.npz'))
+    logits = torch.from_numpy(g['ds/logits'])
+    for tau in (1.0, 0.1, 0.001):
+        for hard in (0, 1):
+            y = O.diff_softmax(logits, tau=tau, hard=bool(hard), dim=1)
+            assert torch.allclose(y, torch.from_numpy(g[f'ds/{tau}/{hard}']), atol=1e-7)
+    sd = {'u.conv.weight': torch.from_numpy(g['up/weight']), 'u.conv.bias': torch.from_numpy(g['up/bias'])}
+    assert torch.allclose(O.learned_upsample(sd, 'u', torch.from_numpy(g['up/x'])), torch.from_numpy(g['up/y']), atol=1e-6)
+    xs = [torch.from_numpy(g[f'ce/x{i}']) for i in range(2)]
+    ts = [torch.from_numpy(g[f'ce/t{i}']) for i in range(2)]
+    losses = O.cross_entropy_2d(xs, ts, g['ce/weight'])
+    for i in range(2):
+        assert abs(losses[i].item() - float(g[f'ce/loss{i}'])) < 1e-5
+    for e, v in zip(g['temp/epochs'], g['temp/values']):
+        assert abs(O.exp_decay_temp(1.0, 0.001, 300, int(e)) - v) < 1e-12
+
+
+def test_reference_known_answers():
+    """The reference's only self-checks: confusion-matrix example (src/confusion_matrix.py:181-198)
+    and the R34 MAC table relation total - no-weight = gate cost (…globalgate.py:419-424)."""
+    label = torch.tensor([0, 0, 1, 2, 3])
+    pred = torch.tensor([1, 1, 0, 2, 3])
+    cm = O.confusion_matrix(label, pred, 4)
+    assert cm.tolist() == [[0, 2, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+    iou, miou = O.iou_from_cm(cm)
+    assert np.allclose(iou.numpy(), [0, 0, 1, 1]) and abs(miou.item() - 0.5) < 1e-12
+    total = np.array([22.37101509, 25.23166149, 29.06736069, 34.78465989, 37.65928389])
+    no_w = np.array([22.2534697, 25.1141161, 28.9498153, 34.6671145, 37.5417385])
+    assert np.allclose(total - no_w, 0.1175, atol=1e-3)
+    assert O.DEPTH_ENC_FLOP_R34[0] == 0.2506752 and O.DEPTH_ENC_FLOP_R34[4] == 15.538944
