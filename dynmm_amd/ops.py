@@ -20,6 +20,9 @@ def _lib():
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise L.DynmmHipError('no HIP device is available: the DynMM hot path runs only on its HIP kernels '
+                              '(there is no CPU / eager-PyTorch fallback)')
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -1,0 +1,72 @@
+"""build_model(args, n_classes) -> (model, device): the factory train.py / eval.py call
+(FusionDynMM/src/build_model.py:18-218), restricted to what the HIP hot path implements:
+`--dynamic --global-gate` (SkipGateESANet).  Other model families raise NotImplementedError."""
+import warnings
+
+import torch
+from torch import nn
+
+from ..nn.net import SkipGateESANet
+
+
+def _decoder_shape(args):
+    if 'decreasing' in args.decoder_channels_mode:
+        warnings.warn('Argument --channels_decoder is ignored when --decoder_chanels_mode decreasing is set.')
+        channels = [512, 256, 128]
+    else:
+        channels = [args.channels_decoder] * 3
+    nb = args.nr_decoder_blocks
+    if isinstance(nb, int):
+        nb = [nb] * 3
+    elif len(nb) == 1:
+        nb = list(nb) * 3
+    assert len(nb) == 3
+    return channels, list(nb)
+
+
+def build_model(args, n_classes):
+    pretrained = bool(args.pretrained_on_imagenet) and not args.last_ckpt and args.pretrained_scenenet == ''
+    channels_decoder, nr_decoder_blocks = _decoder_shape(args)
+    if not (args.dynamic and args.global_gate):
+        raise NotImplementedError('the HIP path implements --dynamic --global-gate (SkipGateESANet); '
+                                  'ESANet == the same model with .baseline = True')
+    block_rule = [int(ch) for ch in args.block_rule]
+    assert len(block_rule) == 4
+    if args.encoder_depth in (None, 'None'):
+        args.encoder_depth = args.encoder
+    model = SkipGateESANet(
+        height=args.height, width=args.width, num_classes=n_classes,
+        pretrained_on_imagenet=False, pretrained_dir=args.pretrained_dir,
+        encoder_rgb=args.encoder, encoder_depth=args.encoder_depth, encoder_block=args.encoder_block,
+        activation=args.activation, encoder_decoder_fusion=args.encoder_decoder_fusion,
+        context_module=args.context_module, nr_decoder_blocks=nr_decoder_blocks,
+        channels_decoder=channels_decoder, fuse_depth_in_rgb_encoder=args.fuse_depth_in_rgb_encoder,
+        upsampling=args.upsampling, temp=args.temp, block_rule=block_rule)
+    if pretrained:
+        warnings.warn('ImageNet pre-training requested but no weights are reachable offline; '
+                      'encoders keep their random init (pass --no_imagenet_pretraining to silence)')
+
+    device = torch.device('cuda:0') if torch.cuda.is_available() else torch.device('cpu')
+    print('Device:', device)
+    model.to(device)
+
+    if getattr(args, 'he_init', False):
+        mods = [m for child in model.children() for m in child.modules()]
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Conv2d):
+                followed_by_sigmoid = isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and \
+                    i + 1 < len(mods) and isinstance(mods[i + 1], nn.Identity) and m.bias is not None \
+                    and m.out_channels > m.in_channels
+                if m.out_channels == n_classes or followed_by_sigmoid or m.groups == m.in_channels:
+                    continue
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        print('Applied He init.')
+
+    if getattr(args, 'finetune', None) is not None:
+        ckpt = torch.load(args.finetune, map_location=device)
+        model.load_state_dict(ckpt['state_dict'], strict=False)
+        print(f'Loaded weights for finetuning: {args.finetune}')
+    return model, device

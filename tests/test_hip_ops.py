@@ -1,0 +1,336 @@
+"""GPU: each HIP op (through the C ABI, via dynmm_amd.ops) against a plain PyTorch fp32 CPU reference
+of the same op, forward and backward, on the shape classes of the hot path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5      # fp32 MFMA is an exact-f32 fma chain; differences are summation-order only
+GTOL = 2e-4     # gradients: long reductions (N*H*W terms) in a different order
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dynmm_amd import ops as o
+    from dynmm_amd import lib
+    lib.load()
+    return o
+
+
+CONV_CASES = [
+    # N, Ci, H, W, Co, k, stride, pad, bias, act
+    (2, 64, 24, 32, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),
+    (2, 64, 24, 32, 64, (1, 3), (1, 1), (0, 1), True, None),
+    (2, 64, 24, 32, 128, (3, 1), (2, 1), (1, 0), True, 'relu'),
+    (2, 128, 12, 32, 128, (1, 3), (1, 2), (0, 1), True, None),
+    (2, 64, 24, 32, 128, (1, 1), (2, 2), (0, 0), False, None),
+    (3, 64, 17, 23, 64, (3, 3), (1, 1), (1, 1), False, None),
+    (2, 64, 24, 32, 128, (3, 3), (2, 2), (1, 1), False, None),
+    (2, 256, 6, 8, 512, (3, 1), (2, 1), (1, 0), True, 'relu'),
+    (2, 512, 3, 4, 512, (1, 3), (1, 1), (0, 1), True, None),
+    (2, 3, 48, 64, 64, (7, 7), (2, 2), (3, 3), False, None),
+    (2, 1, 48, 64, 64, (7, 7), (2, 2), (3, 3), False, None),
+    (2, 128, 24, 32, 40, (3, 3), (1, 1), (1, 1), True, None),
+    (2, 128, 12, 16, 40, (1, 1), (1, 1), (0, 0), True, None),
+    (2, 8, 28, 38, 8, (5, 5), (2, 2), (0, 0), True, None),
+    (2, 1024, 3, 4, 128, (1, 1), (1, 1), (0, 0), False, None),
+    (1, 64, 120, 160, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd_bwd(ops, case):
+    N, Ci, H, W, Co, k, s, p, bias, act = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, *k, seed=2, scale=(Ci * k[0] * k[1]) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1) if bias else None
+    x_requires = Ci > 3
+    xr = x.clone().requires_grad_(x_requires)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    y_ref = F.conv2d(xr, wr, br, s, p)
+    if act == 'relu':
+        y_ref = F.relu(y_ref)
+    gy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+
+    xg = x.cuda().requires_grad_(x_requires)
+    wg = w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    y = ops.conv2d(xg, wg, bg, s, p, act)
+    assert rel(y, y_ref) < TOL
+    y.backward(gy.cuda())
+    assert rel(wg.grad, wr.grad) < GTOL
+    if bias:
+        assert rel(bg.grad, br.grad) < GTOL
+    if x_requires:
+        assert rel(xg.grad, xr.grad) < GTOL
+
+
+def test_conv2d_dual_input(ops):
+    """GlobalGate's first conv: cat(rgb, depth) is never materialised."""
+    a, b2 = rnd(2, 64, 24, 32, seed=5), rnd(2, 64, 24, 32, seed=6)
+    w = rnd(8, 128, 5, 5, seed=7, scale=0.02)
+    bias = rnd(8, seed=8, scale=0.1)
+    ar, br_, wr, biasr = [t.clone().requires_grad_(True) for t in (a, b2, w, bias)]
+    y_ref = F.conv2d(torch.cat([ar, br_], 1), wr, biasr, 2)
+    gy = rnd(*y_ref.shape, seed=9)
+    y_ref.backward(gy)
+    ag, bg, wg, biasg = [t.cuda().requires_grad_(True) for t in (a, b2, w, bias)]
+    y = ops.conv2d(ag, wg, biasg, 2, 0, None, x2=bg)
+    assert rel(y, y_ref) < TOL
+    y.backward(gy.cuda())
+    for got, ref in ((ag.grad, ar.grad), (bg.grad, br_.grad), (wg.grad, wr.grad), (biasg.grad, biasr.grad)):
+        assert rel(got, ref) < GTOL
+
+
+@pytest.mark.parametrize('act', [None, 'relu'])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_conv_fused_eval(ops, act, with_res):
+    bn = torch.nn.BatchNorm2d(128, eps=1e-3)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(128, seed=1).abs() + 0.5)
+        bn.bias.copy_(rnd(128, seed=2) * 0.1)
+        bn.running_mean.copy_(rnd(128, seed=3) * 0.1)
+        bn.running_var.copy_(rnd(128, seed=4).abs() + 0.5)
+    bn.eval()
+    x, w, cb = rnd(2, 128, 12, 16, seed=5), rnd(128, 128, 1, 3, seed=6, scale=0.05), rnd(128, seed=7, scale=0.1)
+    res = rnd(2, 128, 12, 16, seed=8) if with_res else None
+    with torch.no_grad():
+        ref = bn(F.conv2d(x, w, cb, 1, (0, 1)))
+        if with_res:
+            ref = ref + res
+        if act:
+            ref = F.relu(ref)
+        bng = torch.nn.BatchNorm2d(128, eps=1e-3).cuda()
+        bng.load_state_dict(bn.state_dict())
+        bng.eval()
+        y = ops.conv2d_fused_eval(x.cuda(), w.cuda(), cb.cuda(), bng, act, res.cuda() if with_res else None, 1, (0, 1))
+    assert rel(y, ref) < TOL
+
+
+@pytest.mark.parametrize('shape', [(4, 64, 24, 32), (3, 8, 27, 37), (4, 256, 1, 1), (2, 128, 5, 5)])
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
+@pytest.mark.parametrize('training', [True, False])
+def test_batch_norm_act(ops, shape, act, training):
+    C = shape[1]
+    x = rnd(*shape, seed=1) * 2 + 0.3
+    res = rnd(*shape, seed=2) if act == 'relu' else None
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C, seed=3).abs() + 0.5)
+        bn.bias.copy_(rnd(C, seed=4) * 0.1)
+        bn.running_mean.copy_(rnd(C, seed=5) * 0.1)
+        bn.running_var.copy_(rnd(C, seed=6).abs() + 0.5)
+    bng = torch.nn.BatchNorm2d(C, eps=1e-3).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(training)
+    bng.train(training)
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if res is not None else None
+    y_ref = bn(xr)
+    if rr is not None:
+        y_ref = y_ref + rr
+    y_ref = {'relu': F.relu, 'tanh': torch.tanh, None: lambda t: t}[act](y_ref)
+    gy = rnd(*shape, seed=7)
+    y_ref.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    rg = res.cuda().requires_grad_(True) if res is not None else None
+    y = ops.batch_norm_act(xg, bng, act, rg)
+    assert rel(y, y_ref) < TOL
+    y.backward(gy.cuda())
+    assert rel(xg.grad, xr.grad) < GTOL
+    assert rel(bng.weight.grad, bn.weight.grad) < GTOL
+    assert rel(bng.bias.grad, bn.bias.grad) < GTOL
+    if rg is not None:
+        assert rel(rg.grad, rr.grad) < GTOL
+    assert rel(bng.running_mean, bn.running_mean) < TOL
+    assert rel(bng.running_var, bn.running_var) < TOL
+    assert int(bng.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
+def test_maxpool_with_ties(ops):
+    x = F.relu(rnd(2, 64, 48, 64, seed=1))          # post-ReLU: many exact-zero ties
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    gy = rnd(*y_ref.shape, seed=2)
+    y_ref.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    y = ops.max_pool_3x3_s2(xg)
+    assert torch.equal(y.cpu(), y_ref.detach())
+    y.backward(gy.cuda())
+    assert rel(xg.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('hw,out', [((15, 20), 1), ((15, 20), 5), ((3, 4), 5), ((5, 6), (1, 5)), ((27, 37), 1)])
+def test_adaptive_avg_pool(ops, hw, out):
+    x = rnd(2, 16, *hw, seed=1)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.adaptive_avg_pool2d(xr, out)
+    gy = rnd(*y_ref.shape, seed=2)
+    y_ref.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    y = ops.adaptive_avg_pool(xg, out)
+    assert rel(y, y_ref) < TOL
+    y.backward(gy.cuda())
+    assert rel(xg.grad, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('hw', [(15, 20), (3, 4), (5, 6)])
+def test_nearest_concat(ops, hw):
+    x, y1, y5 = rnd(2, 32, *hw, seed=1), rnd(2, 16, 1, 1, seed=2), rnd(2, 16, 5, 5, seed=3)
+    ts = [t.clone().requires_grad_(True) for t in (x, y1, y5)]
+    ref = torch.cat([ts[0]] + [F.interpolate(t, hw, mode='nearest') for t in ts[1:]], 1)
+    gy = rnd(*ref.shape, seed=4)
+    ref.backward(gy)
+    tg = [t.cuda().requires_grad_(True) for t in (x, y1, y5)]
+    out = ops.nearest_concat(*tg)
+    assert torch.equal(out.cpu(), ref.detach())
+    out.backward(gy.cuda())
+    for a, b in zip(tg, ts):
+        assert rel(a.grad, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 15, 20), (2, 40, 24, 32), (1, 3, 5, 7)])
+@pytest.mark.parametrize('with_skip', [False, True])
+def test_upsample2x_dw3x3(ops, shape, with_skip):
+    N, C, H, W = shape
+    x, w, b = rnd(*shape, seed=1), rnd(C, 1, 3, 3, seed=2, scale=0.3), rnd(C, seed=3, scale=0.1)
+    skip = rnd(N, C, 2 * H, 2 * W, seed=4) if with_skip else None
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    sr = skip.clone().requires_grad_(True) if with_skip else None
+    ref = F.conv2d(F.interpolate(xr, (2 * H, 2 * W), mode='nearest'), wr, br, 1, 1, groups=C)
+    if with_skip:
+        ref = ref + sr
+    gy = rnd(*ref.shape, seed=5)
+    ref.backward(gy)
+    xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    sg = skip.cuda().requires_grad_(True) if with_skip else None
+    y = ops.upsample2x_dw3x3(xg, wg, bg, sg)
+    assert rel(y, ref) < TOL
+    y.backward(gy.cuda())
+    assert rel(xg.grad, xr.grad) < GTOL
+    assert rel(wg.grad, wr.grad) < GTOL
+    assert rel(bg.grad, br.grad) < GTOL
+    if with_skip:
+        assert rel(sg.grad, sr.grad) < 1e-6
+
+
+def _se_ref(x, p):
+    s = F.adaptive_avg_pool2d(x, 1)
+    s = torch.sigmoid(F.conv2d(F.relu(F.conv2d(s, p[0], p[1])), p[2], p[3]))
+    return x * s
+
+
+@pytest.mark.parametrize('use_se', [True, False])
+@pytest.mark.parametrize('col', [None, 0, 3])
+@pytest.mark.parametrize('shape', [(3, 64, 24, 32), (2, 512, 3, 4), (2, 128, 9, 11)])
+def test_se_fuse_blend(ops, use_se, col, shape):
+    N, C, H, W = shape
+    rgb, depth = rnd(*shape, seed=1), rnd(*shape, seed=2)
+    params = [rnd(C // 16, C, 1, 1, seed=3, scale=0.2), rnd(C // 16, seed=4, scale=0.1),
+              rnd(C, C // 16, 1, 1, seed=5, scale=0.3), rnd(C, seed=6, scale=0.1),
+              rnd(C // 16, C, 1, 1, seed=7, scale=0.2), rnd(C // 16, seed=8, scale=0.1),
+              rnd(C, C // 16, 1, 1, seed=9, scale=0.3), rnd(C, seed=10, scale=0.1)]
+    wcum = torch.rand(N, 4, generator=torch.Generator().manual_seed(11))
+
+    def run(dev, fn):
+        r, d = rgb.to(dev).requires_grad_(True), depth.to(dev).requires_grad_(True)
+        ps = [p.to(dev).requires_grad_(True) for p in params]
+        wc = wcum.to(dev).requires_grad_(True)
+        out = fn(r, d, ps, wc)
+        out.backward(rnd(*shape, seed=12).to(dev))
+        return out, r, d, ps, wc
+
+    def ref_fn(r, d, ps, wc):
+        fused = (_se_ref(r, ps[:4]) + _se_ref(d, ps[4:])) if use_se else r + d
+        if col is None:
+            return fused
+        w = wc[:, col].view(-1, 1, 1, 1)
+        return w * r + (1 - w) * fused
+
+    def hip_fn(r, d, ps, wc):
+        return ops.se_fuse_blend(r, d, ps if use_se else None, None if col is None else wc, col or 0)
+
+    o_ref, r_ref, d_ref, p_ref, w_ref = run('cpu', ref_fn)
+    o, r, d, p, w = run('cuda', hip_fn)
+    assert rel(o, o_ref) < TOL
+    assert rel(r.grad, r_ref.grad) < GTOL
+    assert rel(d.grad, d_ref.grad) < GTOL
+    if use_se:
+        for a, b in zip(p, p_ref):
+            assert rel(a.grad, b.grad) < GTOL
+    if col is not None:
+        assert rel(w.grad, w_ref.grad) < GTOL
+
+
+@pytest.mark.parametrize('temp', [1.0, 0.1, 0.001])
+@pytest.mark.parametrize('hard', [False, True])
+def test_gate_head(ops, temp, hard):
+    from oracle import dynmm_oracle as O
+    N, J = 6, 8
+    pooled, fc = rnd(N, J, 1, 1, seed=1), rnd(5, J, 1, 1, seed=2)
+    tab = torch.tensor(O.DEPTH_ENC_FLOP_R34)
+    gw, gc, gl = rnd(N, 5, seed=3), rnd(N, 4, seed=4), torch.tensor(0.7)
+
+    pr, fr = pooled.clone().requires_grad_(True), fc.clone().requires_grad_(True)
+    w_ref = O.diff_softmax(F.conv2d(pr, fr), tau=temp, hard=hard, dim=1).squeeze(-1).squeeze(-1)
+    wc_ref = torch.stack([w_ref[:, 0], w_ref[:, 0] + w_ref[:, 1], w_ref[:, 0] + w_ref[:, 1] + w_ref[:, 2],
+                          1 - w_ref[:, 4]], 1)
+    l_ref = (w_ref.mean(0) * tab).mean()
+    ((w_ref * gw).sum() + (wc_ref * gc).sum() + l_ref * gl).backward()
+
+    pg, fg = pooled.cuda().requires_grad_(True), fc.cuda().requires_grad_(True)
+    w, wc, l = ops.gate_head(pg, fg, tab.cuda(), temp, hard)
+    assert rel(w, w_ref) < 1e-5 and rel(wc, wc_ref) < 1e-5 and abs(l.item() - l_ref.item()) < 1e-5
+    if hard:
+        assert torch.equal(w.argmax(1).cpu(), w_ref.argmax(1))
+    ((w * gw.cuda()).sum() + (wc * gc.cuda()).sum() + l * gl.cuda()).backward()
+    assert rel(pg.grad, pr.grad) < 2e-4
+    assert rel(fg.grad, fr.grad) < 2e-4
+
+
+def test_gate_from_weight(ops):
+    from oracle import dynmm_oracle as O
+    w = torch.zeros(4, 5)
+    w[range(4), [1, 4, 0, 3]] = 1
+    tab = torch.tensor(O.DEPTH_ENC_FLOP_R34)
+    ww, wc, l = ops.gate_from_weight(w.cuda(), tab.cuda())
+    assert torch.equal(ww.cpu(), w)
+    assert torch.equal(wc.cpu(), torch.tensor([[0., 1, 1, 1], [0, 0, 0, 0], [1, 1, 1, 1], [0, 0, 0, 1]]))
+    assert abs(l.item() - (w.mean(0) * tab).mean().item()) < 1e-6
+
+
+def test_cross_entropy_2d(ops, golden_dir):
+    import os
+    from oracle import dynmm_oracle as O
+    g = np.load(os.path.join(golden_dir, 'ops.npz'))
+    cw = torch.from_numpy(g['ce/weight'])
+    for i in range(2):
+        x, t = torch.from_numpy(g[f'ce/x{i}']), torch.from_numpy(g[f'ce/t{i}'])
+        xr = x.clone().requires_grad_(True)
+        l_ref = O.cross_entropy_2d([xr], [t], cw)[0]
+        l_ref.backward()
+        xg = x.cuda().requires_grad_(True)
+        l = ops.cross_entropy_2d(xg, t.cuda(), cw.cuda())
+        assert abs(l.item() - float(g[f'ce/loss{i}'])) < 1e-5      # the reference's own value
+        l.backward()
+        assert rel(xg.grad, xr.grad) < 1e-4
+
+
+def test_rejects_cpu_tensors(ops):
+    from dynmm_amd.lib import DynmmHipError
+    with pytest.raises(DynmmHipError):
+        ops.conv2d(torch.randn(1, 16, 8, 8), torch.randn(16, 16, 3, 3), None, 1, 1)
