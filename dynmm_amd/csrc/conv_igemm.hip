@@ -483,6 +483,7 @@ using namespace dynmm;
 
 extern "C" int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad, int Co, int Ci,
                                  int KH, int KW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!w || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return DYNMM_EINVAL;
     const int total = Co * Ci * KH * KW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0,
@@ -494,6 +495,7 @@ extern "C" int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
 extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
                                 const float* scale, const float* shift, const float* residual,
                                 float* y, const dynmm_conv_geom* g, int act, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !wp_fwd || !y || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (x2 != nullptr)) return DYNMM_EINVAL;
     IgemmArgs a{};
@@ -508,6 +510,7 @@ extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp
 
 extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
                                   float* dx, float* dx2, const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!dy || !wp_dgrad || !dx || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (dx2 != nullptr)) return DYNMM_EINVAL;
     if (mask && dx2) return DYNMM_EUNSUPPORTED;
@@ -531,6 +534,7 @@ extern "C" size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
 extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw,
                                   void* workspace, size_t workspace_bytes,
                                   const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !dy || !dw || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (x2 != nullptr)) return DYNMM_EINVAL;
     const WgradPlan p = plan_wgrad(g);
@@ -564,6 +568,7 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
 }
 
 extern "C" int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nslabs, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!slabs || !out || n <= 0 || nslabs <= 0) return DYNMM_EINVAL;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, slabs, out, n, nslabs);

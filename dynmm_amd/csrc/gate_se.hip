@@ -247,6 +247,7 @@ extern "C" int dynmm_se_coeff_fwd(const float* sr, const float* sd, const float*
                                   const float* wc, int wc_stride, float* a, float* b, float* hr,
                                   float* hd, float* gr, float* gd, int N, int C, int use_se,
                                   void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!a || !b || N <= 0 || C <= 0 || C > kMaxC) return DYNMM_EINVAL;
     SeParams P{};
     if (use_se) {
@@ -268,6 +269,7 @@ extern "C" int dynmm_se_coeff_bwd(const float* da, const float* db, const float*
                                   const float* hr, const float* hd, const float* gr, const float* gd,
                                   float* const* dparams, float* dsr, float* dsd, float* dwc,
                                   int dwc_stride, int N, int C, int use_se, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!da || !db || N <= 0 || C <= 0 || C > kMaxC) return DYNMM_EINVAL;
     SeParams P{};
     SeGrads G{};
@@ -294,6 +296,7 @@ extern "C" int dynmm_se_coeff_bwd(const float* da, const float* db, const float*
 extern "C" int dynmm_gate_head_fwd(const float* pooled, const float* fc, float* weight, float* wcum,
                                    float* soft, float* flop_loss, const float* flop_table, int N,
                                    int J, float temp, int hard, int mode, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!weight || !wcum || !soft || !flop_loss || !flop_table || N <= 0) return DYNMM_EINVAL;
     if (mode == 0 && (!pooled || !fc || J <= 0 || !(temp > 0.f))) return DYNMM_EINVAL;
     hipLaunchKernelGGL(gate_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pooled, fc,
@@ -306,6 +309,7 @@ extern "C" int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, c
                                    const float* pooled, const float* fc, const float* soft,
                                    const float* flop_table, float* d_pooled, float* d_fc, int N,
                                    int J, float temp, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!pooled || !fc || !soft || !flop_table || !d_pooled || !d_fc || N <= 0 || J <= 0)
         return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;

@@ -102,6 +102,7 @@ using namespace dynmm;
 
 extern "C" int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
                               double* loss_sum_wsum, int N, int C, int HW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !target || !cw || !loss_sum_wsum || N <= 0 || C <= 0 || C > kMaxClasses || HW <= 0)
         return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -115,6 +116,7 @@ extern "C" int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const
 
 extern "C" int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
                               const float* gscale, float* dx, int N, int C, int HW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !target || !cw || !gscale || !dx || N <= 0 || C <= 0 || C > kMaxClasses || HW <= 0)
         return DYNMM_EINVAL;
     int bx = ceil_div(HW, 256);
@@ -127,6 +129,7 @@ extern "C" int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const
 
 extern "C" int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const float* lr,
                                   float momentum, float weight_decay, float grad_scale, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!p || !g || !buf || !lr || n == 0) return DYNMM_EINVAL;
     if (!aligned16(p) || !aligned16(g) || !aligned16(buf)) return DYNMM_EUNSUPPORTED;
     size_t blocks = ceil_div_sz(n, 1024);

@@ -221,6 +221,7 @@ static inline int plane_chunk(int HW, int* nchunks) {
 using namespace dynmm;
 
 extern "C" int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
@@ -238,6 +239,7 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
                               float* save_mean, float* save_invstd, const float* residual, float* y,
                               int N, int C, int HW, float eps, float momentum, int training, int act,
                               void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (training && (!sums || (long long)N * HW <= 1)) return DYNMM_EINVAL;
     if (!training && (!running_mean || !running_var)) return DYNMM_EINVAL;
@@ -260,6 +262,7 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
 extern "C" int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x, const float* mean,
                                    const float* invstd, double* sums, int N, int C, int HW, int act,
                                    void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -279,6 +282,7 @@ extern "C" int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x
                                   const float* invstd, const float* gamma, const double* sums,
                                   float* dx, float* d_residual, float* dgamma, float* dbeta, int N,
                                   int C, int HW, int training, int act, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || HW <= 0)
         return DYNMM_EINVAL;
     if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
@@ -299,6 +303,7 @@ extern "C" int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x
 extern "C" int dynmm_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                              const float* running_var, const float* conv_bias, float* scale,
                              float* shift, int C, float eps, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0)
         return DYNMM_EINVAL;
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -309,6 +314,7 @@ extern "C" int dynmm_bn_fold(const float* gamma, const float* beta, const float*
 
 extern "C" int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias,
                                   int N, int C, int HW, int act, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
     if (!g_out && !dbias) return DYNMM_EINVAL;

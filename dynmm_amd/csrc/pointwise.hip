@@ -387,6 +387,7 @@ using namespace dynmm;
 
 extern "C" int dynmm_maxpool3x3s2_fwd(const float* x, float* y, signed char* idx, int N, int C, int H,
                                       int W, int Ho, int Wo, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return DYNMM_EINVAL;
     dim3 grid(N * C, plane_chunks(Ho * Wo, kChunk));
@@ -397,6 +398,7 @@ extern "C" int dynmm_maxpool3x3s2_fwd(const float* x, float* y, signed char* idx
 
 extern "C" int dynmm_maxpool3x3s2_bwd(const float* g, const signed char* idx, float* dx, int N, int C,
                                       int H, int W, int Ho, int Wo, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !idx || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     dim3 grid(N * C, plane_chunks(H * W, kChunk));
     hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);
@@ -406,6 +408,7 @@ extern "C" int dynmm_maxpool3x3s2_bwd(const float* g, const signed char* idx, fl
 
 extern "C" int dynmm_adaptive_avgpool_fwd(const float* x, float* y, int NC, int H, int W, int OH,
                                           int OW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return DYNMM_EINVAL;
     hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, dim3(ceil_div(NC * OH * OW, 256)), dim3(256), 0,
                        ST, x, y, NC, H, W, OH, OW);
@@ -415,6 +418,7 @@ extern "C" int dynmm_adaptive_avgpool_fwd(const float* x, float* y, int NC, int 
 
 extern "C" int dynmm_adaptive_avgpool_bwd(const float* g, float* dx, int NC, int H, int W, int OH,
                                           int OW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !dx || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return DYNMM_EINVAL;
     hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(ceil_div(NC * H * W, 256)), dim3(256), 0,
                        ST, g, dx, NC, H, W, OH, OW);
@@ -424,6 +428,7 @@ extern "C" int dynmm_adaptive_avgpool_bwd(const float* g, float* dx, int NC, int
 
 extern "C" int dynmm_nearest_into_fwd(const float* y, float* out, int N, int C, int h, int w,
                                       int Ctot, int c_off, int H, int W, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!y || !out || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     if (c_off < 0 || c_off + C > Ctot) return DYNMM_EINVAL;
     hipLaunchKernelGGL(nearest_into_fwd_kernel, dim3(ceil_div(N * C * H * W, 256)), dim3(256), 0, ST,
@@ -434,6 +439,7 @@ extern "C" int dynmm_nearest_into_fwd(const float* y, float* out, int N, int C, 
 
 extern "C" int dynmm_nearest_into_bwd(const float* g_out, float* dy, int N, int C, int h, int w,
                                       int Ctot, int c_off, int H, int W, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g_out || !dy || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     if (c_off < 0 || c_off + C > Ctot) return DYNMM_EINVAL;
     hipLaunchKernelGGL(nearest_into_bwd_kernel, dim3(ceil_div(N * C * h * w, 256)), dim3(256), 0, ST,
@@ -445,6 +451,7 @@ extern "C" int dynmm_nearest_into_bwd(const float* g_out, float* dy, int N, int 
 extern "C" int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const float* b,
                                           const float* skip, float* y, int N, int C, int H, int W,
                                           void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !w || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     dim3 grid(N * C, plane_chunks(4 * H * W, kChunk));
     // V=4: four consecutive outputs of one row per lane (2W % 4 == 0 keeps a quad inside its row)
@@ -459,6 +466,7 @@ extern "C" int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const 
 extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const float* w, float* dx,
                                           float* dw, float* db, int N, int C, int H, int W,
                                           void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !w || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     if (dx) {
         dim3 grid(N * C, plane_chunks(H * W, kChunk));
@@ -480,6 +488,7 @@ extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const 
 
 extern "C" int dynmm_gap2_fwd(const float* xr, const float* xd, float* sr, float* sd, int NC, int HW,
                               void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!xr || !sr || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (xd && !sd) return DYNMM_EINVAL;
     if (can_vec4(HW, {xr, xd}))
@@ -492,6 +501,7 @@ extern "C" int dynmm_gap2_fwd(const float* xr, const float* xd, float* sr, float
 
 extern "C" int dynmm_axpby_fwd(const float* xr, const float* xd, const float* a, const float* b,
                                float* out, int NC, int HW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!xr || !xd || !a || !b || !out || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
     dim3 grid(NC, plane_chunks(HW, kChunk));
     if (can_vec4(HW, {xr, xd, out}))
@@ -504,6 +514,7 @@ extern "C" int dynmm_axpby_fwd(const float* xr, const float* xd, const float* a,
 
 extern "C" int dynmm_axpby_bwd_reduce(const float* g, const float* xr, const float* xd, float* da,
                                       float* db, int NC, int HW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !xr || !xd || !da || !db || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (can_vec4(HW, {g, xr, xd}))
         hipLaunchKernelGGL(axpby_bwd_reduce_kernel<4>, dim3(NC), dim3(256), 0, ST, g, xr, xd, da, db, HW);
@@ -516,6 +527,7 @@ extern "C" int dynmm_axpby_bwd_reduce(const float* g, const float* xr, const flo
 extern "C" int dynmm_axpby_bwd_apply(const float* g, const float* a, const float* b, const float* ca,
                                      const float* cb, float cscale, float* dxr, float* dxd, int NC,
                                      int HW, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !a || !b || !dxr || !dxd || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
     dim3 grid(NC, plane_chunks(HW, kChunk));
     if (can_vec4(HW, {g, dxr, dxd}))

@@ -92,7 +92,16 @@ def load():
         raise DynmmHipError(
             f'{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). '
             'Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C dynmm_amd/csrc`.')
+    # PyTorch-ROCm ships its own libamdhip64 in torch/lib.  Import torch FIRST so that our library's
+    # DT_NEEDED libamdhip64.so.N binds to that already-loaded runtime; loading ours first would put a
+    # second HIP runtime (from /opt/rocm) in the process, in which torch's device context and
+    # allocations do not exist (launches then fail with hipErrorNoDevice).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    runtimes = _mapped_hip_runtimes()
+    if len(runtimes) > 1:
+        raise DynmmHipError(f'two HIP runtimes are mapped in this process: {sorted(runtimes)}; '
+                            'import torch before anything that links libamdhip64')
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
@@ -101,6 +110,14 @@ def load():
         raise DynmmHipError('libdynmm_hip.so ABI version mismatch')
     _lib = lib
     return lib
+
+
+def _mapped_hip_runtimes():
+    try:
+        with open('/proc/self/maps') as f:
+            return {ln.split()[-1] for ln in f if 'libamdhip64' in ln}
+    except OSError:
+        return set()
 
 
 def check(status, what):

@@ -247,9 +247,9 @@ def test_se_fuse_blend(ops, use_se, col, shape):
     wcum = torch.rand(N, 4, generator=torch.Generator().manual_seed(11))
 
     def run(dev, fn):
-        r, d = rgb.to(dev).requires_grad_(True), depth.to(dev).requires_grad_(True)
-        ps = [p.to(dev).requires_grad_(True) for p in params]
-        wc = wcum.to(dev).requires_grad_(True)
+        r, d = [t.detach().clone().to(dev).requires_grad_(True) for t in (rgb, depth)]
+        ps = [p.detach().clone().to(dev).requires_grad_(True) for p in params]
+        wc = wcum.detach().clone().to(dev).requires_grad_(True)
         out = fn(r, d, ps, wc)
         out.backward(rnd(*shape, seed=12).to(dev))
         return out, r, d, ps, wc
