@@ -1,0 +1,115 @@
+"""Pure data-parallel gradient exchange for the hot path: one process per GPU, a full
+replica per rank, ONE logical all-reduce(sum)/world of all gradients per step over RCCL/xGMI.
+
+Design for MI355X: gradients live in a single flat fp32 buffer (129.6 MB for config P) carved into a
+few large buckets; every parameter's `.grad` is a view into it, so autograd accumulates in place and
+no flatten/unflatten copies exist.  xGMI is point-to-point, so a ring all-reduce is bound by one link
+(~153 GB/s/dir): a few ~32 MB buckets keep each collective far above the latency floor while letting
+the first buckets (decoder grads, produced first) fly on a side stream under the rest of backward.
+BatchNorm statistics stay per replica (DDP semantics; the reference has no SyncBN).
+
+Works with any torch.distributed backend: `nccl` (= RCCL) on GPUs, `gloo` on CPU for the
+world_size-2 tests in tests/test_dp_gloo.py.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, params, bucket_mb=32.0, overlap=True, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        dev = self.params[0].device
+        # buckets are filled in REVERSE parameter order: backward produces the last layers' grads first
+        order = list(reversed(self.params))
+        total = sum(p.numel() for p in order)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets = []          # (start, end) element ranges in self.flat
+        self._bucket_of = {}
+        off, bstart, bidx = 0, 0, 0
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[p] = bidx
+            off += n
+            if off - bstart >= cap:
+                self.buckets.append((bstart, off))
+                bstart, bidx = off, bidx + 1
+        if off > bstart:
+            self.buckets.append((bstart, off))
+        self._pending = [0] * len(self.buckets)
+        self._count = [0] * len(self.buckets)
+        for p in order:
+            self._count[self._bucket_of[p]] += 1
+        self._works = []
+        self.overlap = overlap and self.world > 1
+        self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda') else None
+        self._hooks = []
+        if self.overlap:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+
+    # -- step protocol --------------------------------------------------------------------------
+    def zero(self):
+        """Start of a step: clear the flat buffer (grads accumulate in place into their views)."""
+        self.flat.zero_()
+        self._pending = list(self._count)
+        self._works = []
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        chunk = self.flat[s:e]
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad_ready(self, p):
+        b = self._bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """After backward: make sure every bucket is reduced, then average."""
+        if self.world == 1:
+            return
+        if not self.overlap:
+            for b in range(len(self.buckets)):
+                self._launch(b)
+        else:
+            for b, left in enumerate(self._pending):   # params that received no grad this step
+                if left > 0:
+                    self._launch(b)
+        for w in self._works:
+            w.wait()
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self.flat.mul_(1.0 / self.world)
+        self._works = []
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_parameters(module, src=0, process_group=None):
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=process_group)
+
+
+def shard_batch(global_batch, rank, world):
+    """Contiguous per-rank slice [lo, hi) of a global batch (used by train/eval drivers)."""
+    per = global_batch // world
+    rem = global_batch % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)

@@ -41,6 +41,29 @@ def _chk(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Optional per-launch timing of the implicit-GEMM kernels (bench.py's roofline leg): when PROFILE is a
+# list, every conv launch is bracketed by events recorded on the stream it is launched on.
+PROFILE = None
+
+
+def _tile(co):
+    return '128x128' if co > 64 else ('64x256' if co > 32 else '32x256')
+
+
+def _timed(kind, g, call):
+    if PROFILE is None:
+        return call()
+    co = g.Ci if kind == 'dgrad' else g.Co
+    name = f'conv_{"wgrad" if kind == "wgrad" else "igemm"}_{kind}<{_tile(co) if kind != "wgrad" else ("co" + _tile(co).split("x")[0])}>'
+    flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = call()
+    e1.record()
+    PROFILE.append((name, flops, e0, e1))
+    return r
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -75,8 +98,8 @@ class _Conv2d(Function):
         wpd = torch.empty(K * g.Co, device=x.device, dtype=torch.float32) if need_dx else None
         L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
         y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=x.device, dtype=torch.float32)
-        L.check(lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
-                                     C.byref(g), act, st), 'conv2d_fwd')
+        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
+                                                              C.byref(g), act, st)), 'conv2d_fwd')
         ctx.geom = g
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -104,15 +127,15 @@ class _Conv2d(Function):
         if wpd is not None:
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            L.check(lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), None, _p(dx), _p(dx2), C.byref(g), st),
-                    'conv2d_dgrad')
+            L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), None, _p(dx), _p(dx2),
+                                                                      C.byref(g), st)), 'conv2d_dgrad')
         dw = None
         if ctx.needs_input_grad[2]:
             dw = torch.empty(ctx.wshape, device=gy.device, dtype=torch.float32)
             nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
             ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
-            L.check(lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes, C.byref(g), st),
-                    'conv2d_wgrad')
+            L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes,
+                                                                      C.byref(g), st)), 'conv2d_wgrad')
         return dx, dx2, dw, dbias, None, None, None
 
 
@@ -142,8 +165,8 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     else:
         shift = _chk(conv_bias, 'bias')
     y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=dev, dtype=torch.float32)
-    L.check(lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual), _p(y),
-                                 C.byref(g), ACT[act], st), 'conv2d_fwd')
+    L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
+                                                          _p(y), C.byref(g), ACT[act], st)), 'conv2d_fwd')
     return y
 
 
