@@ -105,12 +105,19 @@ def kernel_timing(step_fn):
     step_fn()
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
-    agg = {}
-    for name, flops, e0, e1 in rec:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += e0.elapsed_time(e1)
-        a[2] += flops
+    agg, shapes = {}, {}
+    for name, flops, e0, e1, shape in rec:
+        ms = e0.elapsed_time(e1)
+        for d, key in ((agg, name), (shapes, (name, shape))):
+            a = d.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += flops
+    if os.environ.get('DYNMM_BENCH_SHAPES'):
+        with open(os.environ['DYNMM_BENCH_SHAPES'], 'w') as f:
+            f.write('kernel | N,Ci,H,W,Co,KH,KW,SH,SW | launches | total ms | avg us | TFLOP/s\n')
+            for (name, shape), (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                f.write(f'{name} | {shape} | {n} | {ms:.3f} | {1000 * ms / n:.1f} | {fl / (ms * 1e-3) / 1e12:.1f}\n')
     return agg
 
 

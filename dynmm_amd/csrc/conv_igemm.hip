@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct IgemmArgs {
     const float* x;        // gemm input  [N, Ci, H, W]  (first c_in_split channels)
     const float* x2;       // remaining input channels or nullptr
-    const float* wp;       // packed weights [K][Co]
+    const float* wp;       // packed weights [K][CoP]  (CoP = Co rounded up to 4)
     const float* scale;    // [Co] or nullptr
     const float* shift;    // [Co] or nullptr
     const float* residual; // like y or nullptr
@@ -35,9 +35,19 @@ struct IgemmArgs {
     int KH, KW, SH, SW, PH, PW;
     int c_in_split, c_out_split;
     int act;
-    int M, K;
+    int M, K, CoP;
     int n_co_tiles, n_pix_tiles;
 };
+
+// uniform (SGPR) base + 32-bit per-lane byte offset: lets the compiler pick the
+// `global_load_dword v, v_off, s[base:base+1]` form — one VALU-free address per load instead of a
+// 64-bit multiply-add chain.  All tensors on this path are < 4 GiB (checked in geom_ok).
+__device__ __forceinline__ float ldg_f32(const float* sbase, unsigned voff_bytes) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
+}
+__device__ __forceinline__ float4 ldg_f32x4(const float* sbase, unsigned voff_bytes) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
@@ -48,11 +58,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
     constexpr int MCO = WCO / 32, MPIX = WPIX / 32;
     constexpr int WAVES_PIX = TPIX / WPIX;
     static_assert((TCO / WCO) * WAVES_PIX == 4, "4 waves per workgroup");
-    constexpr int A_PER = BK * TCO / 256, A_ROWSTEP = 256 / TCO;
+    // weight tile: float4 along co.  AQ float4 per k-row.
+    constexpr int AQ = TCO / 4, A_ROWSTEP = 256 / AQ;
+    constexpr int A_PER = (BK * AQ + 255) / 256;
     constexpr int B_PER = BK * TPIX / 256, B_ROWSTEP = 256 / TPIX;
 
-    __shared__ float As[2][BK][TCO];
-    __shared__ float Bs[2][BK][TPIX];
+    __shared__ __attribute__((aligned(16))) float As[2][BK][TCO];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][TPIX];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -69,9 +81,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
     const int HoWo = a.Ho * a.Wo;
 
     // ---- per-thread loader coordinates (fixed for the whole K loop) ----
-    const int a_col = t % TCO, a_row0 = t / TCO;
-    const int co_a = co0 + a_col;
-    const bool a_ok = co_a < a.Co;
+    const int a_q = t % AQ, a_row0 = t / AQ;
+    const bool a_active = a_row0 < BK;                 // TCO=32: only half the threads carry weights
+    int q_glob = co0 / 4 + a_q;
+    if (q_glob > a.CoP / 4 - 1) q_glob = a.CoP / 4 - 1;  // rows past Co: finite junk, discarded below
+    const unsigned a_voff = (unsigned)((a_active ? a_row0 : 0) * a.CoP + q_glob * 4) * 4u;
 
     const int b_col = t % TPIX, b_row0 = t / TPIX;
     const int m_b = pix0 + b_col;
@@ -84,13 +98,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
         ow_b = rem - oh_b * a.Wo;
     }
     const int c2 = a.Ci - a.c_in_split;
-    const float* xn = a.x + (size_t)n_b * a.c_in_split * HW;
-    const float* x2n = a.x2 ? a.x2 + (size_t)n_b * c2 * HW : nullptr;
-
-    float ra[A_PER], rb[B_PER];
-
-    const int cpt = GENERIC ? 1 : a.Ci / BK;                  // K-chunks per filter tap
-    const int nk = GENERIC ? (a.K + BK - 1) / BK : a.KH * a.KW * cpt;
 
     auto in_coord = [&](int r, int s, int& ih, int& iw) -> bool {
         if (!DGRAD) {
@@ -106,62 +113,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
         }
     };
 
-    auto load_tile = [&](int kt) {
-        if (!GENERIC) {
-            const int tap = kt / cpt;
-            const int ci0 = (kt - tap * cpt) * BK;
-            const int r = tap / a.KW, s = tap - r * a.KW;
-            const int kbase = tap * a.Ci + ci0;
-#pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int row = a_row0 + i * A_ROWSTEP;
-                ra[i] = a_ok ? a.wp[(size_t)(kbase + row) * a.Co + co_a] : 0.f;
-            }
-            int ih = 0, iw = 0;
-            const bool ok = in_coord(r, s, ih, iw);
-            const float* base = (ci0 < a.c_in_split) ? xn + (size_t)ci0 * HW
-                                                     : x2n + (size_t)(ci0 - a.c_in_split) * HW;
-            const int off = ih * a.W + iw;
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int row = b_row0 + i * B_ROWSTEP;
-                rb[i] = ok ? base[(size_t)row * HW + off] : 0.f;
-            }
-        } else {
-            const int kbase = kt * BK;
-#pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int k = kbase + a_row0 + i * A_ROWSTEP;
-                ra[i] = (a_ok && k < a.K) ? a.wp[(size_t)k * a.Co + co_a] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int k = kbase + b_row0 + i * B_ROWSTEP;
-                float v = 0.f;
-                if (k < a.K) {
-                    const int tap = k / a.Ci;
-                    const int ci = k - tap * a.Ci;
-                    const int r = tap / a.KW, s = tap - r * a.KW;
-                    int ih = 0, iw = 0;
-                    if (in_coord(r, s, ih, iw)) {
-                        const float* p = (ci < a.c_in_split)
-                                             ? xn + (size_t)ci * HW
-                                             : x2n + (size_t)(ci - a.c_in_split) * HW;
-                        v = p[ih * a.W + iw];
-                    }
-                }
-                rb[i] = v;
-            }
-        }
-    };
-
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) As[buf][a_row0 + i * A_ROWSTEP][a_col] = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = rb[i];
-    };
-
+    float4 ra[A_PER];
+    float rb[B_PER];
     f32x16 acc[MCO][MPIX];
 #pragma unroll
     for (int mi = 0; mi < MCO; ++mi)
@@ -170,14 +123,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int khalf = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);   // global loads fly under the MFMAs below
+
+    auto mfma_tile = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float af[MCO], bf[MPIX];
@@ -193,8 +141,119 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
                 for (int ni = 0; ni < MPIX; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    if constexpr (!GENERIC) {
+        // ---------------- fast path: Ci % 16 == 0, one filter tap per K-step ----------------
+        const int cpt = a.Ci / BK;
+        const int nk = a.KH * a.KW * cpt;
+        // K-iteration state (wave-uniform) and the per-lane tap geometry
+        int ci0 = 0, tr = 0, ts = 0, kbase = 0;
+        bool tap_ok;
+        unsigned voff1, voff2;          // byte offsets into x / x2 for the current tap
+        auto set_tap = [&]() {
+            int ih = 0, iw = 0;
+            tap_ok = in_coord(tr, ts, ih, iw);
+            const unsigned pix = tap_ok ? (unsigned)(ih * a.W + iw) : 0u;
+            voff1 = ((unsigned)(n_b * a.c_in_split + b_row0) * (unsigned)HW + pix) * 4u;
+            voff2 = ((unsigned)(n_b * c2 + b_row0) * (unsigned)HW + pix) * 4u;
+        };
+        bool ld_ok = false;             // validity of the tile currently held in rb[]
+        auto load_tile = [&]() {
+            // weights: rows kbase + a_row0 + i*A_ROWSTEP, 4 consecutive co per lane
+            const float* wbase = a.wp + (size_t)kbase * a.CoP;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                ra[i] = ldg_f32x4(wbase + (size_t)(i * A_ROWSTEP) * a.CoP, a_voff);
+            // activations: channels ci0 + b_row0 + i*B_ROWSTEP at this lane's (tap-shifted) pixel
+            const bool first = ci0 < a.c_in_split;
+            const float* xbase = first ? a.x + (size_t)ci0 * HW : a.x2 + (size_t)(ci0 - a.c_in_split) * HW;
+            const unsigned voff = first ? voff1 : voff2;
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+                rb[i] = ldg_f32(xbase + (size_t)(i * B_ROWSTEP) * HW, voff);
+            ld_ok = tap_ok;
+            // advance the K iterator
+            ci0 += BK;
+            kbase += BK;
+            if (ci0 >= a.Ci) {
+                ci0 = 0;
+                if (++ts == a.KW) { ts = 0; ++tr; }
+                set_tap();
+            }
+        };
+        auto store_tile = [&](int buf) {
+            if (a_active) {
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i)
+                    *reinterpret_cast<float4*>(&As[buf][a_row0 + i * A_ROWSTEP][a_q * 4]) = ra[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = ld_ok ? rb[i] : 0.f;
+        };
+
+        set_tap();
+        load_tile();
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile();        // global loads fly under the MFMAs below
+            mfma_tile(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // ---------------- generic path: any Ci (stems Ci=1/3, gate Ci=8, dgrad of Co=40) ----------------
+        constexpr int AS_PER = BK * TCO / 256, AS_ROWSTEP = 256 / TCO;
+        const int a_col = t % TCO, as_row0 = t / TCO;
+        const int co_a = co0 + a_col;
+        const bool a_ok = co_a < a.Co;
+        const float* xn = a.x + (size_t)n_b * a.c_in_split * HW;
+        const float* x2n = a.x2 ? a.x2 + (size_t)n_b * c2 * HW : nullptr;
+        float rs[AS_PER];
+        const int nk = (a.K + BK - 1) / BK;
+        auto load_tile = [&](int kt) {
+            const int kb = kt * BK;
+#pragma unroll
+            for (int i = 0; i < AS_PER; ++i) {
+                const int k = kb + as_row0 + i * AS_ROWSTEP;
+                rs[i] = (a_ok && k < a.K) ? a.wp[(size_t)k * a.CoP + co_a] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int k = kb + b_row0 + i * B_ROWSTEP;
+                float v = 0.f;
+                if (k < a.K) {
+                    const int tap = k / a.Ci;
+                    const int ci = k - tap * a.Ci;
+                    const int r = tap / a.KW, s = tap - r * a.KW;
+                    int ih = 0, iw = 0;
+                    if (in_coord(r, s, ih, iw)) {
+                        const float* p = (ci < a.c_in_split) ? xn + (size_t)ci * HW
+                                                             : x2n + (size_t)(ci - a.c_in_split) * HW;
+                        v = p[ih * a.W + iw];
+                    }
+                }
+                rb[i] = v;
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < AS_PER; ++i) As[buf][as_row0 + i * AS_ROWSTEP][a_col] = rs[i];
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = rb[i];
+        };
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile(kt + 1);
+            mfma_tile(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: scale/shift (bias or folded BN), residual, activation, ReLU-mask; NCHW store ----
@@ -236,9 +295,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
 template <bool DGRAD>
 static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     const bool dual_in = a.x2 != nullptr;
-    const bool generic = (a.Ci % 16 != 0) || (dual_in && (a.c_in_split % 16 != 0));
+    const bool generic = (a.Ci % 16 != 0) || (dual_in && (a.c_in_split % 16 != 0)) ||
+                         ((reinterpret_cast<uintptr_t>(a.wp) & 15u) != 0);
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Ci;
+    a.CoP = (a.Co + 3) & ~3;
 #define DYNMM_IGEMM_LAUNCH(TCO, TPIX, WCO, WPIX)                                               \
     do {                                                                                       \
         a.n_co_tiles = ceil_div(a.Co, TCO);                                                    \
@@ -251,12 +312,19 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((conv_igemm_kernel<TCO, TPIX, WCO, WPIX, DGRAD, false>), grid,  \
                                dim3(256), 0, st, a);                                           \
     } while (0)
-    if (a.Co > 64)
-        DYNMM_IGEMM_LAUNCH(128, 128, 64, 64);
-    else if (a.Co > 32)
+    if (a.Co > 64) {
+        // 256 CUs x 3 resident workgroups: below one full residency round, halve the pixel tile so
+        // the deep stages (M = N*15*20 .. N*30*40) still spread over every CU.
+        const long blocks128 = (long)ceil_div(a.Co, 128) * ceil_div(a.M, 128);
+        if (blocks128 < 768)
+            DYNMM_IGEMM_LAUNCH(128, 64, 64, 32);
+        else
+            DYNMM_IGEMM_LAUNCH(128, 128, 64, 64);
+    } else if (a.Co > 32) {
         DYNMM_IGEMM_LAUNCH(64, 256, 64, 64);
-    else
+    } else {
         DYNMM_IGEMM_LAUNCH(32, 256, 32, 64);
+    }
 #undef DYNMM_IGEMM_LAUNCH
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
@@ -279,7 +347,7 @@ struct WgradArgs {
     int steps_per_split;   // 32-pixel steps handled by one workgroup
 };
 
-template <int TCO, int TK, int WCO, int WK>
+template <int TCO, int TK, int WCO, int WK, bool DUAL>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     constexpr int BP = 32, LDP = BP + 1;     // +1 pad: column reads of the [row][pixel] tiles
     constexpr int MCO = WCO / 32, MK = WK / 32;
@@ -304,18 +372,31 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     const int p = t & 31, rg = t >> 5;
     const int c2 = a.Ci - a.c_split;
 
-    // per-thread description of the X rows it gathers: ci | r<<16 | s<<24, or -1 (k >= K)
-    int xinfo[X_PER];
+    // per-thread row descriptors, fixed for the whole pixel loop:
+    //   dy rows: byte offset of channel min(co, Co-1) (rows past Co are junk and never stored)
+    //   x rows : element offset ci*HW + r*W + s and packed (r, s, second-input flag, k<K flag)
+    unsigned goff[G_PER];
+#pragma unroll
+    for (int i = 0; i < G_PER; ++i) {
+        int co = co0 + rg + 8 * i;
+        if (co > a.Co - 1) co = a.Co - 1;
+        goff[i] = (unsigned)co * (unsigned)HoWo * 4u;
+    }
+    int xoff[X_PER], xrs[X_PER];
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
         const int k = k0 + rg + 8 * i;
         if (k < a.K) {
             const int tap = k / a.Ci;
-            const int ci = k - tap * a.Ci;
+            int ci = k - tap * a.Ci;
             const int r = tap / a.KW, s = tap - r * a.KW;
-            xinfo[i] = ci | (r << 16) | (s << 24);
+            int second = 0;
+            if (DUAL && ci >= a.c_split) { ci -= a.c_split; second = 1; }
+            xoff[i] = ci * HW + r * a.W + s;
+            xrs[i] = r | (s << 8) | (second << 16) | (1 << 17);
         } else {
-            xinfo[i] = -1;
+            xoff[i] = 0;
+            xrs[i] = 0;
         }
     }
 
@@ -334,29 +415,26 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             oh = rem / a.Wo;
             ow = rem - oh * a.Wo;
         }
-        const float* dyn = a.dy + (size_t)n * a.Co * HoWo + rem;
+        const unsigned gv = ((unsigned)(n * a.Co) * (unsigned)HoWo + (unsigned)rem) * 4u;
 #pragma unroll
         for (int i = 0; i < G_PER; ++i) {
-            const int co = co0 + rg + 8 * i;
-            rgv[i] = (ok && co < a.Co) ? dyn[(size_t)co * HoWo] : 0.f;
+            const float v = ldg_f32(a.dy, gv + goff[i]);
+            rgv[i] = ok ? v : 0.f;
         }
-        const float* xn = a.x + (size_t)n * a.c_split * HW;
-        const float* x2n = a.x2 ? a.x2 + (size_t)n * c2 * HW : nullptr;
         const int ihb = oh * a.SH - a.PH, iwb = ow * a.SW - a.PW;
+        const int xb1 = n * a.c_split * HW + ihb * a.W + iwb;     // may be negative at the borders
+        const int xb2 = DUAL ? n * c2 * HW + ihb * a.W + iwb : 0;
 #pragma unroll
         for (int i = 0; i < X_PER; ++i) {
-            float v = 0.f;
-            const int info = xinfo[i];
-            if (ok && info >= 0) {
-                const int ci = info & 0xffff;
-                const int ih = ihb + ((info >> 16) & 0xff), iw = iwb + ((info >> 24) & 0x7f);
-                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-                    const float* pl = (ci < a.c_split) ? xn + (size_t)ci * HW
-                                                       : x2n + (size_t)(ci - a.c_split) * HW;
-                    v = pl[ih * a.W + iw];
-                }
-            }
-            rxv[i] = v;
+            const int d = xrs[i];
+            const int r = d & 0xff, s = (d >> 8) & 0xff;
+            const bool valid = ok && (d >> 17) && (unsigned)(ihb + r) < (unsigned)a.H &&
+                               (unsigned)(iwb + s) < (unsigned)a.W;
+            const bool second = DUAL && ((d >> 16) & 1);
+            const int e = (second ? xb2 : xb1) + xoff[i];
+            const unsigned vo = valid ? (unsigned)e * 4u : 0u;
+            const float v = ldg_f32(second ? a.x2 : a.x, vo);
+            rxv[i] = valid ? v : 0.f;
         }
     };
     auto store_step = [&]() {
@@ -431,7 +509,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     const int M = g->N * g->Ho * g->Wo;
     const int total_steps = ceil_div(M, 32);
     const int tiles = p.n_co_tiles * p.n_k_tiles;
-    int splits = ceil_div(1024, tiles);                // ~4 workgroups per CU in flight
+    int splits = ceil_div(768, tiles);                 // one residency round: 256 CUs x 3 workgroups
     const int max_splits = ceil_div(total_steps, 8);   // >= 256 pixels per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -440,19 +518,39 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     return p;
 }
 
+template <int V>
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs,
                                                            float* __restrict__ out, int n, int nslabs) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * V;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * n + i];
-    out[i] = s;
+    if (V == 4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nslabs; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)k * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = s;
+    } else {
+        float s = 0.f;
+        for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * n + i];
+        out[i] = s;
+    }
 }
 
+static void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipStream_t st) {
+    const bool v4 = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    if (v4)
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, slabs, out, n, nslabs);
+    else
+        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(ceil_div(n, 256)), dim3(256), 0, st, slabs, out, n, nslabs);
+}
+
+// wf[(tap*Ci+ci)*CoP + co], wd[(tap*Co+co)*CiP + ci]; padding columns are never consumed.
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w,
                                                           float* __restrict__ wf,
                                                           float* __restrict__ wd,
-                                                          int Co, int Ci, int KHKW) {
+                                                          int Co, int Ci, int KHKW, int CoP, int CiP) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int total = Co * Ci * KHKW;
     if (i >= total) return;
@@ -460,8 +558,8 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     const int ci = (i / KHKW) % Ci;
     const int co = i / (KHKW * Ci);
     const float v = w[i];
-    if (wf) wf[((size_t)tap * Ci + ci) * Co + co] = v;
-    if (wd) wd[((size_t)tap * Co + co) * Ci + ci] = v;
+    if (wf) wf[((size_t)tap * Ci + ci) * CoP + co] = v;
+    if (wd) wd[((size_t)tap * Co + co) * CiP + ci] = v;
 }
 
 static bool geom_ok(const dynmm_conv_geom* g) {
@@ -472,8 +570,8 @@ static bool geom_ok(const dynmm_conv_geom* g) {
     if (g->Ho != (g->H + 2 * g->PH - g->KH) / g->SH + 1) return false;
     if (g->Wo != (g->W + 2 * g->PW - g->KW) / g->SW + 1) return false;
     if (g->c_split <= 0 || g->c_split > g->Ci) return false;
-    if ((double)g->N * g->Ci * g->H * g->W >= 2147483647.0) return false;
-    if ((double)g->N * g->Co * g->Ho * g->Wo >= 2147483647.0) return false;
+    if ((double)g->N * g->Ci * g->H * g->W >= 1073741824.0) return false;   // 32-bit byte offsets
+    if ((double)g->N * g->Co * g->Ho * g->Wo >= 1073741824.0) return false;
     return true;
 }
 
@@ -487,7 +585,7 @@ extern "C" int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
     if (!w || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return DYNMM_EINVAL;
     const int total = Co * Ci * KH * KW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, wp_fwd, wp_dgrad, Co, Ci, KH * KW);
+                       (hipStream_t)stream, w, wp_fwd, wp_dgrad, Co, Ci, KH * KW, (Co + 3) & ~3, (Ci + 3) & ~3);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -551,17 +649,24 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     a.n_co_tiles = p.n_co_tiles; a.n_k_tiles = p.n_k_tiles; a.steps_per_split = p.steps_per_split;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(p.n_co_tiles * p.n_k_tiles), (unsigned)p.splits);
+    const bool dual = x2 != nullptr;
+#define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
+    do {                                                                                              \
+        if (dual)                                                                                     \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, true>), grid, dim3(256), 0, st, a);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false>), grid, dim3(256), 0, st, a); \
+    } while (0)
     if (p.tco == 128)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, a);
+        DYNMM_WGRAD_LAUNCH(128, 128, 64, 64);
     else if (p.tco == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 64, 32>), grid, dim3(256), 0, st, a);
+        DYNMM_WGRAD_LAUNCH(64, 128, 64, 32);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 32, 32>), grid, dim3(256), 0, st, a);
+        DYNMM_WGRAD_LAUNCH(32, 128, 32, 32);
+#undef DYNMM_WGRAD_LAUNCH
     DYNMM_LAUNCH_CHECK();
     if (p.splits > 1) {
-        const int n = g->Co * a.K;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st,
-                           (const float*)workspace, dw, n, p.splits);
+        launch_reduce_slabs((const float*)workspace, dw, g->Co * a.K, p.splits, st);
         DYNMM_LAUNCH_CHECK();
     }
     return DYNMM_OK;
@@ -570,8 +675,7 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
 extern "C" int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nslabs, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!slabs || !out || n <= 0 || nslabs <= 0) return DYNMM_EINVAL;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, slabs, out, n, nslabs);
+    launch_reduce_slabs(slabs, out, n, nslabs, (hipStream_t)stream);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -60,8 +60,12 @@ def _timed(kind, g, call):
     e0.record()
     r = call()
     e1.record()
-    PROFILE.append((name, flops, e0, e1))
+    PROFILE.append((name, flops, e0, e1, (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW)))
     return r
+
+
+def _up4(v):
+    return (v + 3) & ~3
 
 
 def _pair(v):
@@ -94,8 +98,9 @@ class _Conv2d(Function):
         g = _geom(x, x2, weight, stride, padding)
         K = g.Ci * g.KH * g.KW
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
-        wp = torch.empty(K * g.Co, device=x.device, dtype=torch.float32)
-        wpd = torch.empty(K * g.Co, device=x.device, dtype=torch.float32) if need_dx else None
+        taps = g.KH * g.KW
+        wp = torch.empty(taps * g.Ci * _up4(g.Co), device=x.device, dtype=torch.float32)
+        wpd = torch.empty(taps * g.Co * _up4(g.Ci), device=x.device, dtype=torch.float32) if need_dx else None
         L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
         y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=x.device, dtype=torch.float32)
         L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
@@ -154,7 +159,7 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     g = _geom(x, x2, weight, _pair(stride), _pair(padding))
     K = g.Ci * g.KH * g.KW
     dev = x.device
-    wp = torch.empty(K * g.Co, device=dev, dtype=torch.float32)
+    wp = torch.empty(g.KH * g.KW * g.Ci * _up4(g.Co), device=dev, dtype=torch.float32)
     L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
     scale = shift = None
     if bn is not None:

@@ -51,8 +51,10 @@ typedef struct {
 } dynmm_conv_geom;
 
 /* Re-layout of a conv weight for the implicit-GEMM kernels (done per step; weights are small).
- *   wp_fwd  [(tap*Ci+ci)][Co]   (tap = r*KW+s)   — operand of dynmm_conv2d_fwd
- *   wp_dgrad[(tap*Co+co)][Ci]                     — operand of dynmm_conv2d_dgrad
+ *   wp_fwd  [(tap*Ci+ci)][CoP]  (tap = r*KW+s)   — operand of dynmm_conv2d_fwd
+ *   wp_dgrad[(tap*Co+co)][CiP]                    — operand of dynmm_conv2d_dgrad
+ * CoP / CiP = Co / Ci rounded up to a multiple of 4 (rows stay 16-byte aligned for dwordx4 loads;
+ * the padding columns are never consumed).  Sizes: KH*KW*Ci*CoP and KH*KW*Co*CiP floats.
  * Either output may be NULL. */
 int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
                       int Co, int Ci, int KH, int KW, void* stream);
