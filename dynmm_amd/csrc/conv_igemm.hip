@@ -401,10 +401,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     }
 
     float rgv[G_PER], rxv[X_PER];
+    unsigned vmask = 0;      // validity of the tile held in rgv/rxv: bit i = x row i, bit 31 = pixel < M
     const int step_begin = split * a.steps_per_split;
     const int total_steps = (a.M + BP - 1) / BP;
     const int step_end = min(total_steps, step_begin + a.steps_per_split);
 
+    // Loads are issued unconditionally from clamped (always mapped) addresses and the zero-fill of
+    // padding / out-of-range lanes is deferred to store_step(): nothing consumes a loaded value
+    // before the MFMA block, so the whole global-load latency hides under the 64 MFMAs of a step.
     auto load_step = [&](int st) {
         const int m = st * BP + p;
         const bool ok = m < a.M;
@@ -417,13 +421,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
         const unsigned gv = ((unsigned)(n * a.Co) * (unsigned)HoWo + (unsigned)rem) * 4u;
 #pragma unroll
-        for (int i = 0; i < G_PER; ++i) {
-            const float v = ldg_f32(a.dy, gv + goff[i]);
-            rgv[i] = ok ? v : 0.f;
-        }
+        for (int i = 0; i < G_PER; ++i) rgv[i] = ldg_f32(a.dy, gv + goff[i]);
         const int ihb = oh * a.SH - a.PH, iwb = ow * a.SW - a.PW;
         const int xb1 = n * a.c_split * HW + ihb * a.W + iwb;     // may be negative at the borders
         const int xb2 = DUAL ? n * c2 * HW + ihb * a.W + iwb : 0;
+        unsigned vm = ok ? 0x80000000u : 0u;
 #pragma unroll
         for (int i = 0; i < X_PER; ++i) {
             const int d = xrs[i];
@@ -433,15 +435,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             const bool second = DUAL && ((d >> 16) & 1);
             const int e = (second ? xb2 : xb1) + xoff[i];
             const unsigned vo = valid ? (unsigned)e * 4u : 0u;
-            const float v = ldg_f32(second ? a.x2 : a.x, vo);
-            rxv[i] = valid ? v : 0.f;
+            rxv[i] = ldg_f32(second ? a.x2 : a.x, vo);
+            vm |= valid ? (1u << i) : 0u;
         }
+        vmask = vm;
     };
     auto store_step = [&]() {
+        const bool ok = (vmask >> 31) != 0;
 #pragma unroll
-        for (int i = 0; i < G_PER; ++i) Gs[rg + 8 * i][p] = rgv[i];
+        for (int i = 0; i < G_PER; ++i) Gs[rg + 8 * i][p] = ok ? rgv[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = rxv[i];
+        for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((vmask >> i) & 1u) ? rxv[i] : 0.f;
     };
 
     f32x16 acc[MCO][MK];
@@ -509,7 +513,8 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     const int M = g->N * g->Ho * g->Wo;
     const int total_steps = ceil_div(M, 32);
     const int tiles = p.n_co_tiles * p.n_k_tiles;
-    int splits = ceil_div(768, tiles);                 // one residency round: 256 CUs x 3 workgroups
+    int splits = 512 / tiles;                          // ONE residency round: 256 CUs x 2 workgroups (202 VGPRs)
+    if (splits < 1) splits = 1;
     const int max_splits = ceil_div(total_steps, 8);   // >= 256 pixels per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
