@@ -152,9 +152,15 @@ __global__ void __launch_bounds__(256) nearest_into_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// learned 2x upsample: y = dwconv3x3(nearest2x(x)) + bias (+ skip)   — write-bandwidth bound
+// learned 2x upsample: y = dwconv3x3(nearest2x(x)) + bias (+ skip)   — write-bandwidth bound.
+//
+// nearest-2x followed by a zero-padded 3x3 collapses to a 2x2 stencil on the INPUT with pre-summed
+// taps: output row 2i   reads input rows {i-1: w[0],      i: w[1]+w[2]},
+//       output row 2i+1 reads input rows {i:   w[0]+w[1], i+1: w[2]}      (same along columns;
+// out-of-range input rows/cols contribute 0, which is exactly the zero padding of the upsampled
+// map).  One lane owns 2 input pixels = a 2x4 output patch: 12 input loads, 32 FMAs, two 16-byte
+// stores, instead of 9 loads + index tests per output.
 // ------------------------------------------------------------------------------------------------
-template <int V>
 __global__ void __launch_bounds__(256) upsample_fwd_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wgt,
                                                            const float* __restrict__ bias,
@@ -163,42 +169,86 @@ __global__ void __launch_bounds__(256) upsample_fwd_kernel(const float* __restri
                                                            int W) {
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % C);
-    const int H2 = 2 * H, W2 = 2 * W, HW2 = H2 * W2;
+    const int W2 = 2 * W;
     const float* xp = x + plane * H * W;
+    float* yp = y + plane * 4 * H * W;
+    const float* sp = skip ? skip + plane * 4 * H * W : nullptr;
     float k[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) k[j] = wgt[c * 9 + j];
     const float b = bias ? bias[c] : 0.f;
-    const int beg = blockIdx.y * kChunk, end = min(HW2, beg + kChunk);
-    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
-        const int oh = i / W2, ow0 = i - oh * W2;
-        float o[V];
+    // row/col tap groups: [a][0] multiplies the "previous/this" input, [a][1] the "this/next" one
+    // a = 0 (even output): {w0, w1+w2};  a = 1 (odd output): {w0+w1, w2}
+    float rc[2][2][2][2];   // [a_row][which_row][a_col][which_col]
 #pragma unroll
-        for (int v = 0; v < V; ++v) o[v] = b;
+    for (int ar = 0; ar < 2; ++ar)
+#pragma unroll
+        for (int wr = 0; wr < 2; ++wr)
+#pragma unroll
+            for (int ac = 0; ac < 2; ++ac)
+#pragma unroll
+                for (int wc = 0; wc < 2; ++wc) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const bool rin = ar == 0 ? (wr == 0 ? r == 0 : r >= 1) : (wr == 0 ? r <= 1 : r == 2);
+                        if (!rin) continue;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const bool qin = ac == 0 ? (wc == 0 ? q == 0 : q >= 1) : (wc == 0 ? q <= 1 : q == 2);
+                            if (qin) s += k[r * 3 + q];
+                        }
+                    }
+                    rc[ar][wr][ac][wc] = s;
+                }
+    const int Wh = (W + 1) / 2;                 // lane-owned column pairs per input row
+    const int items = H * Wh;
+    const int beg = blockIdx.y * (kChunk / 8), end = min(items, beg + kChunk / 8);
+    for (int it = beg + threadIdx.x; it < end; it += 256) {
+        const int i = it / Wh, j0 = (it - i * Wh) * 2;
+        // 3 x 4 input neighbourhood: rows i-1..i+1, cols j0-1..j0+2 (zero outside)
+        float v[3][4];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int uy = oh + r - 1;
-            if (uy < 0 || uy >= H2) continue;
-            const float* row = xp + (uy >> 1) * W;
+            const int ii = i + r - 1;
+            const bool rok = ii >= 0 && ii < H;
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int ux = ow0 + v + s - 1;
-                    if (ux >= 0 && ux < W2) o[v] += k[r * 3 + s] * row[ux >> 1];
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int jj = j0 + q - 1;
+                v[r][q] = (rok && jj >= 0 && jj < W) ? xp[ii * W + jj] : 0.f;
             }
         }
-        if (skip) {
-            float sk[V];
-            vload<V>(skip + plane * HW2 + i, sk);
+        const bool two = j0 + 1 < W;
 #pragma unroll
-            for (int v = 0; v < V; ++v) o[v] += sk[v];
+        for (int ar = 0; ar < 2; ++ar) {
+            float o[4];
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)          // which of the lane's 2 input columns
+#pragma unroll
+                for (int ac = 0; ac < 2; ++ac) {
+                    // input rows: ar==0 -> (i-1, i) = v[0], v[1]; ar==1 -> (i, i+1) = v[1], v[2]
+                    // input cols: ac==0 -> (j-1, j);            ac==1 -> (j, j+1)
+                    const int r0 = ar, c0 = pc + ac;
+                    o[pc * 2 + ac] = b + rc[ar][0][ac][0] * v[r0][c0] + rc[ar][0][ac][1] * v[r0][c0 + 1] +
+                                     rc[ar][1][ac][0] * v[r0 + 1][c0] + rc[ar][1][ac][1] * v[r0 + 1][c0 + 1];
+                }
+            const size_t off = (size_t)(2 * i + ar) * W2 + 2 * j0;
+            if (two && (W2 % 4 == 0)) {
+                if (sp) {
+                    const float4 sk = *reinterpret_cast<const float4*>(sp + off);
+                    o[0] += sk.x; o[1] += sk.y; o[2] += sk.z; o[3] += sk.w;
+                }
+                *reinterpret_cast<float4*>(yp + off) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                const int nout = two ? 4 : 2;
+                for (int q = 0; q < nout; ++q) yp[off + q] = o[q] + (sp ? sp[off + q] : 0.f);
+            }
         }
-        vstore<V>(y + plane * HW2 + i, o);
     }
 }
 
+// dx[i][j] = sum over the 4x4 output patch rows 2i-1..2i+2, cols 2j-1..2j+2 with the transposed
+// pre-summed taps (same grouping as above, seen from the input pixel).
 __global__ void __launch_bounds__(256) upsample_bwd_dx_kernel(const float* __restrict__ g,
                                                               const float* __restrict__ wgt,
                                                               float* __restrict__ dx, int C, int H,
@@ -238,17 +288,19 @@ __global__ void __launch_bounds__(256) upsample_bwd_dx_kernel(const float* __res
         for (int a = 0; a < 4; ++a) {
             const int oh = 2 * ih + a - 1;
             if (oh < 0 || oh >= H2) continue;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const int ow = 2 * iw + bb - 1;
-                if (ow >= 0 && ow < W2) s += e[a][bb] * gp[oh * W2 + ow];
-            }
+            const float* row = gp + (size_t)oh * W2;
+            // the two centre columns 2iw, 2iw+1 are always in range and 8-byte aligned
+            const float2 mid = *reinterpret_cast<const float2*>(row + 2 * iw);
+            s += e[a][1] * mid.x + e[a][2] * mid.y;
+            if (iw > 0) s += e[a][0] * row[2 * iw - 1];
+            if (iw < W - 1) s += e[a][3] * row[2 * iw + 2];
         }
         dx[plane * HW + i] = s;
     }
 }
 
-// dw[c][r][s] += sum g*U ; db[c] += sum g.  grid (C, splits over n)
+// dw[c][r][s] += sum g*U ; db[c] += sum g.  grid (C, splits over n).  One lane owns 4 consecutive
+// outputs of a row (16-byte load of g) and the 3x4 input patch they see.
 __global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __restrict__ g,
                                                              const float* __restrict__ x,
                                                              float* __restrict__ dw,
@@ -256,25 +308,50 @@ __global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __rest
                                                              int H, int W) {
     __shared__ float red[4];
     const int c = blockIdx.x, S = gridDim.y;
-    const int H2 = 2 * H, W2 = 2 * W, HW2 = H2 * W2;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const bool vec = (W2 % 4 == 0);
     float acc[10];
 #pragma unroll
     for (int j = 0; j < 10; ++j) acc[j] = 0.f;
     for (int n = blockIdx.y; n < N; n += S) {
-        const float* gp = g + ((size_t)n * C + c) * HW2;
+        const float* gp = g + ((size_t)n * C + c) * H2 * W2;
         const float* xp = x + ((size_t)n * C + c) * H * W;
-        for (int i = threadIdx.x; i < HW2; i += 256) {
-            const int oh = i / W2, ow = i - oh * W2;
-            const float gv = gp[i];
-            acc[9] += gv;
+        if (vec) {
+            const int Wq = W2 / 4, items = H2 * Wq;
+            for (int it = threadIdx.x; it < items; it += 256) {
+                const int oh = it / Wq, ow0 = (it - oh * Wq) * 4;
+                const float4 gq = *reinterpret_cast<const float4*>(gp + (size_t)oh * W2 + ow0);
+                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+                acc[9] += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+                const int jb = ow0 / 2;     // outputs ow0..ow0+3 see input cols jb-1 .. jb+2
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int uy = oh + r - 1;
-                if (uy < 0 || uy >= H2) continue;
+                for (int r = 0; r < 3; ++r) {
+                    const int uy = oh + r - 1;
+                    if (uy < 0 || uy >= H2) continue;
+                    const float* row = xp + (uy >> 1) * W;
+                    const float xm = jb > 0 ? row[jb - 1] : 0.f;
+                    const float x0 = row[jb], x1 = row[jb + 1];
+                    const float xpv = jb + 2 < W ? row[jb + 2] : 0.f;
+                    // U(ow+s-1): ow0+q+s-1 >> 1 ; q = 0..3, s = 0..2
+                    acc[r * 3 + 0] += gv[0] * xm + gv[1] * x0 + gv[2] * x0 + gv[3] * x1;   // s=0: cols ow-1
+                    acc[r * 3 + 1] += gv[0] * x0 + gv[1] * x0 + gv[2] * x1 + gv[3] * x1;   // s=1: cols ow
+                    acc[r * 3 + 2] += gv[0] * x0 + gv[1] * x1 + gv[2] * x1 + gv[3] * xpv;  // s=2: cols ow+1
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < H2 * W2; i += 256) {
+                const int oh = i / W2, ow = i - oh * W2;
+                const float gv = gp[i];
+                acc[9] += gv;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int ux = ow + s - 1;
-                    if (ux >= 0 && ux < W2) acc[r * 3 + s] += gv * xp[(uy >> 1) * W + (ux >> 1)];
+                for (int r = 0; r < 3; ++r) {
+                    const int uy = oh + r - 1;
+                    if (uy < 0 || uy >= H2) continue;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const int ux = ow + s - 1;
+                        if (ux >= 0 && ux < W2) acc[r * 3 + s] += gv * xp[(uy >> 1) * W + (ux >> 1)];
+                    }
                 }
             }
         }
@@ -453,12 +530,9 @@ extern "C" int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const 
                                           void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !w || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
-    dim3 grid(N * C, plane_chunks(4 * H * W, kChunk));
-    // V=4: four consecutive outputs of one row per lane (2W % 4 == 0 keeps a quad inside its row)
-    if ((2 * W) % 4 == 0 && can_vec4(4 * H * W, {skip, y}))
-        hipLaunchKernelGGL(upsample_fwd_kernel<4>, grid, dim3(256), 0, ST, x, w, b, skip, y, C, H, W);
-    else
-        hipLaunchKernelGGL(upsample_fwd_kernel<1>, grid, dim3(256), 0, ST, x, w, b, skip, y, C, H, W);
+    if (!aligned16(y) || (skip && !aligned16(skip))) return DYNMM_EUNSUPPORTED;
+    dim3 grid(N * C, plane_chunks(H * ((W + 1) / 2), kChunk / 8));
+    hipLaunchKernelGGL(upsample_fwd_kernel, grid, dim3(256), 0, ST, x, w, b, skip, y, C, H, W);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
