@@ -14,6 +14,8 @@
 // addressing on pre-transposed weights); a second one computes the weight gradient with the
 // pixel axis as the reduction dimension, split over workgroups into slabs that are reduced
 // deterministically (no float atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dynmm {
@@ -292,8 +294,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
     }
 }
 
+// Tuning knobs for experiments (read once; unset = built-in choice):
+//   DYNMM_IGEMM_TPIX=64|128      pixel tile of the Co>64 configuration
+//   DYNMM_IGEMM_TPIX_C64=128|256 pixel tile of the 32<Co<=64 configuration
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
 template <bool DGRAD>
 static int launch_igemm(IgemmArgs& a, hipStream_t st) {
+    static const int force_tpix = env_int("DYNMM_IGEMM_TPIX");
+    static const int force_tpix64 = env_int("DYNMM_IGEMM_TPIX_C64");
     const bool dual_in = a.x2 != nullptr;
     const bool generic = (a.Ci % 16 != 0) || (dual_in && (a.c_in_split % 16 != 0)) ||
                          ((reinterpret_cast<uintptr_t>(a.wp) & 15u) != 0);
@@ -313,15 +325,20 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
                                dim3(256), 0, st, a);                                           \
     } while (0)
     if (a.Co > 64) {
-        // 256 CUs x 3 resident workgroups: below one full residency round, halve the pixel tile so
-        // the deep stages (M = N*15*20 .. N*30*40) still spread over every CU.
-        const long blocks128 = (long)ceil_div(a.Co, 128) * ceil_div(a.M, 128);
-        if (blocks128 < 768)
-            DYNMM_IGEMM_LAUNCH(128, 64, 64, 32);
-        else
+        // Measured on MI355X (batch 32): the 128co x 64pix tile (32 accumulator VGPRs, ~5 resident
+        // workgroups/CU) beats 128x128 (64 acc, 3/CU) on every stage — 93 vs 83 TFLOP/s at C=128,
+        // 98 vs 73 at C=256, 80 vs 56 at C=512: this kernel is limited by latency hiding / residency
+        // rounds, not by MFMA issue, so more, smaller workgroups win.  (BK=32 and a 2-deep register
+        // prefetch both lost for the same reason: they cost occupancy.)
+        if (force_tpix == 128)
             DYNMM_IGEMM_LAUNCH(128, 128, 64, 64);
+        else
+            DYNMM_IGEMM_LAUNCH(128, 64, 64, 32);
     } else if (a.Co > 32) {
-        DYNMM_IGEMM_LAUNCH(64, 256, 64, 64);
+        if (force_tpix64 == 256)
+            DYNMM_IGEMM_LAUNCH(64, 256, 64, 64);
+        else
+            DYNMM_IGEMM_LAUNCH(64, 128, 32, 64);     // 77/84 vs 67/77 TFLOP/s (fwd/dgrad) at C=64
     } else {
         DYNMM_IGEMM_LAUNCH(32, 256, 32, 64);
     }

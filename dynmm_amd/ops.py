@@ -47,7 +47,7 @@ PROFILE = None
 
 
 def _tile(co):
-    return '128x128' if co > 64 else ('64x256' if co > 32 else '32x256')
+    return '128x64' if co > 64 else ('64x128' if co > 32 else '32x256')
 
 
 def _timed(kind, g, call):
