@@ -127,7 +127,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
-        dist.init_process_group('nccl')
+        # nccl == RCCL on ROCm.  DYNMM_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a
+        # single-GPU box (ranks then share device 0).
+        dist.init_process_group(os.environ.get('DYNMM_DIST_BACKEND', 'nccl'))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 

@@ -1,0 +1,53 @@
+"""python -m dynmm_amd.eval --dynamic --global-gate [--baseline] --hard --ckpt_path CKPT ...
+
+Counterpart of FusionDynMM/eval.py:35-151: load a (reference-format) checkpoint strictly, set the gate
+flags, optional Gaussian-noise robustness runs (modes 0/1/2), mIoU*100 per run."""
+import random
+import sys
+
+import torch
+
+from . import engine
+from .data import SyntheticRGBD
+from .src.args import ArgumentParserRGBDSegmentation
+from .src.build_model import build_model
+
+
+def main(argv=None):
+    p = ArgumentParserRGBDSegmentation(description='Efficient RGBD Indoor Semantic Segmentation (Evaluation, MI355X)')
+    p.set_common_args()
+    p.set_eval_args()
+    p.add_argument('--synthetic_samples', type=int, default=8)
+    args = p.parse_args(argv)
+    args.pretrained_on_imagenet = False
+    model, device = build_model(args, n_classes=40)
+    if args.ckpt_path:
+        ckpt = torch.load(args.ckpt_path, map_location=device)
+        model.load_state_dict(ckpt['state_dict'])               # strict, eval.py:60-61
+        print(f'Loaded checkpoint from {args.ckpt_path}')
+    model.eval()
+    model.start_weight()
+    model.hard_gate, model.ini_stage, model.baseline = args.hard, args.ini, args.baseline
+    data = SyntheticRGBD(args.synthetic_samples, args.batch_size_valid or args.batch_size, args.height, args.width,
+                         seed=77, device=device)
+    results = []
+    for r in range(args.num_runs):
+        def batches():
+            for s in data:
+                image, depth = s['image'], s['depth']
+                u = random.random()                              # eval.py:91-102
+                if args.mode in (0, 2) and u < 0.33:
+                    image = image + args.noise * image.abs().mean() * torch.randn_like(image)
+                elif (args.mode == 1 and u < 0.33) or (args.mode == 2 and u < 0.66):
+                    depth = depth + args.noise * depth.abs().mean() * torch.randn_like(depth)
+                yield image, depth, s['label_orig']
+        miou, _ = engine.evaluate(model, batches(), hard=args.hard)
+        print(f'Run {r}, mIoU: {miou:0.2f}')
+        results.append(miou)
+    model.end_weight(print_flop=args.hard)
+    print(results)
+    return results
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

@@ -54,7 +54,7 @@ def _timed(kind, g, call):
     if PROFILE is None:
         return call()
     co = g.Ci if kind == 'dgrad' else g.Co
-    name = f'conv_{"wgrad" if kind == "wgrad" else "igemm"}_{kind}<{_tile(co) if kind != "wgrad" else ("co" + _tile(co).split("x")[0])}>'
+    name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co)}>'
     flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -1,0 +1,38 @@
+"""Host-side scalar schedules of the training driver (FusionDynMM/train.py:120-128, 189, 195-197;
+src/utils.py:203-214).  Pure Python — nothing here touches the device."""
+import math
+
+
+class ExpDecayTemp:
+    """start_t * b**epoch with b = exp(log(end_t/start_t)/time_len); b = 1 when time_len == 0.
+    Not clamped: the reference keeps decaying after `time_len` epochs."""
+
+    def __init__(self, start_t, end_t, time_len):
+        self.start_t, self.end_t, self.time_len = start_t, end_t, time_len
+        self.b = 1 if time_len == 0 else math.exp(1 / time_len * math.log(end_t / start_t))
+
+    def get_t(self, epoch):
+        return self.start_t * self.b ** epoch
+
+
+def one_cycle_lr(epoch, total_steps, max_lr, div_factor=25.0, pct_start=0.1, final_div_factor=1e4):
+    """torch.optim.lr_scheduler.OneCycleLR (cos anneal, two phases) evaluated at step `epoch` — the
+    reference steps it once per EPOCH with total_steps = epochs (train.py:119-128, 267)."""
+    initial_lr = max_lr / div_factor
+    min_lr = initial_lr / final_div_factor
+    up_end = float(pct_start * total_steps) - 1.0
+    down_end = float(total_steps) - 1.0
+
+    def cos(start, end, pct):
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    if epoch <= up_end or up_end <= 0 and epoch <= 0:
+        pct = epoch / up_end if up_end > 0 else 1.0
+        return cos(initial_lr, max_lr, pct)
+    pct = (epoch - up_end) / (down_end - up_end)
+    return cos(max_lr, min_lr, min(pct, 1.0))
+
+
+def scaled_lr(lr, batch_size):
+    """train.py:46-49: the CLI learning rate refers to batch 8 (use the GLOBAL batch under DP)."""
+    return lr if batch_size == 8 else lr * batch_size / 8

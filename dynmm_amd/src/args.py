@@ -55,7 +55,7 @@ _COMMON = [
     (('--upsampling',), dict(default='learned-3x3-zeropad',
                              choices=['nearest', 'bilinear', 'learned-3x3', 'learned-3x3-zeropad'])),
     # data
-    (('--dataset',), dict(default='nyuv2', choices=['sunrgbd', 'nyuv2', 'cityscapes', 'cityscapes-with-depth', 'scenenetrgbd'])),
+    (('--dataset',), dict(default='nyuv2', choices=['sunrgbd', 'nyuv2', 'cityscapes', 'cityscapes-with-depth', 'scenenetrgbd', 'synthetic'])),
     (('--dataset_dir',), dict(default=None)),
     (('--raw_depth',), dict(action='store_true', default=False)),
     (('--aug_scale_min',), dict(default=1.0, type=float)),

@@ -212,6 +212,40 @@ def ops_fixture():
     np.savez_compressed(os.path.join(HERE, 'ops.npz'), **blob)
 
 
+def train_steps_fixture():
+    """two deterministic optimisation steps exactly as train.py:289-324 runs them —
+    reference model + reference CrossEntropyLoss2d (src/utils.py:18-50) + torch SGD-Nesterov
+    (train.py:557-563) with the total-loss rule of train.py:313-321 (loss_ratio, flop_budget)."""
+    h, w, n = 96, 128, 2
+    m = build('P_se', h, w)
+    m.train()
+    m.temp, m.hard_gate = 0.8, False
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s).float() for s in (1, 8, 16, 32)]
+    cw = np.linspace(0.5, 2.0, 40).astype(np.float32)
+    ce = ref_utils.CrossEntropyLoss2d(torch.device('cpu'), cw)
+    opt = torch.optim.SGD(m.parameters(), lr=0.002, weight_decay=1e-4, momentum=0.9, nesterov=True)
+    ratio, budget = 0.5, 1.0
+    blob = {'meta': np.array([h, w, n]), 'cw': cw, 'hyper': np.array([0.002, 1e-4, 0.9, ratio, budget, 0.8])}
+    for step in range(2):
+        m.start_weight()
+        opt.zero_grad()
+        outs, lf = m(rgb, depth)
+        losses = ce(outs, labels)
+        total = sum(losses) + ratio * max(torch.zeros_like(lf), lf - budget)
+        total.backward()
+        opt.step()
+        blob[f'step{step}/losses'] = np.array([l.item() for l in losses], np.float64)
+        blob[f'step{step}/loss_flop'] = np.float64(lf.item())
+        blob[f'step{step}/total'] = np.float64(total.item())
+        blob[f'step{step}/weight'] = m.weight_list.detach().numpy().copy()
+        m.end_weight()
+    sd = m.state_dict()
+    blob['param_norms'] = np.array([sd[k].double().norm().item() for k in sd if sd[k].dtype.is_floating_point])
+    blob['param_names'] = np.array([k for k in sd if sd[k].dtype.is_floating_point])
+    np.savez_compressed(os.path.join(HERE, 'train_steps_P_se.npz'), **blob)
+
+
 def contract_fixture():
     """state_dict keys / shapes / dtypes of the reference model (the strict-load contract, eval.py:61)."""
     blob = {}
@@ -227,7 +261,11 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'contract':
         contract_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'train_steps':
+        train_steps_fixture()
+        sys.exit(0)
     contract_fixture()
+    train_steps_fixture()
     ops_fixture()
     model_fixture('P_se', 96, 128, 2, MODES)
     model_fixture('P_add', 96, 128, 2, ['eval_soft', 'train_soft'])
