@@ -39,6 +39,10 @@ def parse():
     ap.add_argument('--config', default='P', choices=['P', 'S'])
     ap.add_argument('--mode', default='train', choices=['train', 'fwd'],
                     help="train: fwd+bwd soft gates (configs[2]); fwd: eval forward, gate forced on (configs[1])")
+    ap.add_argument('--branches', default='all4', choices=['all4', 'uniform', 'all0'],
+                    help='--mode fwd only: per-sample gate branch (hard one-hot); uniform = k = n %% 5. '
+                         'With K16 compaction depth stage j runs on the samples with k >= j only')
+    ap.add_argument('--no-compact', action='store_true', help='--mode fwd: disable K16 compaction (dense reference semantics)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
@@ -146,7 +150,12 @@ def main():
         reducer = dp.GradBucketReducer(model.parameters(), bucket_mb=32, overlap=False)
     else:
         model.eval()
-        model.baseline = True
+        model.compact = not args.no_compact
+        if args.branches == 'all4':
+            model.baseline = True                 # configs[1]: static fuse, gate forced on
+        else:
+            model.ini_stage = True
+            model.ini_branches = [(i % 5) if args.branches == 'uniform' else 0 for i in range(args.batch)]
 
     def fwd_bwd():
         if not train:
@@ -161,7 +170,7 @@ def main():
         return total
 
     graph = None
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and (train or args.no_compact)   # compaction reads the branch on the host
     # warm-up (also initialises lazily-created buffers before capture)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -247,6 +256,7 @@ def main():
                                     'weighted 4-scale CE + FLOP loss' if train else
                                     'configs[1]: fwd-only eval, static fuse (gate forced on)'),
                        'net': f'SkipGateESANet R34-{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
+                       'branches': None if train else args.branches, 'compaction': None if train else (not args.no_compact),
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'height': args.height, 'width': args.width,
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if graph is not None else 'eager',

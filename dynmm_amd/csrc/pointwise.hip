@@ -456,11 +456,74 @@ __global__ void __launch_bounds__(256) axpby_bwd_apply_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gate-decision stream compaction: batch-row gather / merge.
+//   gather: dst[i]   = src[idx[i]]                      (i < n_out)
+//   merge : out[n]   = map[n] >= 0 ? sub[map[n]] : base[n]   (n < N)
+// Rows are whole samples (C*H*W floats), so every access is a long contiguous run.
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) batch_gather_kernel(const float* __restrict__ src,
+                                                           const int* __restrict__ idx,
+                                                           float* __restrict__ dst, size_t row) {
+    const size_t s = (size_t)idx[blockIdx.y] * row, d = (size_t)blockIdx.y * row;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < row; i += (size_t)gridDim.x * 256 * V) {
+        float v[V];
+        vload<V>(src + s + i, v);
+        vstore<V>(dst + d + i, v);
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) batch_merge_kernel(const float* __restrict__ base,
+                                                          const float* __restrict__ sub,
+                                                          const int* __restrict__ map,
+                                                          float* __restrict__ out, size_t row) {
+    const int m = map[blockIdx.y];
+    const float* src = m >= 0 ? sub + (size_t)m * row : base + (size_t)blockIdx.y * row;
+    const size_t d = (size_t)blockIdx.y * row;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < row; i += (size_t)gridDim.x * 256 * V) {
+        float v[V];
+        vload<V>(src + i, v);
+        vstore<V>(out + d + i, v);
+    }
+}
+
 }  // namespace dynmm
 
 using namespace dynmm;
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int dynmm_batch_gather(const float* src, const int* idx, float* dst, int n_out, size_t row,
+                                  void* stream) {
+    (void)hipGetLastError();
+    if (!src || !idx || !dst || n_out <= 0 || row == 0) return DYNMM_EINVAL;
+    unsigned bx = (unsigned)((row / 4 + 255) / 256);
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    if (row % 4 == 0 && aligned16(src) && aligned16(dst))
+        hipLaunchKernelGGL(batch_gather_kernel<4>, dim3(bx, n_out), dim3(256), 0, ST, src, idx, dst, row);
+    else
+        hipLaunchKernelGGL(batch_gather_kernel<1>, dim3(bx, n_out), dim3(256), 0, ST, src, idx, dst, row);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_batch_merge(const float* base, const float* sub, const int* map, float* out, int N,
+                                 size_t row, void* stream) {
+    (void)hipGetLastError();
+    if (!base || !sub || !map || !out || N <= 0 || row == 0) return DYNMM_EINVAL;
+    unsigned bx = (unsigned)((row / 4 + 255) / 256);
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    if (row % 4 == 0 && aligned16(base) && aligned16(sub) && aligned16(out))
+        hipLaunchKernelGGL(batch_merge_kernel<4>, dim3(bx, N), dim3(256), 0, ST, base, sub, map, out, row);
+    else
+        hipLaunchKernelGGL(batch_merge_kernel<1>, dim3(bx, N), dim3(256), 0, ST, base, sub, map, out, row);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
 
 extern "C" int dynmm_maxpool3x3s2_fwd(const float* x, float* y, signed char* idx, int N, int C, int H,
                                       int W, int Ho, int Wo, void* stream) {

@@ -124,6 +124,12 @@ class SkipGateESANet(nn.Module):
         self.depth_enc_flop = torch.tensor(R34_DEPTH_ENC_FLOP if r34 else OTHER_DEPTH_ENC_FLOP)
         self.total_flop = torch.tensor(R34_TOTAL_FLOP if r34 else OTHER_TOTAL_FLOP)
         self._tab_cache = {}
+        # K16 (new capability): in inference with one-hot gate weights, run each depth-encoder stage
+        # only on the samples whose branch takes it.  Exact up to fp32 rounding; never used when
+        # gradients are recorded or BN is in training mode.
+        self.compact = True
+        self.ini_branches = None          # optional fixed branch per sample for ini_stage (else CPU RNG)
+        self.last_stage_batch = None      # depth-stage batch sizes of the last compacted forward
 
     # ---- caller protocol (train.py:141,190-197,284,351; eval.py:64-68) -------------------------
     def freeze(self):
@@ -173,7 +179,8 @@ class SkipGateESANet(nn.Module):
             weight, wcum, loss = ops.gate_from_weight(onehot, tab)
         elif self.ini_stage:                                         # …globalgate.py:267-270 (CPU RNG)
             onehot = torch.zeros(bs, 5)
-            onehot[torch.arange(bs), torch.randint(0, 5, (bs,))] = 1
+            idx = torch.randint(0, 5, (bs,)) if self.ini_branches is None else torch.as_tensor(self.ini_branches)[:bs]
+            onehot[torch.arange(bs), idx] = 1
             weight, wcum, loss = ops.gate_from_weight(onehot.to(rgb.device), tab)
         else:
             pooled = self.gate_layer.features(r, d)
@@ -181,12 +188,37 @@ class SkipGateESANet(nn.Module):
         if self.save_weight_info:
             self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
 
+        one_hot = self.baseline or self.ini_stage or self.hard_gate
+        compacted = self.compact and one_hot and not self.training and not torch.is_grad_enabled()
+        branch = weight.argmax(1).tolist() if compacted else None     # ONE host sync per forward
+        alive = list(range(bs))                  # samples whose depth features are still being computed
+        self.last_stage_batch = [] if compacted else None
+
         skips = []
         for j in (1, 2, 3, 4):
             r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
-            d = getattr(ed, f'forward_layer{j}')(d)
-            # stage j<4: w*rgb + (1-w)*fused with w = sum_{k<j} weight[:,k];  stage 4: w = 1-weight[:,4]
-            fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
+            if not compacted:
+                d = getattr(ed, f'forward_layer{j}')(d)
+                # stage j<4: w*rgb + (1-w)*fused with w = sum_{k<j} weight[:,k];  stage 4: w = 1-weight[:,4]
+                fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
+            else:
+                keep = [pos for pos, n in enumerate(alive) if branch[n] >= j]
+                if len(keep) < len(alive) and keep:
+                    d = ops.batch_gather(d, torch.tensor(keep, dtype=torch.int32, device=r.device))
+                alive = [alive[pos] for pos in keep]
+                self.last_stage_batch.append(len(alive))
+                if not alive:
+                    fuse, d = r, None            # every sample skips depth from here on
+                else:
+                    d = getattr(ed, f'forward_layer{j}')(d)
+                    if len(alive) == bs:
+                        fuse = ops.se_fuse_blend(r, d, self._se(j))          # w = 0 for every sample
+                    else:
+                        idx = torch.tensor(alive, dtype=torch.int32, device=r.device)
+                        fused = ops.se_fuse_blend(ops.batch_gather(r, idx), d, self._se(j))
+                        mapping = torch.full((bs,), -1, dtype=torch.int32)
+                        mapping[alive] = torch.arange(len(alive), dtype=torch.int32)
+                        fuse = ops.batch_merge(r, fused, mapping.to(r.device))
             if j < 4:
                 sk = getattr(self, f'skip_layer{j}')
                 skips.append(sk[0](fuse) if len(sk) else fuse)

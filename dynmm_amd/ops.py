@@ -515,6 +515,31 @@ def gate_from_weight(weight, flop_table):
 
 
 # ------------------------------------------------------------------------------------------------
+# gate-decision compaction (inference only)
+# ------------------------------------------------------------------------------------------------
+def batch_gather(x, index):
+    """x[index] along the batch axis; `index` is a device int32 tensor."""
+    lib = _lib()
+    x = _chk(x, 'x')
+    n_out = index.numel()
+    out = torch.empty((n_out,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    row = x[0].numel()
+    L.check(lib.dynmm_batch_gather(_p(x), index.data_ptr(), _p(out), n_out, C.c_size_t(row), _stream()), 'batch_gather')
+    return out
+
+
+def batch_merge(base, sub, mapping):
+    """out[n] = sub[mapping[n]] if mapping[n] >= 0 else base[n]; `mapping` is a device int32 [N]."""
+    lib = _lib()
+    base, sub = _chk(base, 'base'), _chk(sub, 'sub')
+    out = torch.empty_like(base)
+    row = base[0].numel()
+    L.check(lib.dynmm_batch_merge(_p(base), _p(sub), mapping.data_ptr(), _p(out), base.shape[0], C.c_size_t(row),
+                                  _stream()), 'batch_merge')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # weighted 2-D cross entropy (caller of the path; SURVEY.md §8f-1)
 # ------------------------------------------------------------------------------------------------
 class _CrossEntropy2d(Function):

@@ -189,6 +189,14 @@ int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
 int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
                    const float* gscale, float* dx, int N, int C, int HW, void* stream);
 
+/* ---- gate-decision stream compaction (new: SURVEY.md K16; the reference never skips compute,
+ * src/models/model_skip_mod_globalgate.py:276-310) ----
+ * gather: dst[i] = src[idx[i]]  (i < n_out);  merge: out[n] = map[n] >= 0 ? sub[map[n]] : base[n].
+ * Rows are whole samples of `row` floats; idx/map are device int32. */
+int dynmm_batch_gather(const float* src, const int* idx, float* dst, int n_out, size_t row, void* stream);
+int dynmm_batch_merge(const float* base, const float* sub, const int* map, float* out, int N, size_t row,
+                      void* stream);
+
 /* ---- helpers ---- */
 /* out[i] = sum_s slabs[s][i] */
 int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nslabs, void* stream);

@@ -200,3 +200,49 @@ def test_full_size_properties():
     assert Hh.rel_err(halves.cpu(), full.cpu()) < 1e-5                # samples independent in eval
     assert torch.all((wfull.sum(1) - 1).abs() < 1e-6)
     assert full.shape == (4, 40, 480, 640) and torch.isfinite(full).all()
+
+
+@pytest.mark.parametrize('cfg', ['P_se', 'S_add'])
+def test_hard_gate_compaction_is_exact(cfg):
+    """K16: per-sample branch compaction in inference (depth stage j runs only on samples with branch >= j)
+    must reproduce the dense reference semantics; checked against the dense HIP path and the oracle."""
+    from oracle import dynmm_oracle as O
+    h, w, n = 96, 128, 6
+    branches = [1, 4, 0, 3, 2, 4]
+    rgb, depth = synth.synth_inputs(n, h, w, seed=21)
+    m = hip_model(cfg, h, w, seed=2)
+    m.eval()
+    m.ini_stage = True
+    real = torch.randint
+    torch.randint = lambda *a, **k: torch.tensor(branches)
+    try:
+        with torch.no_grad():
+            m.compact = True
+            out_c, w_c = m(rgb.cuda(), depth.cuda(), test=True, return_weight=True)
+            assert m.last_stage_batch == [5, 4, 3, 2]         # samples still needing depth at stages 1..4
+            m.compact = False
+            out_d, w_d = m(rgb.cuda(), depth.cuda(), test=True, return_weight=True)
+            assert m.last_stage_batch is None
+    finally:
+        torch.randint = real
+    assert torch.equal(w_c, w_d)
+    assert Hh.rel_err(out_c.cpu(), out_d.cpu()) < 1e-5
+    sd = Hh.filled_state_dict(Hh.CFGS[cfg], seed=2)
+    iw = torch.zeros(n, 5)
+    iw[range(n), branches] = 1
+    with torch.no_grad():
+        ref = O.forward(sd, rgb, depth, Hh.CFGS[cfg], test=True, ini_stage=True, ini_weight=iw)
+    assert Hh.rel_err(out_c.cpu(), ref) < LOGIT_TOL
+    # all-skip and all-fuse extremes
+    for br, expect in (([0] * n, [0, 0, 0, 0]), ([4] * n, [n] * 4)):
+        torch.randint = lambda *a, **k: torch.tensor(br)
+        try:
+            with torch.no_grad():
+                m.compact = True
+                oc = m(rgb.cuda(), depth.cuda(), test=True)
+                assert m.last_stage_batch == expect
+                m.compact = False
+                od = m(rgb.cuda(), depth.cuda(), test=True)
+        finally:
+            torch.randint = real
+        assert Hh.rel_err(oc.cpu(), od.cpu()) < 1e-5
