@@ -285,9 +285,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
                     idx = ((size_t)n * co_rest + (co - co_split)) * HoWo + rem;
                     out = a.y2;
                 }
-                if (a.residual) v += a.residual[idx];
-                v = act_fwd(v, a.act);
-                if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                if (DGRAD) {
+                    // dx = (dgrad term) * [mask > 0] + accum : ReLU backward of the producer of x and
+                    // the residual-branch gradient, both fused into the store
+                    if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                    if (a.residual) v += a.residual[idx];
+                } else {
+                    if (a.residual) v += a.residual[idx];
+                    v = act_fwd(v, a.act);
+                }
                 out[idx] = v;
             }
         }
@@ -629,13 +635,14 @@ extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp
 }
 
 extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
-                                  float* dx, float* dx2, const dynmm_conv_geom* g, void* stream) {
+                                  const float* accum, float* dx, float* dx2,
+                                  const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!dy || !wp_dgrad || !dx || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (dx2 != nullptr)) return DYNMM_EINVAL;
-    if (mask && dx2) return DYNMM_EUNSUPPORTED;
+    if ((mask || accum) && dx2) return DYNMM_EUNSUPPORTED;
     IgemmArgs a{};
-    a.x = dy; a.x2 = nullptr; a.wp = wp_dgrad; a.mask = mask; a.y = dx; a.y2 = dx2;
+    a.x = dy; a.x2 = nullptr; a.wp = wp_dgrad; a.mask = mask; a.residual = accum; a.y = dx; a.y2 = dx2;
     // the GEMM's input is dy [N,Co,Ho,Wo], its output dx [N,Ci,H,W]
     a.N = g->N; a.Ci = g->Co; a.H = g->Ho; a.W = g->Wo;
     a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W;

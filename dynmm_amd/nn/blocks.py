@@ -9,7 +9,7 @@ import torch.nn as nn
 from .. import ops
 
 
-def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None):
+def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False, conv_link=None, res_link=None):
     """act(BN(conv(x|x2)) + residual).
 
     inference (eval, no grad): ONE kernel — BN folded into the implicit-GEMM epilogue.
@@ -18,8 +18,9 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None):
     if not bn.training and not torch.is_grad_enabled():
         return ops.conv2d_fused_eval(x, conv.weight, conv.bias, bn, act, residual,
                                      conv.stride, conv.padding, x2)
-    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2)
-    return ops.batch_norm_act(y, bn, act, residual)
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input,
+                   link=conv_link)
+    return ops.batch_norm_act(y, bn, act, residual, link=res_link)
 
 
 class ConvBNAct(nn.Sequential):
@@ -50,13 +51,18 @@ class NonBottleneck1D(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # Backward fusions (forward results unchanged): the ReLU backward of each 3x1 conv is applied in
+        # the dgrad epilogue of the 1x3 conv that consumes it, and the identity branch's gradient is
+        # added in the dgrad epilogue of the first conv instead of a separate autograd add pass.
+        fuse_bwd = torch.is_grad_enabled() and x.requires_grad
+        link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
         c = self.conv3x1_1
-        y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu')
-        y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu')
+        y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link)
+        y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd)
         c = self.conv3x1_2
-        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu')
+        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd)
         idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
-        return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt)
+        return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link)
 
 
 class BasicBlock(nn.Module):
@@ -72,9 +78,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = conv_bn_act(x, self.conv1, self.bn1, 'relu')
+        fuse_bwd = torch.is_grad_enabled() and x.requires_grad
+        link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
+        y = conv_bn_act(x, self.conv1, self.bn1, 'relu', conv_link=link)
         idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
-        return conv_bn_act(y, self.conv2, self.bn2, 'relu', residual=idt)
+        return conv_bn_act(y, self.conv2, self.bn2, 'relu', residual=idt, res_link=link)
 
 
 BLOCKS = {'NonBottleneck1D': NonBottleneck1D, 'BasicBlock': BasicBlock}

@@ -89,9 +89,19 @@ def _geom(x, x2, weight, stride, padding):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
+class GradLink:
+    """Hands the residual-branch gradient of a block from the op that produces it (the BatchNorm that
+    adds the identity) to the op that can absorb it for free (the epilogue of the first conv's dgrad),
+    instead of letting autograd materialise `dgrad + dres` with a separate add pass."""
+    __slots__ = ('dres',)
+
+    def __init__(self):
+        self.dres = None
+
+
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, padding, act):
+    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link):
         lib = _lib()
         st = _stream()
         x, x2, weight, bias = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight'), _chk(bias, 'bias')
@@ -109,7 +119,10 @@ class _Conv2d(Function):
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_x2 = x2 is not None
-        ctx.save_for_backward(x, x2, wpd, y if act != L.ACT_NONE else None)
+        ctx.mask_input = mask_input       # x is a ReLU output: apply [x > 0] in the dgrad epilogue
+        ctx.defer_mask = defer_mask       # our own ReLU backward is applied by the consumer's dgrad
+        ctx.link = link
+        ctx.save_for_backward(x, x2, wpd, y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
         return y
 
@@ -121,19 +134,24 @@ class _Conv2d(Function):
         g = ctx.geom
         gy = _chk(gy, 'grad')
         dbias = None
-        if ctx.act != L.ACT_NONE or ctx.has_bias:
-            ge = torch.empty_like(gy) if ctx.act != L.ACT_NONE else None
+        act = L.ACT_NONE if ctx.defer_mask else ctx.act     # deferred: gy arrives already masked
+        if act != L.ACT_NONE or ctx.has_bias:
+            ge = torch.empty_like(gy) if act != L.ACT_NONE else None
             dbias = torch.empty(g.Co, device=gy.device, dtype=torch.float32) if ctx.has_bias else None
             L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), _p(dbias), g.N, g.Co, g.Ho * g.Wo,
-                                           ctx.act, st), 'act_bwd_bias')
+                                           act, st), 'act_bwd_bias')
             if ge is not None:
                 gy = ge
         dx = dx2 = None
         if wpd is not None:
             dx = torch.empty_like(x)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), None, _p(dx), _p(dx2),
-                                                                      C.byref(g), st)), 'conv2d_dgrad')
+            mask = x if ctx.mask_input else None
+            accum = None
+            if ctx.link is not None and ctx.link.dres is not None:
+                accum, ctx.link.dres = ctx.link.dres, None
+            L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
+                                                                      _p(dx2), C.byref(g), st)), 'conv2d_dgrad')
         dw = None
         if ctx.needs_input_grad[2]:
             dw = torch.empty(ctx.wshape, device=gy.device, dtype=torch.float32)
@@ -141,12 +159,19 @@ class _Conv2d(Function):
             ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
             L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes,
                                                                       C.byref(g), st)), 'conv2d_wgrad')
-        return dx, dx2, dw, dbias, None, None, None
+        return dx, dx2, dw, dbias, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None):
-    """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable."""
-    return _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act])
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_input=False, defer_mask=False,
+           link=None):
+    """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable.
+
+    Backward-fusion hints (set by block code that knows the dataflow; results are unchanged):
+      defer_mask : this op's ReLU backward is applied by its (single) consumer — pair with
+      mask_input : x is the output of a `defer_mask` op: the dgrad epilogue applies [x > 0];
+      link       : GradLink whose residual-branch gradient is added in the dgrad epilogue."""
+    return _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
+                         bool(defer_mask), link)
 
 
 def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=1, padding=0, x2=None):
@@ -180,7 +205,7 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
 # ------------------------------------------------------------------------------------------------
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link):
         lib = _lib()
         st = _stream()
         x, residual = _chk(x, 'x'), _chk(residual, 'residual')
@@ -199,6 +224,7 @@ class _BatchNormAct(Function):
                                    N, Cc, HW, eps, momentum, int(training), act, st), 'bn_apply')
         ctx.act = act
         ctx.training = training
+        ctx.link = link
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if act != L.ACT_NONE else None, gamma, mean, invstd)
         return y
@@ -225,16 +251,19 @@ class _BatchNormAct(Function):
                                        int(ctx.training), ctx.act, st), 'bn_bwd_apply')
         if need_res and dres is None:
             dres = gy            # no activation: the residual branch receives the gradient unchanged
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+        if ctx.link is not None and dres is not None:
+            ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
-def batch_norm_act(x, bn, act=None, residual=None, training=None):
-    """act(BatchNorm2d(x) + residual) using the parameters/buffers of the nn.BatchNorm2d `bn`."""
+def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
+    """act(BatchNorm2d(x) + residual) using the parameters/buffers of the nn.BatchNorm2d `bn`.
+    `link`: GradLink that carries the residual's gradient to the op that consumes the same tensor."""
     training = bn.training if training is None else training
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
-                               bool(training), float(bn.momentum), float(bn.eps), ACT[act])
+                               bool(training), float(bn.momentum), float(bn.eps), ACT[act], link)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -69,10 +69,12 @@ int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
                      const float* scale, const float* shift, const float* residual,
                      float* y, const dynmm_conv_geom* g, int act, void* stream);
 
-/* dx = conv_transpose(dy, w)  (the autograd "input gradient" of the conv above); if mask != NULL
- * the result is multiplied by (mask > 0) — the ReLU backward of the producer of x, fused.
+/* dx = conv_transpose(dy, w) * [mask > 0] + accum   (mask, accum optional, shaped like x):
+ * the autograd "input gradient" of the conv above, with the ReLU backward of the producer of x and
+ * the gradient arriving over a residual branch fused into the epilogue (saves the separate
+ * threshold_backward and add passes of the reference's autograd).
  * dx covers cat([x,x2]) when g->c_split < g->Ci: dx2 receives channels [c_split, Ci). */
-int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
+int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
                        float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
 
 /* dw[Co,Ci,KH,KW] = sum_{n,oh,ow} dy * x(window).  Split over the pixel range into partial slabs in
