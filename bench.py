@@ -148,6 +148,7 @@ def main():
         model.train()
         model.hard_gate, model.temp = False, 1.0
         reducer = dp.GradBucketReducer(model.parameters(), bucket_mb=32, overlap=False)
+        ops.DIRECT_GRAD = True      # kernels write parameter gradients straight into the flat buffer views
     else:
         model.eval()
         model.compact = not args.no_compact

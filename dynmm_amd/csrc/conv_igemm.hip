@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "vec.h"
 
 namespace dynmm {
 
@@ -546,22 +547,35 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     return p;
 }
 
+// out[i] = sum_s slabs[s][i], deterministic.  64 columns (V floats each) x 4 slab-groups per
+// workgroup: four independent load streams per column are in flight, partials meet in LDS and are
+// added in a fixed order (no atomics => bit-reproducible weight gradients).
 template <int V>
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs,
                                                            float* __restrict__ out, int n, int nslabs) {
-    const int i = (blockIdx.x * 256 + threadIdx.x) * V;
-    if (i >= n) return;
-    if (V == 4) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < nslabs; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)k * n + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    __shared__ float part[4][64][V];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = (blockIdx.x * 64 + tx) * V;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (i < n) {
+#pragma unroll 4
+        for (int k = ty; k < nslabs; k += 4) {
+            float v[V];
+            vload<V>(slabs + (size_t)k * n + i, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += v[j];
         }
-        *reinterpret_cast<float4*>(out + i) = s;
-    } else {
-        float s = 0.f;
-        for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * n + i];
-        out[i] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) part[ty][tx][j] = acc[j];
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float r[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) r[j] = ((part[0][tx][j] + part[1][tx][j]) + part[2][tx][j]) + part[3][tx][j];
+        vstore<V>(out + i, r);
     }
 }
 
@@ -569,9 +583,9 @@ static void launch_reduce_slabs(const float* slabs, float* out, int n, int nslab
     const bool v4 = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15u) == 0) &&
                     ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
     if (v4)
-        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, slabs, out, n, nslabs);
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(ceil_div(n / 4, 64)), dim3(256), 0, st, slabs, out, n, nslabs);
     else
-        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(ceil_div(n, 256)), dim3(256), 0, st, slabs, out, n, nslabs);
+        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(ceil_div(n, 64)), dim3(256), 0, st, slabs, out, n, nslabs);
 }
 
 // wf[(tap*Ci+ci)*CoP + co], wd[(tap*Co+co)*CiP + ci]; padding columns are never consumed.

@@ -72,6 +72,7 @@ class TrainStep:
             raise NotImplementedError('TrainStep with frozen parameters: build it after model.freeze() is not '
                                       'supported yet; use per-parameter torch.optim.SGD for --freeze runs')
         self.opt = SGDNesterov(self.flatp.flat, self.reducer.flat, lr, momentum, weight_decay)
+        ops.DIRECT_GRAD = True      # one backward per zero(): gradients are written in place, not accumulated
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)
         self.use_graph = use_graph
         self._graph = None
@@ -100,10 +101,11 @@ class TrainStep:
             return self.last
         if self._graph is None:
             self._static = (rgb.clone(), depth.clone(), [t.clone() for t in targets])
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            # snapshot BEFORE the side stream forks, so the warm-up cannot race the clones
             sd = {k: v.clone() for k, v in self.model.state_dict().items()}
             mom = self.opt.buf.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):       # warm-up outside capture (allocator, lazy init)
                 self._body(*self._static)
             torch.cuda.current_stream().wait_stream(side)

@@ -41,6 +41,22 @@ def _chk(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Opt-in (TrainStep / bench): when a parameter already owns a contiguous `.grad` buffer (a view into the
+# flat gradient buffer of dp.GradBucketReducer), backward kernels write the parameter gradient
+# STRAIGHT into it and return None to autograd — no temporary, no per-parameter accumulate kernel
+# (607 tiny adds per step).  Semantics: overwrite, so valid for one backward per zero().
+DIRECT_GRAD = False
+
+
+def _grad_dst(param, like=None):
+    """(tensor to write the gradient into, value to return to autograd)."""
+    if DIRECT_GRAD and param is not None and getattr(param, 'grad', None) is not None and param.grad.is_contiguous() \
+            and param.grad.dtype == torch.float32:
+        return param.grad, None
+    t = torch.empty_like(param if like is None else like)
+    return t, t
+
+
 # Optional per-launch timing of the implicit-GEMM kernels (bench.py's roofline leg): when PROFILE is a
 # list, every conv launch is bracketed by events recorded on the stream it is launched on.
 PROFILE = None
@@ -124,6 +140,7 @@ class _Conv2d(Function):
         ctx.link = link
         ctx.save_for_backward(x, x2, wpd, y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
+        ctx.w_param, ctx.b_param = weight, bias
         return y
 
     @staticmethod
@@ -135,9 +152,11 @@ class _Conv2d(Function):
         gy = _chk(gy, 'grad')
         dbias = None
         act = L.ACT_NONE if ctx.defer_mask else ctx.act     # deferred: gy arrives already masked
+        dbias_ret = None
         if act != L.ACT_NONE or ctx.has_bias:
             ge = torch.empty_like(gy) if act != L.ACT_NONE else None
-            dbias = torch.empty(g.Co, device=gy.device, dtype=torch.float32) if ctx.has_bias else None
+            if ctx.has_bias:
+                dbias, dbias_ret = _grad_dst(ctx.b_param)
             L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), _p(dbias), g.N, g.Co, g.Ho * g.Wo,
                                            act, st), 'act_bwd_bias')
             if ge is not None:
@@ -152,14 +171,14 @@ class _Conv2d(Function):
                 accum, ctx.link.dres = ctx.link.dres, None
             L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
                                                                       _p(dx2), C.byref(g), st)), 'conv2d_dgrad')
-        dw = None
+        dw_ret = None
         if ctx.needs_input_grad[2]:
-            dw = torch.empty(ctx.wshape, device=gy.device, dtype=torch.float32)
+            dw, dw_ret = _grad_dst(ctx.w_param)
             nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
             ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
             L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes,
                                                                       C.byref(g), st)), 'conv2d_wgrad')
-        return dx, dx2, dw, dbias, None, None, None, None, None, None
+        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_input=False, defer_mask=False,
@@ -227,6 +246,7 @@ class _BatchNormAct(Function):
         ctx.link = link
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if act != L.ACT_NONE else None, gamma, mean, invstd)
+        ctx.g_param, ctx.b_param = gamma, beta
         return y
 
     @staticmethod
@@ -244,8 +264,8 @@ class _BatchNormAct(Function):
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[5]
         dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None
-        dgamma = torch.empty(Cc, device=dev, dtype=torch.float32)
-        dbeta = torch.empty(Cc, device=dev, dtype=torch.float32)
+        dgamma, dgamma_ret = _grad_dst(ctx.g_param)
+        dbeta, dbeta_ret = _grad_dst(ctx.b_param)
         L.check(lib.dynmm_bn_bwd_apply(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
                                        _p(dx), _p(dres), _p(dgamma), _p(dbeta), N, Cc, HW,
                                        int(ctx.training), ctx.act, st), 'bn_bwd_apply')
@@ -253,7 +273,7 @@ class _BatchNormAct(Function):
             dres = gy            # no activation: the residual branch receives the gradient unchanged
         if ctx.link is not None and dres is not None:
             ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
