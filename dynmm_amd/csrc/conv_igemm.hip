@@ -128,22 +128,28 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
 
     const int khalf = lane >> 5, l31 = lane & 31;
 
+    // Fragments for the whole K-step are fetched from LDS first (BK/2 * (MCO+MPIX) VGPRs), then the
+    // MFMAs issue back to back: one LDS round trip per K-step per wave instead of one per k-pair
+    // (+2 % measured).  Tried and rejected on MI355X (all cost occupancy or code quality, -5..-40 %):
+    // BK=32, 2-deep register prefetch, a persistent multi-tile loop per workgroup.
     auto mfma_tile = [&](int buf) {
+        float af[BK / 2][MCO], bf[BK / 2][MPIX];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[MCO], bf[MPIX];
 #pragma unroll
             for (int mi = 0; mi < MCO; ++mi)
-                af[mi] = As[buf][2 * kk + khalf][wave_co * WCO + mi * 32 + l31];
+                af[kk][mi] = As[buf][2 * kk + khalf][wave_co * WCO + mi * 32 + l31];
 #pragma unroll
             for (int ni = 0; ni < MPIX; ++ni)
-                bf[ni] = Bs[buf][2 * kk + khalf][wave_pix * WPIX + ni * 32 + l31];
+                bf[kk][ni] = Bs[buf][2 * kk + khalf][wave_pix * WPIX + ni * 32 + l31];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
             for (int mi = 0; mi < MCO; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < MPIX; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-        }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
     };
 
     if constexpr (!GENERIC) {
