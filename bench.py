@@ -43,7 +43,12 @@ def parse():
                     help='--mode fwd only: per-sample gate branch (hard one-hot); uniform = k = n %% 5. '
                          'With K16 compaction depth stage j runs on the samples with k >= j only')
     ap.add_argument('--no-compact', action='store_true', help='--mode fwd: disable K16 compaction (dense reference semantics)')
-    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step as one hipGraph.  Default is eager multi-stream launches: the step is '
+                         'GPU-bound at batch 32 (eager == graph on one stream) and the 3-stream schedule '
+                         '(RGB encoder | depth encoder | weight gradients) overlaps better un-captured')
+    ap.add_argument('--no-graph', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--single-stream', action='store_true', help='disable the depth-encoder and wgrad side streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -102,13 +107,23 @@ def cpu_baseline(args):
                       f'{args.mode} step, median of 3 after 1 warm-up'}
 
 
+model_ref = [None]
+
+
 def kernel_timing(step_fn):
     """One instrumented EAGER step: HIP events around every implicit-GEMM launch on the stream it is
     launched on.  Returns per-kernel-variant totals (launches, ms, algorithmic GFLOP)."""
+    # isolated per-kernel durations: the instrumented pass runs on ONE stream (in the timed region the
+    # RGB / depth / wgrad streams overlap, which inflates every individual kernel's wall duration)
+    saved = (ops.ASYNC_WGRAD, getattr(model_ref[0], 'dual_stream', False))
+    ops.ASYNC_WGRAD = False
+    model_ref[0].dual_stream = False
+    torch.cuda.synchronize()
     ops.PROFILE = []
     step_fn()
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
+    ops.ASYNC_WGRAD, model_ref[0].dual_stream = saved
     agg, shapes = {}, {}
     for name, flops, e0, e1, shape in rec:
         ms = e0.elapsed_time(e1)
@@ -139,6 +154,7 @@ def main():
     device = torch.device('cuda', local_rank)
 
     model = make_model(args.config, args.height, args.width, device)
+    model_ref[0] = model
     dp.broadcast_parameters(model)
     rgb, depth, labels = make_batch(args.batch, args.height, args.width, device, 1234 + rank)
     cw = torch.linspace(0.5, 2.0, 40, device=device)
@@ -147,6 +163,8 @@ def main():
     if train:
         model.train()
         model.hard_gate, model.temp = False, 1.0
+        model.dual_stream = not args.single_stream
+        ops.ASYNC_WGRAD = not args.single_stream
         reducer = dp.GradBucketReducer(model.parameters(), bucket_mb=32, overlap=False)
         ops.DIRECT_GRAD = True      # kernels write parameter gradients straight into the flat buffer views
     else:
@@ -168,10 +186,11 @@ def main():
         for o, t in zip(outs, labels):
             total = total + ops.cross_entropy_2d(o, t, cw)
         total.backward()
+        ops.join_async()
         return total
 
     graph = None
-    use_graph = not args.no_graph and (train or args.no_compact)   # compaction reads the branch on the host
+    use_graph = args.graph and (train or args.no_compact)   # compaction reads the branch on the host
     # warm-up (also initialises lazily-created buffers before capture)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -261,6 +280,7 @@ def main():
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'height': args.height, 'width': args.width,
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if graph is not None else 'eager',
+                       'streams': 1 if (args.single_stream or not train) else 3,
                        'model_tflops': round(value * gflop_img / 1e3, 2),
                        'model_frac_of_fp32_mfma_peak': round(value * gflop_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)},
             'roofline': roofline, 'cpu_baseline': cpu,

@@ -62,7 +62,7 @@ class SGDNesterov:
 
 class TrainStep:
     def __init__(self, model, class_weight, lr, momentum=0.9, weight_decay=1e-4, loss_ratio=0.0,
-                 flop_budget=0.0, use_graph=False, bucket_mb=32.0):
+                 flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True):
         self.model = model
         self.cw = torch.as_tensor(class_weight, dtype=torch.float32, device=next(model.parameters()).device)
         self.flatp = FlatParameters(model)
@@ -73,6 +73,10 @@ class TrainStep:
                                       'supported yet; use per-parameter torch.optim.SGD for --freeze runs')
         self.opt = SGDNesterov(self.flatp.flat, self.reducer.flat, lr, momentum, weight_decay)
         ops.DIRECT_GRAD = True      # one backward per zero(): gradients are written in place, not accumulated
+        # 3-stream schedule: RGB encoder | depth encoder | conv weight gradients (see nn/net.py, ops.py)
+        ops.ASYNC_WGRAD = bool(multi_stream)
+        if hasattr(model, 'dual_stream'):
+            model.dual_stream = bool(multi_stream)
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)
         self.use_graph = use_graph
         self._graph = None
@@ -88,6 +92,7 @@ class TrainStep:
             seg = seg + l
         total = seg + self.loss_ratio * torch.clamp(lf - self.flop_budget, min=0.0) if self.loss_ratio > 0 else seg
         total.backward()
+        ops.join_async()
         self.last = {'losses': torch.stack([l.detach() for l in losses]), 'loss_flop': lf.detach(),
                      'total': total.detach()}
 

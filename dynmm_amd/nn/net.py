@@ -129,6 +129,12 @@ class SkipGateESANet(nn.Module):
         # gradients are recorded or BN is in training mode.
         self.compact = True
         self.ini_branches = None          # optional fixed branch per sample for ini_stage (else CPU RNG)
+        # Run the depth encoder's stages on a second HIP stream so its kernels' ramp-up / store-burst /
+        # tail phases overlap with the RGB encoder's (both encoders are independent between fusion
+        # points).  Autograd replays each backward node on its forward stream, so the backward gets
+        # the same concurrency.  Off by default until measured.
+        self.dual_stream = False
+        self._side = None
         self.last_stage_batch = None      # depth-stage batch sizes of the last compacted forward
 
     # ---- caller protocol (train.py:141,190-197,284,351; eval.py:64-68) -------------------------
@@ -196,6 +202,25 @@ class SkipGateESANet(nn.Module):
 
         skips = []
         for j in (1, 2, 3, 4):
+            if self.dual_stream and not compacted:
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                main = torch.cuda.current_stream()
+                capturing = torch.cuda.is_current_stream_capturing()
+                self._side.wait_stream(main)
+                if not capturing:
+                    d.record_stream(self._side)      # allocated on `main`, read on the side stream
+                with torch.cuda.stream(self._side):
+                    d = getattr(ed, f'forward_layer{j}')(d)
+                r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
+                main.wait_stream(self._side)
+                if not capturing:
+                    d.record_stream(main)            # allocated on the side stream, read by the fusion on `main`
+                fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
+                if j < 4:
+                    sk = getattr(self, f'skip_layer{j}')
+                    skips.append(sk[0](fuse) if len(sk) else fuse)
+                continue
             r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
             if not compacted:
                 d = getattr(ed, f'forward_layer{j}')(d)

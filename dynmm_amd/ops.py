@@ -48,6 +48,28 @@ def _chk(t, name='tensor'):
 DIRECT_GRAD = False
 
 
+# Opt-in with DIRECT_GRAD: launch every conv weight-gradient kernel on a dedicated stream.  dgrad and
+# wgrad of a layer depend only on the incoming gradient, so the wgrad queue runs concurrently with
+# the main backward chain and fills its ramp-up / tail bubbles.  Tensors it reads are kept alive in
+# _INFLIGHT until join_async() (call it after backward, on the stream that consumes the gradients).
+ASYNC_WGRAD = False
+_WGRAD_STREAM = None
+_INFLIGHT = []
+
+
+def _wgrad_stream():
+    global _WGRAD_STREAM
+    if _WGRAD_STREAM is None:
+        _WGRAD_STREAM = torch.cuda.Stream()
+    return _WGRAD_STREAM
+
+
+def join_async():
+    if _WGRAD_STREAM is not None and _INFLIGHT:
+        torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
+    _INFLIGHT.clear()
+
+
 def _grad_dst(param, like=None):
     """(tensor to write the gradient into, value to return to autograd)."""
     if DIRECT_GRAD and param is not None and getattr(param, 'grad', None) is not None and param.grad.is_contiguous() \
@@ -175,9 +197,18 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[2]:
             dw, dw_ret = _grad_dst(ctx.w_param)
             nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
-            ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
-            L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes,
-                                                                      C.byref(g), st)), 'conv2d_wgrad')
+            if ASYNC_WGRAD and dw_ret is None and PROFILE is None:
+                ws_stream = _wgrad_stream()
+                ws_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(ws_stream):
+                    ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
+                    L.check(lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes, C.byref(g),
+                                                   ws_stream.cuda_stream), 'conv2d_wgrad')
+                _INFLIGHT.append((x, x2, gy))
+            else:
+                ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
+                L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes,
+                                                                          C.byref(g), st)), 'conv2d_wgrad')
         return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None
 
 

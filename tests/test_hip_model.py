@@ -114,8 +114,8 @@ def _rl2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize('cfg', ['P_se', 'S_add'])
-def test_model_vs_oracle_fwd_bwd_full_tensors(cfg):
+@pytest.mark.parametrize('cfg,dual', [('P_se', False), ('S_add', False), ('P_se', True)])
+def test_model_vs_oracle_fwd_bwd_full_tensors(cfg, dual):
     """Every output and EVERY parameter-gradient tensor of one train step, HIP vs oracle.
 
     Train-mode gradients of this ~100-layer net are ill-conditioned in fp32 (stacked BatchNorm
@@ -133,8 +133,10 @@ def test_model_vs_oracle_fwd_bwd_full_tensors(cfg):
     m = hip_model(cfg, h, w, seed=5)
     m.train()
     m.temp = 0.7
+    m.dual_stream = dual          # depth encoder on a second HIP stream (fwd and, via autograd, bwd)
     outs, lf = m(rgb.cuda(), depth.cuda())
     Hh.train_loss(outs, lf).backward()
+    torch.cuda.synchronize()
     for a, b32, b64 in zip(outs, outs32, outs64):
         e_ref = Hh.rel_err(b32.detach(), b64.detach())
         assert Hh.rel_err(a.detach().cpu(), b64.detach()) < max(3 * e_ref, 1e-5) and \
