@@ -249,7 +249,7 @@ def main():
             pmc = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                    traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
             roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,

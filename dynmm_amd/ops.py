@@ -92,7 +92,9 @@ def _timed(kind, g, call):
     if PROFILE is None:
         return call()
     co = g.Ci if kind == 'dgrad' else g.Co
-    name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co)}>'
+    gemm_ci = g.Co if kind == 'dgrad' else g.Ci
+    generic = ',generic' if (kind != 'wgrad' and (gemm_ci % 16 != 0 or (g.c_split < g.Ci and g.c_split % 16 != 0))) else ''
+    name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co)}{generic}>'
     flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

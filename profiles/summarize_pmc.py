@@ -1,0 +1,61 @@
+"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (mean per launch) and emit the
+HBM-traffic record bench.py reads (profiles/pmc_dominant_kernel.json).
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  gfx950 correction (MI355X_MICROARCH.md, section HBM):
+FETCH_SIZE under-reports a wide (16 B/lane) coalesced read stream by exactly 2x; the implicit-GEMM
+gathers are 4 B/lane (uncalibrated width), so both the raw and the x2 figure are recorded and the
+JSON carries the raw one plus the bound.  WRITE_SIZE matched the algorithmic output bytes exactly in
+a calibration launch (76,800 KiB reported vs 78.6 MB written)."""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} | {'launches': len(next(iter(d.values())))} for k, d in agg.items()}
+
+
+def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr):
+    f, w, q = per_kernel(fetch_csv), per_kernel(write_csv), per_kernel(sq_csv)
+    names = sorted(f, key=lambda k: -f[k].get('FETCH_SIZE', 0) * f[k]['launches'])
+    lines = ['| kernel | launches | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | MFMA busy / (SIMDs x GUI cycles) | WAIT_INST_ANY / WAVE_CYCLES |',
+             '|---|---|---|---|---|---|']
+    for k in names[:25]:
+        sq = q.get(k, {})
+        util = ''
+        if sq.get('GRBM_GUI_ACTIVE'):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+            util = f"{sq.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024 * sq['GRBM_GUI_ACTIVE'] / 8):.2f}"
+        wi = f"{sq.get('SQ_WAIT_INST_ANY', 0) / sq['SQ_WAVE_CYCLES']:.2f}" if sq.get('SQ_WAVE_CYCLES') else ''
+        short = k if len(k) < 90 else k[:87] + '...'
+        lines.append(f"| `{short}` | {f[k]['launches']} | {f[k].get('FETCH_SIZE', 0):.0f} | {w.get(k, {}).get('WRITE_SIZE', 0):.0f} | {util} | {wi} |")
+    open(out_md, 'w').write('\n'.join(lines) + '\n')
+    # bench.py kernel-variant name -> demangled template instance
+    variants = {'conv_igemm_fwd<128x64>': 'conv_igemm_kernel<128, 64, 64, 32, false, false>',
+                'conv_igemm_dgrad<128x64>': 'conv_igemm_kernel<128, 64, 64, 32, true, false>',
+                'conv_igemm_fwd<64x128>': 'conv_igemm_kernel<64, 128, 32, 64, false, false>',
+                'conv_igemm_dgrad<64x128>': 'conv_igemm_kernel<64, 128, 32, 64, true, false>',
+                'conv_wgrad<co128>': 'conv_wgrad_kernel<128, 128, 64, 64, false>',
+                'conv_wgrad<co64>': 'conv_wgrad_kernel<64, 128, 64, 32, false>'}
+    out = {'note': 'mean per launch over one bench step (batch 32); raw FETCH_SIZE+WRITE_SIZE, KiB->bytes. 4 B/lane '
+                   'gathers are an uncalibrated width for FETCH_SIZE on gfx950: *_if_fetch_x2 is the upper bound.'}
+    for bench_name, sub in variants.items():
+        ks = [k for k in f if sub in k]
+        if not ks:
+            continue
+        k = ks[0]
+        fe, wr = f[k].get('FETCH_SIZE', 0), w.get(k, {}).get('WRITE_SIZE', 0)
+        out[bench_name] = {'kernel': k, 'launches_profiled': f[k]['launches'], 'fetch_kib_per_launch_raw': fe,
+                           'write_kib_per_launch': wr, 'hbm_bytes_per_launch': (fe + wr) * 1024,
+                           'hbm_bytes_per_launch_if_fetch_x2': (2 * fe + wr) * 1024}
+    json.dump(out, open(out_json, 'w'), indent=1)
+    print(json.dumps(out, indent=1)[:1500])
+    print('\n'.join(lines[:12]))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:7])
