@@ -96,6 +96,40 @@ __global__ void __launch_bounds__(256) sgd_nesterov_kernel(float* __restrict__ p
     }
 }
 
+// eval.py:117-141 as ONE pass: bilinear resize (align_corners=False) of the 40-channel logits to the
+// label resolution, arg-max over classes, void mask (label 0), confusion-matrix increment
+// cm[(label-1)*C + pred] += 1 (int64).  The resized logits and the arg-max map are never materialised.
+__global__ void __launch_bounds__(256) eval_confusion_kernel(const float* __restrict__ x,
+                                                             const unsigned char* __restrict__ label,
+                                                             unsigned long long* __restrict__ cm,
+                                                             int C, int H, int W, int Ho, int Wo) {
+    const int n = blockIdx.y;
+    const float* xn = x + (size_t)n * C * H * W;
+    const unsigned char* ln = label + (size_t)n * Ho * Wo;
+    const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.x * 256) {
+        const int lab = (int)ln[p] - 1;
+        if (lab < 0 || lab >= C) continue;
+        const int oh = p / Wo, ow = p - oh * Wo;
+        float fy = sh * ((float)oh + 0.5f) - 0.5f, fx = sw * ((float)ow + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int c = 0; c < C; ++c) {
+            const float* pc = xn + (size_t)c * H * W;
+            const float v = ly0 * (lx0 * pc[y0 * W + x0] + lx1 * pc[y0 * W + x1]) +
+                            ly1 * (lx0 * pc[y1 * W + x0] + lx1 * pc[y1 * W + x1]);
+            if (v > best) { best = v; arg = c; }       // first maximum, as torch.argmax
+        }
+        atomicAdd(&cm[(size_t)lab * C + arg], 1ull);
+    }
+}
+
 }  // namespace dynmm
 
 using namespace dynmm;
@@ -136,6 +170,19 @@ extern "C" int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t n
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        p, g, buf, n, lr, momentum, weight_decay, grad_scale);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_eval_confusion(const float* logits, const unsigned char* label, long long* cm, int N,
+                                    int C, int H, int W, int Ho, int Wo, void* stream) {
+    (void)hipGetLastError();
+    if (!logits || !label || !cm || N <= 0 || C <= 0 || C > kMaxClasses || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0)
+        return DYNMM_EINVAL;
+    int bx = ceil_div(Ho * Wo, 256);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(eval_confusion_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, logits, label,
+                       reinterpret_cast<unsigned long long*>(cm), C, H, W, Ho, Wo);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -11,7 +11,6 @@
 import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
 from . import dp, ops
 from . import lib as L
@@ -143,11 +142,7 @@ def evaluate(model, batches, num_classes=40, hard=True):
     old_hard, model.hard_gate = model.hard_gate, hard
     cm = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=next(model.parameters()).device)
     for rgb, depth, label in batches:
-        pred = model(rgb, depth, True)
-        pred = F.interpolate(pred, label.shape[-2:], mode='bilinear', align_corners=False).argmax(1)
-        mask = label > 0
-        lab = label[mask].long() - 1
-        cm += torch.bincount(num_classes * lab + pred[mask], minlength=num_classes ** 2).reshape(num_classes, num_classes)
+        ops.eval_confusion(model(rgb, depth, True), label, cm)     # resize + argmax + void mask + bincount, one kernel
     model.hard_gate = old_hard
     model.train(was_training)
     cmd = cm.double()

@@ -62,6 +62,7 @@ SIGNATURES = {
     'dynmm_gate_head_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_fl, c_f]),
     'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_f]),
     'dynmm_ce2d_bwd': (c_i, [c_f] * 5 + [c_i, c_i, c_i, c_f]),
+    'dynmm_eval_confusion': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
     'dynmm_batch_gather': (c_i, [c_f, c_f, c_f, c_i, c_sz, c_f]),
     'dynmm_batch_merge': (c_i, [c_f, c_f, c_f, c_f, c_i, c_sz, c_f]),
     'dynmm_reduce_slabs': (c_i, [c_f, c_f, c_i, c_i, c_f]),

@@ -653,3 +653,19 @@ def cross_entropy_2d(logits, target, class_weight):
     if not t.is_contiguous():
         t = t.contiguous()
     return _CrossEntropy2d.apply(logits, t, class_weight)
+
+
+def eval_confusion(logits, label, cm):
+    """cm (int64 [C,C], device) += confusion counts of argmax(bilinear_resize(logits, label size)) vs label-1
+    over non-void pixels — eval.py:117-141 fused into one kernel (no resized logits, no arg-max map)."""
+    lib = _lib()
+    logits = _chk(logits, 'logits')
+    lab = label if label.dtype == torch.uint8 else label.to(torch.uint8)
+    lab = lab if lab.is_contiguous() else lab.contiguous()
+    N, Cc, H, W = logits.shape
+    Ho, Wo = lab.shape[-2:]
+    if cm.dtype != torch.int64 or not cm.is_contiguous() or cm.numel() != Cc * Cc:
+        raise L.DynmmHipError('cm must be a contiguous int64 [C,C] tensor')
+    L.check(lib.dynmm_eval_confusion(_p(logits), lab.data_ptr(), cm.data_ptr(), N, Cc, H, W, Ho, Wo, _stream()),
+            'eval_confusion')
+    return cm

@@ -191,6 +191,12 @@ int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
 int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
                    const float* gscale, float* dx, int N, int C, int HW, void* stream);
 
+/* ---- eval post-processing + confusion matrix on device (eval.py:117-141, src/confusion_matrix.py:118-130;
+ * SURVEY §8f-2): cm[(label-1)*C + argmax_c bilinear(logits)(label pixel)] += 1 for label > 0.
+ * logits [N,C,H,W]; label uint8 [N,Ho,Wo] (0 = void); cm int64 [C*C], accumulated (caller zeroes). */
+int dynmm_eval_confusion(const float* logits, const unsigned char* label, long long* cm,
+                         int N, int C, int H, int W, int Ho, int Wo, void* stream);
+
 /* ---- gate-decision stream compaction (new: SURVEY.md K16; the reference never skips compute,
  * src/models/model_skip_mod_globalgate.py:276-310) ----
  * gather: dst[i] = src[idx[i]]  (i < n_out);  merge: out[n] = map[n] >= 0 ? sub[map[n]] : base[n].

@@ -334,3 +334,20 @@ def test_rejects_cpu_tensors(ops):
     from dynmm_amd.lib import DynmmHipError
     with pytest.raises(DynmmHipError):
         ops.conv2d(torch.randn(1, 16, 8, 8), torch.randn(16, 16, 3, 3), None, 1, 1)
+
+
+@pytest.mark.parametrize('label_hw', [(24, 32), (37, 50), (12, 16)])
+def test_eval_confusion(ops, label_hw):
+    """eval.py:117-141 fused: bilinear resize to the label size, argmax, void mask, confusion matrix."""
+    x = rnd(3, 40, 24, 32, seed=1)
+    g = torch.Generator().manual_seed(5)
+    label = torch.randint(0, 41, (3, *label_hw), generator=g)
+    pred = F.interpolate(x, label_hw, mode='bilinear', align_corners=False).argmax(1)
+    mask = label > 0
+    ref = torch.bincount(40 * (label[mask] - 1) + pred[mask], minlength=1600).reshape(40, 40)
+    cm = torch.zeros(40, 40, dtype=torch.int64, device='cuda')
+    ops.eval_confusion(x.cuda(), label.cuda(), cm)
+    ops.eval_confusion(x.cuda(), label.cuda(), cm)       # accumulates
+    diff = (cm.cpu() - 2 * ref).abs().sum().item()
+    assert diff <= 4, diff      # a handful of fp32 arg-max ties at most
+    assert cm.sum().item() == 2 * mask.sum().item()
