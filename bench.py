@@ -287,6 +287,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()          # rank 0 finishes its instrumented pass before anyone tears NCCL down
         dist.destroy_process_group()
 
 

@@ -112,7 +112,16 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+def _same_shape(a, b, what):
+    if b is not None and tuple(a.shape) != tuple(b.shape):
+        raise L.DynmmHipError(f'{what}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}')
+
+
 def _geom(x, x2, weight, stride, padding):
+    if x.dim() != 4 or weight.dim() != 4:
+        raise L.DynmmHipError('conv2d expects NCHW input and OIHW weight')
+    if x2 is not None and (x2.shape[0] != x.shape[0] or tuple(x2.shape[2:]) != tuple(x.shape[2:])):
+        raise L.DynmmHipError(f'conv2d: second input {tuple(x2.shape)} does not match {tuple(x.shape)}')
     N, C0, H, W = x.shape
     Ci = C0 + (x2.shape[1] if x2 is not None else 0)
     Co, Ciw, KH, KW = weight.shape
@@ -122,6 +131,9 @@ def _geom(x, x2, weight, stride, padding):
     PH, PW = padding
     Ho = (H + 2 * PH - KH) // SH + 1
     Wo = (W + 2 * PW - KW) // SW + 1
+    if N <= 0 or Ho <= 0 or Wo <= 0:
+        raise L.DynmmHipError(f'conv2d: empty output for input {tuple(x.shape)}, kernel {(KH, KW)}, stride {stride}, '
+                              f'padding {padding}')
     g = L.ConvGeom(N, Ci, H, W, Co, Ho, Wo, KH, KW, SH, SW, PH, PW, C0)
     return g
 
@@ -261,10 +273,13 @@ class _BatchNormAct(Function):
         lib = _lib()
         st = _stream()
         x, residual = _chk(x, 'x'), _chk(residual, 'residual')
+        _same_shape(x, residual, 'batch_norm residual')
         N, Cc, H, W = x.shape
         HW = H * W
         dev = x.device
         sums = None
+        if training and N * HW <= 1:
+            raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
         if training:
             sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
             L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, st), 'bn_stats')
@@ -429,6 +444,9 @@ class _Upsample2xDw(Function):
         lib = _lib()
         x, weight, bias, skip = _chk(x, 'x'), _chk(weight, 'weight'), _chk(bias, 'bias'), _chk(skip, 'skip')
         N, Cc, H, W = x.shape
+        if skip is not None and tuple(skip.shape) != (N, Cc, 2 * H, 2 * W):
+            raise L.DynmmHipError(f'upsample skip connection {tuple(skip.shape)} does not match the upsampled '
+                                  f'feature map {(N, Cc, 2 * H, 2 * W)} (input H, W must be multiples of 32)')
         y = torch.empty((N, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
         L.check(lib.dynmm_upsample2x_dw3x3_fwd(_p(x), _p(weight), _p(bias), _p(skip), _p(y), N, Cc, H, W,
                                                _stream()), 'upsample_fwd')
@@ -473,6 +491,7 @@ class _SEFuseBlend(Function):
         lib = _lib()
         st = _stream()
         rgb, depth = _chk(rgb, 'rgb'), _chk(depth, 'depth')
+        _same_shape(rgb, depth, 'rgb/depth fusion')
         N, Cc, H, W = rgb.shape
         HW = H * W
         dev = rgb.device

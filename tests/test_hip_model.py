@@ -248,3 +248,27 @@ def test_hard_gate_compaction_is_exact(cfg):
         finally:
             torch.randint = real
         assert Hh.rel_err(oc.cpu(), od.cpu()) < 1e-5
+
+
+def test_edge_shapes_and_errors():
+    """Edge cases around the boundary: batch 1 inference, the smallest legal resolution, batch 1 in
+    training mode (BatchNorm over one value -> the same ValueError PyTorch raises), inputs whose size is
+    not a multiple of 32 (decoder skip shapes cannot match), mismatched rgb/depth."""
+    from dynmm_amd.lib import DynmmHipError
+    m = hip_model('P_se', 96, 128)
+    m.eval()
+    with torch.no_grad():
+        rgb, depth = synth.synth_inputs(1, 96, 128, seed=1, device='cuda')
+        out = m(rgb, depth, test=True)
+        assert out.shape == (1, 40, 96, 128) and torch.isfinite(out).all()
+        rgb2, depth2 = synth.synth_inputs(2, 96, 128, seed=1, device='cuda')
+        out2 = m(torch.cat([rgb, rgb2[1:]]), torch.cat([depth, depth2[1:]]), test=True)
+        assert Hh.rel_err(out2[:1].cpu(), out.cpu()) < 1e-5          # batch-composition invariance
+        with pytest.raises(DynmmHipError):
+            r, d = synth.synth_inputs(1, 100, 128, seed=1, device='cuda')     # 100 is not a multiple of 32
+            m(r, d, test=True)
+        with pytest.raises(DynmmHipError):
+            m(rgb, depth2, test=True)                                          # batch mismatch rgb vs depth
+    m.train()
+    with pytest.raises(ValueError):
+        m(rgb, depth)                                                          # PPM 1x1 branch: one value per channel
