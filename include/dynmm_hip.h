@@ -84,6 +84,25 @@ int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* 
                        void* workspace, size_t workspace_bytes,
                        const dynmm_conv_geom* g, void* stream);
 
+/* ---- split-precision variant (csrc/conv_bf16x3.hip) ----
+ * fp32 tensors; every operand is split on the fly into `nsplit` bf16 pieces and the piece products with
+ * p+q < nsplit are accumulated in fp32 on v_mfma_f32_32x32x16_bf16:
+ *   nsplit = 3 ("bf16x6", 24 mantissa bits): fp32-rounding-class results at 6/16 of the fp32-MFMA cost;
+ *   nsplit = 2 ("bf16x3", 16 bits): ~1e-5 on eval logits, opt-in.
+ * Epilogue identical to the fp32 entry points above.  Eligible when the GEMM's reduction channels are a
+ * multiple of 32 and it has > 32 output channels (dynmm_conv_bf16x3_eligible); weights come pre-split from
+ * dynmm_pack_weight_bf16:  fwd [nsplit][Co][KH*KW*Ci] (k = tap*Ci+ci),
+ *                          dgrad [nsplit][Ci][KH*KW*Co] (k = tap*Co+co), bf16 bit patterns. */
+int dynmm_conv_bf16x3_eligible(const dynmm_conv_geom* g, int dgrad);
+int dynmm_pack_weight_bf16(const float* w, unsigned short* fwd, unsigned short* dgrad,
+                           int Co, int Ci, int KH, int KW, int nsplit, void* stream);
+int dynmm_conv2d_fwd_bf16(const float* x, const unsigned short* w_split, int nsplit,
+                          const float* scale, const float* shift, const float* residual,
+                          float* y, const dynmm_conv_geom* g, int act, void* stream);
+int dynmm_conv2d_dgrad_bf16(const float* dy, const unsigned short* wd_split, int nsplit,
+                            const float* mask, const float* accum, float* dx,
+                            const dynmm_conv_geom* g, void* stream);
+
 /* g_out = g * act'(y) ; dbias[c] = sum_{n,hw} g_out   (either output may be NULL).
  * ReLU/tanh backward + bias gradient of a conv+bias+act (autograd of resnet.py:125-126 etc.). */
 int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias,

@@ -351,3 +351,31 @@ def test_eval_confusion(ops, label_hw):
     diff = (cm.cpu() - 2 * ref).abs().sum().item()
     assert diff <= 4, diff      # a handful of fp32 arg-max ties at most
     assert cm.sum().item() == 2 * mask.sum().item()
+
+
+@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 5e-5, 5e-4), ('bf16x6', 2e-5, 2e-4)])
+@pytest.mark.parametrize('case', [(2, 128, 24, 32, 128, (3, 1), (1, 1), (1, 0)), (2, 64, 24, 32, 64, (1, 3), (1, 1), (0, 1)),
+                                  (2, 256, 12, 16, 512, (3, 1), (2, 1), (1, 0)), (2, 128, 24, 32, 128, (3, 3), (1, 1), (1, 1))])
+def test_conv2d_split_precision(ops, precision, tol, gtol, case):
+    """Opt-in bf16 split-precision matrix-core paths (csrc/conv_bf16x3.hip): forward and input gradient vs
+    a float64 PyTorch reference.  bf16x3 = 16 mantissa bits (3 MFMAs), bf16x6 = 24 bits (6 MFMAs)."""
+    N, Ci, H, W, Co, k, s, p = case
+    x, w = rnd(N, Ci, H, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * k[0] * k[1]) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.relu(F.conv2d(xr, wr, br, s, p))
+    gy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(gy.double())
+    old = ops.PRECISION
+    ops.PRECISION = precision
+    try:
+        xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+        with torch.no_grad():
+            y_inf = ops.conv2d(xg, wg, bg, s, p, 'relu')
+        y = ops.conv2d(xg, wg, bg, s, p, 'relu')
+        y.backward(gy.cuda())
+    finally:
+        ops.PRECISION = old
+    assert rel(y_inf, y_ref) < tol and rel(y, y_ref) < tol
+    assert rel(xg.grad, xr.grad) < gtol
+    assert rel(wg.grad, wr.grad) < GTOL           # weight gradients stay on the fp32 kernel
