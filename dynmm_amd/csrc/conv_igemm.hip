@@ -543,7 +543,9 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     const int M = g->N * g->Ho * g->Wo;
     const int total_steps = ceil_div(M, 32);
     const int tiles = p.n_co_tiles * p.n_k_tiles;
-    int splits = 512 / tiles;                          // ONE residency round: 256 CUs x 2 workgroups (202 VGPRs)
+    static const int target_env = env_int("DYNMM_WGRAD_BLOCKS");
+    const int target = target_env ? target_env : 512;  // ONE residency round: 256 CUs x 2 workgroups (180 VGPRs)
+    int splits = target / tiles;
     if (splits < 1) splits = 1;
     const int max_splits = ceil_div(total_steps, 8);   // >= 256 pixels per workgroup
     if (splits > max_splits) splits = max_splits;

@@ -6,6 +6,7 @@ functions require contiguous fp32 tensors on a HIP device and raise otherwise â€
 fallback.
 """
 import ctypes as C
+import os as _os
 
 import torch
 from torch.autograd import Function
@@ -85,20 +86,24 @@ DIRECT_GRAD = False
 # the main backward chain and fills its ramp-up / tail bubbles.  Tensors it reads are kept alive in
 # _INFLIGHT until join_async() (call it after backward, on the stream that consumes the gradients).
 ASYNC_WGRAD = False
-_WGRAD_STREAM = None
+WGRAD_STREAMS = int(_os.environ.get('DYNMM_WGRAD_STREAMS', '1'))
+_WGRAD_POOL = []
+_WGRAD_RR = [0]
 _INFLIGHT = []
 
 
 def _wgrad_stream():
-    global _WGRAD_STREAM
-    if _WGRAD_STREAM is None:
-        _WGRAD_STREAM = torch.cuda.Stream()
-    return _WGRAD_STREAM
+    while len(_WGRAD_POOL) < max(1, WGRAD_STREAMS):
+        _WGRAD_POOL.append(torch.cuda.Stream())
+    _WGRAD_RR[0] = (_WGRAD_RR[0] + 1) % max(1, WGRAD_STREAMS)
+    return _WGRAD_POOL[_WGRAD_RR[0]]
 
 
 def join_async():
-    if _WGRAD_STREAM is not None and _INFLIGHT:
-        torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
+    if _INFLIGHT:
+        cur = torch.cuda.current_stream()
+        for s in _WGRAD_POOL:
+            cur.wait_stream(s)
     _INFLIGHT.clear()
 
 
