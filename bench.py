@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 from dynmm_amd import dp, ops, synth                        # noqa: E402
 from dynmm_amd.nn.net import SkipGateESANet                 # noqa: E402
+from dynmm_amd.nn.net_skip import SkipESANet                # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 GFLOP_PER_IMG_FWD_BWD = {'P': 222.98, 'S': 300.8}   # BASELINE.md §2 (conv MACs x2, fwd+bwd)
@@ -37,6 +38,9 @@ def parse():
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--config', default='P', choices=['P', 'S'])
+    ap.add_argument('--model', default='gate', choices=['gate', 'skip'],
+                    help="gate: SkipGateESANet (global gate, the north-star line); skip: SkipESANet (per-stage Gumbel "
+                         "gates, block_rule 2222) — a side measurement, SURVEY.md §8f-3")
     ap.add_argument('--mode', default='train', choices=['train', 'fwd'],
                     help="train: fwd+bwd soft gates (configs[2]); fwd: eval forward, gate forced on (configs[1])")
     ap.add_argument('--branches', default='all4', choices=['all4', 'uniform', 'all0'],
@@ -55,9 +59,14 @@ def parse():
     return ap.parse_args()
 
 
-def make_model(cfg, h, w, device):
+def make_model(cfg, h, w, device, kind='gate'):
     block = 'NonBottleneck1D' if cfg == 'P' else 'BasicBlock'
-    m = SkipGateESANet(height=h, width=w, encoder_block=block, fuse_depth_in_rgb_encoder='SE-add')
+    if kind == 'skip':
+        m = SkipESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34', encoder_depth='resnet34',
+                       encoder_block=block, nr_decoder_blocks=[3, 3, 3], fuse_depth_in_rgb_encoder='SE-add',
+                       block_rule=[2, 2, 2, 2])
+    else:
+        m = SkipGateESANet(height=h, width=w, encoder_block=block, fuse_depth_in_rgb_encoder='SE-add')
     synth.fill_state_dict(m.state_dict(), seed=0)
     return m.to(device)
 
@@ -77,21 +86,29 @@ def cpu_baseline(args):
     from oracle import dynmm_oracle as O
     n = args.cpu_batch
     cfg = O.Config(encoder_block='NonBottleneck1D' if args.config == 'P' else 'BasicBlock', fuse='SE-add')
-    m = make_model(args.config, args.height, args.width, 'cpu')
+    m = make_model(args.config, args.height, args.width, 'cpu', args.model)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k]
     rgb, depth, labels = make_batch(n, args.height, args.width, 'cpu', 1234)
     cw = torch.linspace(0.5, 2.0, 40)
     cores = torch.get_num_threads()
 
+    noise = [torch.empty(n, 2).exponential_() for _ in range(4)]
+
     def one():
         if args.mode == 'fwd':
             with torch.no_grad():
-                O.forward(sd, rgb, depth, cfg, test=True, baseline=True)
+                if args.model == 'skip':
+                    O.forward_skip(sd, rgb, depth, cfg, noise, test=True)
+                else:
+                    O.forward(sd, rgb, depth, cfg, test=True, baseline=True)
             return
         for p in params:
             p.grad = None
-        outs, lf = O.forward(sd, rgb, depth, cfg, training=True, temp=1.0)
+        if args.model == 'skip':
+            outs, lf = O.forward_skip(sd, rgb, depth, cfg, noise, training=True), 0.0
+        else:
+            outs, lf = O.forward(sd, rgb, depth, cfg, training=True, temp=1.0)
         losses = O.cross_entropy_2d(outs, labels, cw)
         (sum(losses) + lf).backward()
 
@@ -153,7 +170,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
-    model = make_model(args.config, args.height, args.width, device)
+    model = make_model(args.config, args.height, args.width, device, args.model)
     model_ref[0] = model
     dp.broadcast_parameters(model)
     rgb, depth, labels = make_batch(args.batch, args.height, args.width, device, 1234 + rank)
@@ -181,8 +198,10 @@ def main():
             with torch.no_grad():
                 return model(rgb, depth, test=True)
         reducer.zero()
-        outs, lf = model(rgb, depth)
-        total = lf
+        if args.model == 'skip':
+            outs, total = model(rgb, depth), 0.0
+        else:
+            outs, total = model(rgb, depth)
         for o, t in zip(outs, labels):
             total = total + ops.cross_entropy_2d(o, t, cw)
         total.backward()
@@ -272,10 +291,14 @@ def main():
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('configs[2]: fwd+bwd --dynamic --global-gate soft DiffSoftmax gates tau=1, '
-                                    'weighted 4-scale CE + FLOP loss' if train else
-                                    'configs[1]: fwd-only eval, static fuse (gate forced on)'),
-                       'net': f'SkipGateESANet R34-{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
+            'config': {'workload': (('configs[2]: fwd+bwd --dynamic --global-gate soft DiffSoftmax gates tau=1, '
+                                     'weighted 4-scale CE + FLOP loss' if train else
+                                     'configs[1]: fwd-only eval, static fuse (gate forced on)') if args.model == 'gate' else
+                                    ('fwd+bwd --dynamic (per-stage Gumbel-softmax gates, block_rule 2222, soft tau=1), '
+                                     'weighted 4-scale CE' if train else 'fwd-only eval test=True (hard Gumbel gates; depth stages run on the still-fusing samples only '
+                                     'unless --no-compact)')),
+                       'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
+                              f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
                        'branches': None if train else args.branches, 'compaction': None if train else (not args.no_compact),
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'height': args.height, 'width': args.width,

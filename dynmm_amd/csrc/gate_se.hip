@@ -239,6 +239,158 @@ __global__ void __launch_bounds__(256) gate_head_bwd_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SkipESANet per-stage gate (rgb_depth_fusion.py:29-65, model_utils.py:54-70, model_skip_mod.py:248-311)
+//   p      = [GAP(rgb); GAP(depth)]                       (2C values, from gap2)
+//   g      = sigmoid(W2 relu(W1 p + b1) + b2)             (SE excitation over the concatenation)
+//   s      = mean_{c,h,w}(x * g) = sum_c g[c] p[c] / 2C   (the feature map is never re-read)
+//   w      = sigmoid(s);  logits = [w, 1-w] / temp
+//   y      = gumbel_softmax(logits, tau=1, hard)          (G = -log E, E ~ Exp(1): given or Philox)
+//   prev  -> b1 = y1 * prev ; b0 = 1 - b1                 (chained stage weights)
+// and, in the same launch, the blend coefficients of THIS stage's fusion
+//   out = w0*rgb + w1*(rgb + depth) = (w0 + w1)*rgb + w1*depth.
+// One workgroup per sample; latency-bound.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAux = 6;   // aux[n] = {w, ysoft0, ysoft1, y1 (forward value), E0, E1}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float exp1_from_bits(uint32_t x) {
+    const float u = ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f);   // (0,1)
+    return -logf(u);
+}
+
+struct MlpParams { const float* p[4]; };   // W1[2C/16,2C] b1 W2[2C,2C/16] b2
+struct MlpGrads { float* p[4]; };
+
+__global__ void __launch_bounds__(256) reweigh_fwd_kernel(
+    const float* __restrict__ sr, const float* __restrict__ sd, MlpParams P,
+    const float* __restrict__ wblend, int blend_mode, const float* __restrict__ prev, int prev_stride,
+    const float* __restrict__ noise, unsigned long long seed, unsigned long long offset, float temp,
+    int hard, float* __restrict__ a, float* __restrict__ b, float* __restrict__ wnext,
+    float* __restrict__ h, float* __restrict__ g, float* __restrict__ aux, int C) {
+    __shared__ float p_lds[kMaxC];
+    __shared__ float h_lds[kMaxHid];
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    if (a) {
+        float fa = 1.f, fb = 1.f;                       // mode 1: rgb + depth
+        if (blend_mode == 0) fb = 0.f;                  // rgb only
+        else if (blend_mode == 2) { fb = wblend[2 * n + 1]; fa = wblend[2 * n] + fb; }
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            a[(size_t)n * C + c] = fa;
+            b[(size_t)n * C + c] = fb;
+        }
+    }
+    if (!wnext) return;
+    const int C2 = 2 * C, Hd = C2 / 16;
+    for (int c = threadIdx.x; c < C2; c += blockDim.x)
+        p_lds[c] = c < C ? sr[(size_t)n * C + c] : sd[(size_t)n * C + (c - C)];
+    __syncthreads();
+    float* gn = g + (size_t)n * C2;
+    se_mlp_fwd(p_lds, P.p[0], P.p[1], P.p[2], P.p[3], h_lds, h + (size_t)n * Hd, gn, C2, Hd);
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C2; c += blockDim.x) acc += gn[c] * p_lds[c];   // same thread wrote gn[c]
+    const float tot = block_reduce_sum_256<float>(acc, red);
+    if (threadIdx.x == 0) {
+        const float w = sigmoidf_(tot / (float)C2);
+        float e0, e1;
+        if (noise) { e0 = noise[2 * n]; e1 = noise[2 * n + 1]; }
+        else {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)n, 0u, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                          (uint32_t)(seed >> 32), r);
+            e0 = exp1_from_bits(r[0]); e1 = exp1_from_bits(r[1]);
+        }
+        const float z0 = w / temp - logf(e0), z1 = (1.f - w) / temp - logf(e1);
+        const float zm = fmaxf(z0, z1);
+        const float x0 = expf(z0 - zm), x1 = expf(z1 - zm);
+        const float ys0 = x0 / (x0 + x1), ys1 = x1 / (x0 + x1);
+        float y0 = ys0, y1 = ys1;
+        if (hard) {                                      // (y_hard - sg(y_soft)) + y_soft, first maximum
+            const int arg = ys1 > ys0 ? 1 : 0;
+            y0 = ((arg == 0 ? 1.f : 0.f) - ys0) + ys0;
+            y1 = ((arg == 1 ? 1.f : 0.f) - ys1) + ys1;
+        }
+        float* ax = aux + (size_t)n * kAux;
+        ax[0] = w; ax[1] = ys0; ax[2] = ys1; ax[3] = y1; ax[4] = e0; ax[5] = e1;
+        if (prev) {
+            const float b1 = y1 * prev[(size_t)n * prev_stride];
+            y0 = 1.f - b1; y1 = b1;
+        }
+        wnext[2 * n] = y0;
+        wnext[2 * n + 1] = y1;
+    }
+}
+
+__global__ void __launch_bounds__(256) reweigh_bwd_kernel(
+    const float* __restrict__ d_wnext, const float* __restrict__ da, const float* __restrict__ db,
+    const float* __restrict__ sr, const float* __restrict__ sd, MlpParams P,
+    const float* __restrict__ prev, int prev_stride, const float* __restrict__ h,
+    const float* __restrict__ g, const float* __restrict__ aux, MlpGrads G, float* __restrict__ dsr,
+    float* __restrict__ dsd, float* __restrict__ d_wblend, float* __restrict__ d_prev, float temp, int C) {
+    __shared__ float p_lds[kMaxC];
+    __shared__ float dg_lds[kMaxC];
+    __shared__ float dz_lds[kMaxC];
+    __shared__ float ds_lds[kMaxC];
+    __shared__ float dh_lds[kMaxHid];
+    __shared__ float red[4];
+    __shared__ float ds_sh;
+    const int n = blockIdx.x;
+    if (d_wblend) {        // w0*rgb + w1*(rgb+depth): d w0 = <g,rgb> ; d w1 = <g,rgb> + <g,depth>
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            s0 += da[(size_t)n * C + c];
+            s1 += db[(size_t)n * C + c];
+        }
+        const float t0 = block_reduce_sum_256<float>(s0, red);
+        const float t1 = block_reduce_sum_256<float>(s1, red);
+        if (threadIdx.x == 0) { d_wblend[2 * n] = t0; d_wblend[2 * n + 1] = t0 + t1; }
+    }
+    if (!d_wnext) return;
+    const int C2 = 2 * C, Hd = C2 / 16;
+    if (threadIdx.x == 0) {
+        const float* ax = aux + (size_t)n * kAux;
+        const float w = ax[0], ys0 = ax[1], ys1 = ax[2], y1 = ax[3];
+        float dy0 = d_wnext[2 * n], dy1 = d_wnext[2 * n + 1];
+        if (prev) {
+            const float db1 = dy1 - dy0;                 // b0 = 1 - b1
+            if (d_prev) d_prev[n] = db1 * y1;
+            dy1 = db1 * prev[(size_t)n * prev_stride];
+            dy0 = 0.f;
+        }
+        const float dot = ys0 * dy0 + ys1 * dy1;
+        const float dz0 = ys0 * (dy0 - dot), dz1 = ys1 * (dy1 - dot);
+        ds_sh = (dz0 - dz1) / temp * w * (1.f - w);
+    }
+    for (int c = threadIdx.x; c < C2; c += blockDim.x)
+        p_lds[c] = c < C ? sr[(size_t)n * C + c] : sd[(size_t)n * C + (c - C)];
+    __syncthreads();
+    const float dsn = ds_sh / (float)C2;
+    for (int c = threadIdx.x; c < C2; c += blockDim.x) dg_lds[c] = dsn * p_lds[c];
+    __syncthreads();
+    const float* gn = g + (size_t)n * C2;
+    se_mlp_bwd(dg_lds, p_lds, h + (size_t)n * Hd, gn, P.p[0], P.p[2], G.p[0], G.p[1], G.p[2], G.p[3],
+               dz_lds, dh_lds, ds_lds, C2, Hd);
+    for (int c = threadIdx.x; c < C2; c += blockDim.x) {
+        const float v = ds_lds[c] + dsn * gn[c];
+        if (c < C) dsr[(size_t)n * C + c] = v;
+        else dsd[(size_t)n * C + (c - C)] = v;
+    }
+}
+
 }  // namespace dynmm
 
 using namespace dynmm;
@@ -316,6 +468,62 @@ extern "C" int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, c
     DYNMM_HIP_TRY(hipMemsetAsync(d_fc, 0, sizeof(float) * kBranches * J, st));
     hipLaunchKernelGGL(gate_head_bwd_kernel, dim3(1), dim3(256), 0, st, d_weight, d_wcum, d_loss,
                        pooled, fc, soft, flop_table, d_pooled, d_fc, N, J, temp);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_reweigh_fwd(const float* sr, const float* sd, const float* const* params,
+                                 const float* wblend, int blend_mode, const float* prev,
+                                 int prev_stride, const float* noise, unsigned long long seed,
+                                 unsigned long long offset, float temp, int hard, float* a, float* b,
+                                 float* wnext, float* h, float* g, float* aux, int N, int C,
+                                 void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+    if (N <= 0 || C <= 0 || (!a && !wnext) || (a && !b)) return DYNMM_EINVAL;
+    if (blend_mode < 0 || blend_mode > 2 || (a && blend_mode == 2 && !wblend)) return DYNMM_EINVAL;
+    MlpParams P{};
+    if (wnext) {
+        if (!sr || !sd || !params || !h || !g || !aux || !(temp > 0.f)) return DYNMM_EINVAL;
+        if ((2 * C) % 16 != 0 || 2 * C > kMaxC || (2 * C) / 16 > kMaxHid) return DYNMM_EUNSUPPORTED;
+        for (int i = 0; i < 4; ++i) {
+            if (!params[i]) return DYNMM_EINVAL;
+            P.p[i] = params[i];
+        }
+    }
+    hipLaunchKernelGGL(reweigh_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, sr, sd, P, wblend,
+                       blend_mode, prev, prev_stride, noise, seed, offset, temp, hard, a, b, wnext, h, g,
+                       aux, C);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_reweigh_bwd(const float* d_wnext, const float* da, const float* db,
+                                 const float* sr, const float* sd, const float* const* params,
+                                 const float* prev, int prev_stride, const float* h, const float* g,
+                                 const float* aux, float* const* dparams, float* dsr, float* dsd,
+                                 float* d_wblend, float* d_prev, float temp, int N, int C,
+                                 void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+    if (N <= 0 || C <= 0 || (!d_wnext && !d_wblend)) return DYNMM_EINVAL;
+    if (d_wblend && (!da || !db)) return DYNMM_EINVAL;
+    MlpParams P{};
+    MlpGrads G{};
+    hipStream_t st = (hipStream_t)stream;
+    if (d_wnext) {
+        if (!sr || !sd || !params || !dparams || !h || !g || !aux || !dsr || !dsd || !(temp > 0.f))
+            return DYNMM_EINVAL;
+        if ((2 * C) % 16 != 0 || 2 * C > kMaxC || (2 * C) / 16 > kMaxHid) return DYNMM_EUNSUPPORTED;
+        const int C2 = 2 * C, Hd = C2 / 16;
+        const size_t sizes[4] = {(size_t)Hd * C2, (size_t)Hd, (size_t)C2 * Hd, (size_t)C2};
+        for (int i = 0; i < 4; ++i) {
+            if (!params[i] || !dparams[i]) return DYNMM_EINVAL;
+            P.p[i] = params[i];
+            G.p[i] = dparams[i];
+            DYNMM_HIP_TRY(hipMemsetAsync(dparams[i], 0, sizeof(float) * sizes[i], st));
+        }
+    }
+    hipLaunchKernelGGL(reweigh_bwd_kernel, dim3(N), dim3(256), 0, st, d_wnext, da, db, sr, sd, P, prev,
+                       prev_stride, h, g, aux, G, dsr, dsd, d_wblend, d_prev, temp, C);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

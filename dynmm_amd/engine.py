@@ -84,7 +84,11 @@ class TrainStep:
 
     def _body(self, rgb, depth, targets):
         self.reducer.zero()
-        outs, lf = self.model(rgb, depth)
+        res = self.model(rgb, depth)
+        if len(res) == 2 and isinstance(res[0], (tuple, list)):
+            outs, lf = res                                   # SkipGateESANet: ((out, out8, out16, out32), flop loss)
+        else:
+            outs, lf = res, torch.zeros((), device=rgb.device)   # SkipESANet: the four outputs only
         losses = [ops.cross_entropy_2d(o, t, self.cw) for o, t in zip(outs, targets)]
         seg = losses[0]
         for l in losses[1:]:

@@ -62,6 +62,9 @@ SIGNATURES = {
     'dynmm_axpby_fwd': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
     'dynmm_axpby_bwd_reduce': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
     'dynmm_axpby_bwd_apply': (c_i, [c_f] * 5 + [c_fl, c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_reweigh_fwd': (c_i, [c_f, c_f, _PP, c_f, c_i, c_f, c_i, c_f, C.c_ulonglong, C.c_ulonglong, c_fl, c_i]
+                          + [c_f] * 6 + [c_i, c_i, c_f]),
+    'dynmm_reweigh_bwd': (c_i, [c_f] * 5 + [_PP, c_f, c_i, c_f, c_f, c_f, _PP, c_f, c_f, c_f, c_f, c_fl, c_i, c_i, c_f]),
     'dynmm_gate_head_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_fl, c_i, c_i, c_f]),
     'dynmm_gate_head_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_fl, c_f]),
     'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_f]),

@@ -58,6 +58,27 @@ class GlobalGate(nn.Module):
         return weight
 
 
+def encoder_stage_pair(model, j, r_in, d_in):
+    """Stage j of both encoders, the depth one on a second HIP stream so the kernels' ramp-up /
+    store-burst / tail phases of the two independent chains overlap.  Autograd replays each backward
+    node on its forward stream, so the backward gets the same concurrency."""
+    if getattr(model, '_side', None) is None:
+        model._side = torch.cuda.Stream()
+    side = model._side
+    main = torch.cuda.current_stream()
+    capturing = torch.cuda.is_current_stream_capturing()
+    side.wait_stream(main)
+    if not capturing:
+        d_in.record_stream(side)         # allocated on `main`, read on the side stream
+    with torch.cuda.stream(side):
+        d = getattr(model.encoder_depth, f'forward_layer{j}')(d_in)
+    r = getattr(model.encoder_rgb, f'forward_layer{j}')(r_in)
+    main.wait_stream(side)
+    if not capturing:
+        d.record_stream(main)            # allocated on the side stream, read by the fusion on `main`
+    return r, d
+
+
 R34_FLOP = [0, 3.27, 7.27, 13.15, 16.02]
 R34_DEPTH_ENC_FLOP = [0.2506752, 3.1113216, 6.9470208, 12.66432, 15.538944]
 R34_TOTAL_FLOP = [22.37101509, 25.23166149, 29.06736069, 34.78465989, 37.65928389]
@@ -203,19 +224,7 @@ class SkipGateESANet(nn.Module):
         skips = []
         for j in (1, 2, 3, 4):
             if self.dual_stream and not compacted:
-                if self._side is None:
-                    self._side = torch.cuda.Stream()
-                main = torch.cuda.current_stream()
-                capturing = torch.cuda.is_current_stream_capturing()
-                self._side.wait_stream(main)
-                if not capturing:
-                    d.record_stream(self._side)      # allocated on `main`, read on the side stream
-                with torch.cuda.stream(self._side):
-                    d = getattr(ed, f'forward_layer{j}')(d)
-                r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
-                main.wait_stream(self._side)
-                if not capturing:
-                    d.record_stream(main)            # allocated on the side stream, read by the fusion on `main`
+                r, d = encoder_stage_pair(self, j, r if j == 1 else fuse, d)
                 fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
                 if j < 4:
                     sk = getattr(self, f'skip_layer{j}')

@@ -550,7 +550,7 @@ def upsample2x_dw3x3(x, weight, bias, skip=None):
 # SE fusion + gated blend
 # ------------------------------------------------------------------------------------------------
 def _ptr_array(tensors):
-    arr = (C.c_void_p * 8)(*[t.data_ptr() for t in tensors])
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr
 
 
@@ -634,6 +634,117 @@ def se_fuse_blend(rgb, depth, se_params=None, wcum=None, col=0):
     use_se = se_params is not None
     params = tuple(se_params) if use_se else ()
     return _SEFuseBlend.apply(rgb, depth, wcum, col, use_se, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# SkipESANet: per-stage Gumbel gate + 2-way blend
+# ------------------------------------------------------------------------------------------------
+_PHILOX_OFFSET = [0]          # advanced once per gate evaluation that draws its own noise
+
+
+def manual_seed(seed):
+    """Seed of the Philox stream the Gumbel gates draw from (device-side RNG; rgb_depth_fusion.py:50,56
+    draws from torch's global generator — parity with the reference is distributional)."""
+    global _PHILOX_SEED
+    _PHILOX_SEED = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _PHILOX_OFFSET[0] = 0
+
+
+_PHILOX_SEED = 0x5EEDD1CE
+
+
+class _ReweighFuse(Function):
+    """out   = rgb | rgb+depth | w0*rgb + w1*(rgb+depth)          (blend_mode 0 | 1 | 2, w = wblend[N,2])
+    wnext = SqueezeAndExciteReweigh(rgb, depth; temp, hard, prev)  (only when `gate`), [N,2]
+    aux   = [N,6] saved gate internals {w, ysoft0, ysoft1, y1, E0, E1} (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, wblend, prev, noise, blend_mode, gate, temp, hard, *params):
+        lib = _lib()
+        st = _stream()
+        rgb, depth = _chk(rgb, 'rgb'), _chk(depth, 'depth')
+        _same_shape(rgb, depth, 'rgb/depth fusion')
+        N, Cc, H, W = rgb.shape
+        HW = H * W
+        f32 = dict(device=rgb.device, dtype=torch.float32)
+        wblend, prev, noise = _chk(wblend, 'wblend'), _chk(prev, 'prev'), _chk(noise, 'noise')
+        if blend_mode == 2 and (wblend is None or wblend.numel() != 2 * N):
+            raise L.DynmmHipError('blend_mode 2 needs wblend[N,2]')
+        sr = sd = h = gg = aux = wnext = parr = None
+        seed = offset = 0
+        if gate:
+            params = [_chk(p_, 'gate param') for p_ in params]
+            parr = _ptr_array(params)
+            sr, sd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            L.check(lib.dynmm_gap2_fwd(_p(rgb), _p(depth), _p(sr), _p(sd), N * Cc, HW, st), 'gap2')
+            h, gg = torch.empty((N, 2 * Cc // 16), **f32), torch.empty((N, 2 * Cc), **f32)
+            aux, wnext = torch.empty((N, 6), **f32), torch.empty((N, 2), **f32)
+            if noise is None:
+                seed, offset = _PHILOX_SEED, _PHILOX_OFFSET[0]
+                _PHILOX_OFFSET[0] += 1
+        a, b = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_reweigh_fwd(_p(sr), _p(sd), parr, _p(wblend), int(blend_mode), _p(prev), 1, _p(noise),
+                                      seed, offset, float(temp), int(bool(hard)), _p(a), _p(b), _p(wnext),
+                                      _p(h), _p(gg), _p(aux), N, Cc, st), 'reweigh_fwd')
+        out = torch.empty_like(rgb)
+        L.check(lib.dynmm_axpby_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(out), N * Cc, HW, st), 'axpby_fwd')
+        ctx.cfg = (int(blend_mode), bool(gate), float(temp), len(params))
+        ctx.save_for_backward(rgb, depth, wblend, prev, a, b, sr, sd, h, gg, aux, *params)
+        if gate:
+            ctx.mark_non_differentiable(aux)
+        return out, wnext, aux
+
+    @staticmethod
+    def backward(ctx, g, d_wnext, _d_aux):
+        lib = _lib()
+        st = _stream()
+        rgb, depth, wblend, prev, a, b, sr, sd, h, gg, aux = ctx.saved_tensors[:11]
+        params = list(ctx.saved_tensors[11:])
+        blend_mode, gate, temp, n_params = ctx.cfg
+        N, Cc, H, W = rgb.shape
+        HW = H * W
+        f32 = dict(device=rgb.device, dtype=torch.float32)
+        if g is None:
+            g = torch.zeros_like(rgb)
+        g = _chk(g, 'grad')
+        need_wb = blend_mode == 2 and ctx.needs_input_grad[2]
+        da = db = d_wblend = None
+        if need_wb:
+            da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            L.check(lib.dynmm_axpby_bwd_reduce(_p(g), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, HW, st),
+                    'axpby_bwd_reduce')
+            d_wblend = torch.empty((N, 2), **f32)
+        dparams = [None] * n_params
+        dsr = dsd = d_prev = parr = dparr = None
+        gate_bwd = gate and d_wnext is not None
+        if gate_bwd:
+            d_wnext = _chk(d_wnext, 'd_wnext')
+            dparams = [torch.empty_like(p_) for p_ in params]
+            parr, dparr = _ptr_array(params), _ptr_array(dparams)
+            dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            if prev is not None and ctx.needs_input_grad[3]:
+                d_prev = torch.empty((N,), **f32)
+        if need_wb or gate_bwd:
+            L.check(lib.dynmm_reweigh_bwd(_p(d_wnext) if gate_bwd else None, _p(da), _p(db), _p(sr), _p(sd), parr,
+                                          _p(prev), 1, _p(h), _p(gg), _p(aux), dparr, _p(dsr), _p(dsd),
+                                          _p(d_wblend), _p(d_prev), temp, N, Cc, st), 'reweigh_bwd')
+        drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
+        L.check(lib.dynmm_axpby_bwd_apply(_p(g), _p(a), _p(b), _p(dsr), _p(dsd), 1.0 / HW,
+                                          _p(drgb), _p(ddepth), N * Cc, HW, st), 'axpby_bwd_apply')
+        return (drgb, ddepth, d_wblend, d_prev, None, None, None, None, None, *dparams)
+
+
+def reweigh_fuse(rgb, depth, wblend=None, blend_mode=1, gate_params=None, temp=1.0, hard=False, prev=None,
+                 noise=None):
+    """One SkipESANet fusion point (model_skip_mod.py:235-311): the stage blend and, when `gate_params`
+    (W1,b1,W2,b2 of SqueezeAndExcitationWeight.fc) is given, the gate evaluated on the same two maps.
+    Returns (fused, wnext[N,2] | None, aux | None).  `noise` = Exp(1) samples [N,2] (tests); default: the
+    kernel draws them with Philox (ops.manual_seed)."""
+    gate = gate_params is not None
+    params = tuple(gate_params) if gate else ()
+    if prev is not None and not prev.is_contiguous():
+        prev = prev.contiguous()
+    return _ReweighFuse.apply(rgb, depth, wblend, prev, noise, blend_mode, gate, temp, hard, *params)
 
 
 # ------------------------------------------------------------------------------------------------

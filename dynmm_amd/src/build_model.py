@@ -1,12 +1,14 @@
 """build_model(args, n_classes) -> (model, device): the factory train.py / eval.py call
 (FusionDynMM/src/build_model.py:18-218), restricted to what the HIP hot path implements:
-`--dynamic --global-gate` (SkipGateESANet).  Other model families raise NotImplementedError."""
+`--dynamic --global-gate` (SkipGateESANet) and `--dynamic` (SkipESANet, per-stage Gumbel gates).
+Other model families raise NotImplementedError."""
 import warnings
 
 import torch
 from torch import nn
 
 from ..nn.net import SkipGateESANet
+from ..nn.net_skip import SkipESANet
 
 
 def _decoder_shape(args):
@@ -27,14 +29,14 @@ def _decoder_shape(args):
 def build_model(args, n_classes):
     pretrained = bool(args.pretrained_on_imagenet) and not args.last_ckpt and args.pretrained_scenenet == ''
     channels_decoder, nr_decoder_blocks = _decoder_shape(args)
-    if not (args.dynamic and args.global_gate):
-        raise NotImplementedError('the HIP path implements --dynamic --global-gate (SkipGateESANet); '
-                                  'ESANet == the same model with .baseline = True')
+    if not args.dynamic:
+        raise NotImplementedError('the HIP path implements --dynamic [--global-gate] (SkipGateESANet / '
+                                  'SkipESANet); ESANet == SkipGateESANet with .baseline = True')
     block_rule = [int(ch) for ch in args.block_rule]
     assert len(block_rule) == 4
     if args.encoder_depth in (None, 'None'):
         args.encoder_depth = args.encoder
-    model = SkipGateESANet(
+    model = (SkipGateESANet if args.global_gate else SkipESANet)(
         height=args.height, width=args.width, num_classes=n_classes,
         pretrained_on_imagenet=False, pretrained_dir=args.pretrained_dir,
         encoder_rgb=args.encoder, encoder_depth=args.encoder_depth, encoder_block=args.encoder_block,

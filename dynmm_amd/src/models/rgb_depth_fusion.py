@@ -1,2 +1,2 @@
 """Counterpart of FusionDynMM/src/models/rgb_depth_fusion.py."""
-from ...nn.fusion import SqueezeAndExciteFusionAdd  # noqa: F401
+from ...nn.fusion import SqueezeAndExciteFusionAdd, SqueezeAndExciteReweigh  # noqa: F401

@@ -189,6 +189,30 @@ int dynmm_axpby_bwd_apply(const float* g, const float* a, const float* b,
                           const float* ca, const float* cb, float cscale, float* dxr, float* dxd,
                           int NC, int HW, void* stream);
 
+/* ---- SkipESANet per-stage gate + 2-way blend (rgb_depth_fusion.py:29-65, model_utils.py:54-70,
+ *      model_skip_mod.py:235-311) ----
+ * Gate (evaluated when wnext != NULL) from the pooled maps sr,sd [N,C] of the stage's rgb/depth features:
+ *   p = [sr; sd];  g = sigmoid(W2 relu(W1 p + b1) + b2);  s = sum_c g[c] p[c] / 2C  (== mean(x*g));
+ *   w = sigmoid(s);  y = gumbel_softmax([w, 1-w]/temp, tau=1, hard)  with Gumbel noise G = -log E:
+ *   E[n,2] ~ Exp(1) taken from `noise` when given, else drawn by Philox4x32-10 keyed (seed; n, offset);
+ *   prev (stride prev_stride, optional): b1 = y1*prev, b0 = 1-b1.   wnext[N,2] = (b0,b1) or y.
+ *   params: 4 pointers {W1[2C/16,2C], b1, W2[2C,2C/16], b2}.  Saves h[N,2C/16], g[N,2C],
+ *   aux[N,6] = {w, ysoft0, ysoft1, y1, E0, E1}.
+ * Blend coefficients (written when a != NULL) for out = a*rgb + b*depth:
+ *   blend_mode 0: rgb only (1,0);  1: rgb+depth (1,1);  2: w0*rgb + w1*(rgb+depth) -> (w0+w1, w1)
+ *   with wblend[N,2].  The backward returns d_wblend from da,db of dynmm_axpby_bwd_reduce, the pooled
+ *   gradients dsr,dsd (to be fed to dynmm_axpby_bwd_apply), the 4 parameter gradients and d_prev[N]. */
+int dynmm_reweigh_fwd(const float* sr, const float* sd, const float* const* params,
+                      const float* wblend, int blend_mode, const float* prev, int prev_stride,
+                      const float* noise, unsigned long long seed, unsigned long long offset,
+                      float temp, int hard, float* a, float* b, float* wnext, float* h, float* g,
+                      float* aux, int N, int C, void* stream);
+int dynmm_reweigh_bwd(const float* d_wnext, const float* da, const float* db, const float* sr,
+                      const float* sd, const float* const* params, const float* prev, int prev_stride,
+                      const float* h, const float* g, const float* aux, float* const* dparams,
+                      float* dsr, float* dsd, float* d_wblend, float* d_prev, float temp,
+                      int N, int C, void* stream);
+
 /* ---- global gate head (…globalgate.py:20-30, 263-272, 314-315, 391-394) ----
  * mode 0: logits = fc[5,J] . pooled[n,J];  weight = DiffSoftmax(logits, temp, hard)
  * mode 1: weight given (baseline / ini_stage one-hots), pooled/fc ignored

@@ -230,6 +230,74 @@ def forward(sd, rgb, depth, cfg: Config, training=False, test=False, return_weig
 
 
 # --------------------------------------------------------------------------------------------
+# SkipESANet: per-stage Gumbel gates
+# --------------------------------------------------------------------------------------------
+def gumbel_softmax(logits, exp_noise, tau=1.0, hard=False):
+    """torch.nn.functional.gumbel_softmax(dim=-1) with the Exp(1) draw made explicit:
+    gumbels = -log(E), E = empty_like(logits).exponential_()  (torch/nn/functional.py, v2.x)."""
+    y_soft = ((logits - exp_noise.log()) / tau).softmax(-1)
+    if not hard:
+        return y_soft
+    idx = y_soft.max(-1, keepdim=True)[1]
+    y_hard = torch.zeros_like(logits).scatter_(-1, idx, 1.0)
+    return y_hard - y_soft.detach() + y_soft
+
+
+def reweigh_gate(sd, p, rgb, depth, temp, exp_noise, hard=False, prev_weight=None, test=False):
+    """SqueezeAndExciteReweigh.forward (src/models/rgb_depth_fusion.py:36-65) with
+    SqueezeAndExcitationWeight (src/models/model_utils.py:66-70); `exp_noise` [N,2] replaces the
+    global-generator draw inside gumbel_softmax.  Returns [N,2]."""
+    x = torch.cat([rgb, depth], dim=1)
+    g = F.adaptive_avg_pool2d(x, 1)
+    g = F.relu(_conv(sd, p + '.se.fc.0', g))
+    g = torch.sigmoid(_conv(sd, p + '.se.fc.2', g))
+    w = torch.sigmoid((x * g.expand_as(x)).mean(dim=(1, 2, 3)))
+    w = torch.stack([w, 1 - w], dim=1)
+    w_norm = gumbel_softmax(w / temp, exp_noise, hard=True if test else hard)
+    if prev_weight is not None:
+        b1 = w_norm[:, 1] * prev_weight
+        w_norm = torch.stack([1 - b1, b1], dim=1)
+    return w_norm
+
+
+def forward_skip(sd, rgb, depth, cfg: Config, exp_noise, training=False, test=False, hard_gate=False,
+                 ini_stage=False, temp=1.0, block_rule=(2, 2, 2, 2), detail=None):
+    """SkipESANet.forward (src/models/model_skip_mod.py:235-311).  `exp_noise`: 4 tensors [N,2] of
+    Exp(1) samples, one per gate, in call order.  Note the reference never uses its se_layer* here:
+    the modality fusion is a plain sum.  Returns the decoder output (4-tuple in training mode)."""
+    r = encoder_stem(sd, 'encoder_rgb', rgb, training)
+    d = encoder_stem(sd, 'encoder_depth', depth, training)
+    fuse = r + d
+    weights = [reweigh_gate(sd, 'gate_layer0', r, d, temp, exp_noise[0], hard_gate, None, test)]
+    r = F.max_pool2d(fuse, 3, 2, 1)
+    d = F.max_pool2d(d, 3, 2, 1)
+    prev = None
+    skips = []
+    for j in (1, 2, 3, 4):
+        r = encoder_stage(sd, 'encoder_rgb', fuse if j > 1 else r, training, cfg, j)
+        d = encoder_stage(sd, 'encoder_depth', d, training, cfg, j)
+        b0, b1 = r, r + d
+        rule = block_rule[j - 1]
+        if rule == 0:
+            fuse = b0
+        elif rule == 1:
+            fuse = b1
+        else:
+            w = weights[j - 1].view(-1, 2, 1, 1)
+            fuse = w[:, 0:1] * b0 + w[:, 1:2] * b1
+            prev = None if ini_stage else w[:, 1, 0, 0]
+        if j < 4:
+            weights.append(reweigh_gate(sd, f'gate_layer{j}', r, d, temp, exp_noise[j], hard_gate, prev, test))
+            skips.append(_skip(sd, f'skip_layer{j}', fuse, training))
+        if detail is not None:
+            detail[f'fuse{j}'] = fuse
+    if detail is not None:
+        detail['weights'] = weights
+    ctx = pyramid_pooling(sd, 'context_module', fuse, training)
+    return decoder(sd, 'decoder', [ctx, skips[2], skips[1], skips[0]], training, cfg)
+
+
+# --------------------------------------------------------------------------------------------
 # callers of the path (SURVEY.md §8a-19): loss, eval post-processing, mIoU, schedules
 # --------------------------------------------------------------------------------------------
 def cross_entropy_2d(logits_scales, target_scales, class_weight):

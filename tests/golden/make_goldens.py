@@ -15,6 +15,9 @@ What is stored (data only: inputs are regenerated from dynmm_amd.synth on both s
   nyu8_P_se.npz            BASELINE config[0] restated on 8 synthetic NYUv2-like pairs, 480x640,
                            eval --baseline: strided logits, argmax histogram, CM and mIoU.
   ops.npz                  DiffSoftmax cases, Upsample fixed init, CE loss, temperature schedule.
+  skip_P_96x128.npz        SkipESANet (per-stage Gumbel gates, model_skip_mod.py): per mode the Exp(1) draws
+                           injected into F.gumbel_softmax (Tensor.exponential_ patched process-locally),
+                           the four gate weights, strided logits and, for train modes, gradient norms.
 """
 import os
 import sys
@@ -32,6 +35,7 @@ torch.Tensor.cuda = lambda self, *a, **k: self            # no GPU here
 warnings.filterwarnings('ignore')
 
 from src.models.model_skip_mod_globalgate import SkipGateESANet, DiffSoftmax  # noqa: E402
+from src.models.model_skip_mod import SkipESANet                               # noqa: E402
 from src.models.model import Upsample                                          # noqa: E402
 from src import utils as ref_utils                                             # noqa: E402
 
@@ -246,6 +250,87 @@ def train_steps_fixture():
     np.savez_compressed(os.path.join(HERE, 'train_steps_P_se.npz'), **blob)
 
 
+SKIP_MODES = {
+    # name: (training, test, hard_gate, temp, block_rule)
+    'eval_test': (False, True, False, 1.0, [2, 2, 2, 2]),
+    'eval_soft': (False, False, False, 1.0, [2, 2, 2, 2]),
+    'eval_mixed_rule': (False, False, False, 0.7, [2, 1, 0, 2]),
+    'train_soft': (True, False, False, 0.7, [2, 2, 2, 2]),
+    'train_hard': (True, False, True, 0.5, [2, 2, 2, 2]),
+}
+
+
+def skip_noise(n, mode):
+    r = np.random.Generator(np.random.PCG64([4242, n, len(mode)]))
+    return [torch.from_numpy(r.exponential(size=(n, 2)).astype(np.float32)) for _ in range(4)]
+
+
+def skip_fixture():
+    """SkipESANet (model_skip_mod.py:20-311) with the Gumbel draws pinned: F.gumbel_softmax calls
+    `empty_like(logits).exponential_()`; that method is replaced for the duration of the forward by one
+    that hands out the recorded Exp(1) samples in call order."""
+    h, w, n = 96, 128, 3
+    blob = {'meta': np.array([h, w, n, STRIDE])}
+    real_exp = torch.Tensor.exponential_
+    for mode, (training, test, hard, temp, rule) in SKIP_MODES.items():
+        print(f'  skip {mode}', flush=True)
+        m = SkipESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34', encoder_depth='resnet34',
+                       encoder_block='NonBottleneck1D', channels_decoder=[128, 128, 128],
+                       nr_decoder_blocks=[3, 3, 3], pretrained_on_imagenet=False,
+                       fuse_depth_in_rgb_encoder='SE-add', upsampling='learned-3x3-zeropad', temp=temp,
+                       block_rule=rule)
+        synth.fill_state_dict(m.state_dict(), seed=0)
+        m.train() if training else m.eval()
+        m.hard_gate = hard
+        rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+        noise = skip_noise(n, mode)
+        calls = [0]
+
+        def fake_exponential(self, *a, **k):
+            self.copy_(noise[calls[0]])
+            calls[0] += 1
+            return self
+        torch.Tensor.exponential_ = fake_exponential
+        try:
+            m.start_weight()
+            if training:
+                outs = m(rgb, depth, test=test)
+                loss = train_loss(outs, torch.zeros(()))
+                loss.backward()
+            else:
+                with torch.no_grad():
+                    outs = m(rgb, depth, test=test)
+        finally:
+            torch.Tensor.exponential_ = real_exp
+        assert calls[0] == 4
+        out = outs[0] if training else outs
+        for k, v in summarize_logits(out).items():
+            blob[f'{mode}/{k}'] = v
+        for j in range(4):
+            blob[f'{mode}/noise{j}'] = noise[j].numpy()
+            blob[f'{mode}/weight{j}'] = m.weight_list[j].detach().numpy().copy()
+        blob[f'{mode}/cfg'] = np.array([int(training), int(test), int(hard)] + list(rule), np.int64)
+        blob[f'{mode}/temp'] = np.float32(temp)
+        if training:
+            blob[f'{mode}/loss'] = np.float32(loss.item())
+            for i, o in enumerate(outs[1:]):
+                blob[f'{mode}/side{i}'] = o.detach().numpy()
+            names, norms = [], []
+            for name, prm in m.named_parameters():
+                names.append(name)
+                norms.append(0.0 if prm.grad is None else prm.grad.norm().item())
+            blob[f'{mode}/grad_names'] = np.array(names)
+            blob[f'{mode}/grad_norms'] = np.array(norms, np.float64)
+            for name in ('gate_layer0.se.fc.0.weight', 'gate_layer2.se.fc.2.bias', 'gate_layer3.se.fc.0.bias',
+                         'encoder_depth.conv1.weight', 'decoder.conv_out.bias'):
+                blob[f'{mode}/grad:' + name] = dict(m.named_parameters())[name].grad.numpy()
+    sd = m.state_dict()
+    blob['keys'] = np.array(list(sd.keys()))
+    blob['shapes'] = np.array([','.join(map(str, v.shape)) for v in sd.values()])
+    blob['dtypes'] = np.array([str(v.dtype) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, 'skip_P_96x128.npz'), **blob)
+
+
 def contract_fixture():
     """state_dict keys / shapes / dtypes of the reference model (the strict-load contract, eval.py:61)."""
     blob = {}
@@ -261,6 +346,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'contract':
         contract_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'skip':
+        skip_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'train_steps':
         train_steps_fixture()
         sys.exit(0)
@@ -273,4 +361,5 @@ if __name__ == '__main__':
     model_fixture('S_add', 96, 128, 2, ['eval_baseline'])
     model_fixture('P_se', 160, 192, 3, ['eval_hard', 'train_soft'])
     nyu8_fixture()
+    skip_fixture()
     print('done')

@@ -83,3 +83,12 @@ def test_reference_import_surface():
     args.block_rule = '111'
     with pytest.raises(AssertionError):
         build_model(args, n_classes=40)
+    # --dynamic without --global-gate selects the per-stage Gumbel variant (src/build_model.py:52-91)
+    from dynmm_amd.src.models.model_skip_mod import SkipESANet  # noqa: F401
+    from dynmm_amd.src.models.rgb_depth_fusion import SqueezeAndExciteReweigh  # noqa: F401
+    args.block_rule, args.global_gate = '2222', False
+    model, _ = build_model(args, n_classes=40)
+    assert type(model).__name__ == 'SkipESANet' and model.block_rule == [2, 2, 2, 2]
+    args.dynamic = False
+    with pytest.raises(NotImplementedError):
+        build_model(args, n_classes=40)

@@ -96,3 +96,16 @@ def test_train_driver_smoke(tmp_path):
                              '--results_dir', str(tmp_path)])
     assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
     assert 'mIoU_test' in logs[0]
+
+
+@pytest.mark.gpu
+def test_train_driver_smoke_per_stage_gates(tmp_path):
+    """--dynamic without --global-gate: SkipESANet (per-stage Gumbel gates) through the same driver."""
+    from dynmm_amd import train
+    logs = train.train_main(['--dynamic', '--block-rule', '2222', '--encoder', 'resnet34', '--encoder_block',
+                             'NonBottleneck1D', '--decoder_channels_mode', 'constant', '--no_imagenet_pretraining',
+                             '--dataset', 'synthetic', '--height', '96', '--width', '128', '--batch_size', '4',
+                             '--synthetic_samples', '8', '--epochs', '2', '--epoch-hard', '1', '--eval-every', '1',
+                             '--results_dir', str(tmp_path)])
+    assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
+    assert 'mIoU_test' in logs[0]
