@@ -52,11 +52,23 @@ __device__ __forceinline__ float4 ldg_f32x4(const float* sbase, unsigned voff_by
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
 }
 
+// Per-workgroup phase timestamps for kernel-structure experiments (scratch/trace/): compiled in only
+// with -DDYNMM_TRACE, never in the shipped library.
+#ifdef DYNMM_TRACE
+__device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: start, prologue, loop, epilogue, HW_ID, XCC_ID
+#define DYNMM_TRACE_MARK(slot)                                                                  \
+    do {                                                                                        \
+        if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 6 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define DYNMM_TRACE_MARK(slot) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
 template <int TCO, int TPIX, int WCO, int WPIX, bool DGRAD, bool GENERIC>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
+__global__ void __launch_bounds__(256, (TCO * TPIX <= 8192 ? 6 : 2)) conv_igemm_kernel(const IgemmArgs a) {
     constexpr int BK = 16;
     constexpr int MCO = WCO / 32, MPIX = WPIX / 32;
     constexpr int WAVES_PIX = TPIX / WPIX;
@@ -72,6 +84,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wave_co = wave / WAVES_PIX, wave_pix = wave % WAVES_PIX;
+    DYNMM_TRACE_MARK(0);
 
     // XCD-aware tile order: consecutive logical ids (same XCD) walk the co-tiles of one pixel tile
     // first, so the gathered input tile is re-used out of that XCD's L2.
@@ -205,6 +218,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
         load_tile();
         store_tile(0);
         __syncthreads();
+        DYNMM_TRACE_MARK(1);
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nk) load_tile();        // global loads fly under the MFMAs below
@@ -266,46 +280,165 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const IgemmArgs a) {
     }
 
     // ---- epilogue: scale/shift (bias or folded BN), residual, activation, ReLU-mask; NCHW store ----
-    const int co_split = a.c_out_split;
-    const int co_rest = a.Co - co_split;
+    // Written so that NO memory wait sits between two stores: per-channel scale/shift are staged in LDS
+    // (the operand tiles are dead), residual/mask values of a whole 32x32 accumulator tile are loaded
+    // as one batch, then its 16 stores issue back to back.  (The first version interleaved
+    // load -> wait -> store per element; on gfx9 vmcnt also counts stores, so every element paid a
+    // full store round trip: 22 us per workgroup, measured with -DDYNMM_TRACE, ~20 % of the kernel.)
+    DYNMM_TRACE_MARK(2);
+    float* const sc_lds = &As[0][0][0];          // [TCO] scale, [TCO] shift  (BK*TCO >= 2*TCO)
+    float* const sh_lds = sc_lds + TCO;
+    {
+        const float* __restrict__ scale = a.scale;
+        const float* __restrict__ shift = a.shift;
+        for (int i = t; i < TCO; i += 256) {
+            const int co = co0 + i;
+            const bool ok = co < a.Co;
+            sc_lds[i] = (scale && ok) ? scale[co] : 1.f;
+            sh_lds[i] = (shift && ok) ? shift[co] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float* __restrict__ res_p = a.residual;
+    const float* __restrict__ mask_p = a.mask;
+    float* __restrict__ y1_p = a.y;
+    float* __restrict__ y2_p = a.y2;
+    const bool has_res = res_p != nullptr, has_mask = mask_p != nullptr;
+    const unsigned co_split = (unsigned)a.c_out_split;
+    const unsigned co_rest = (unsigned)a.Co - co_split;
+    const bool single_out = co_split >= (unsigned)a.Co;
+    const int act = a.act;
+    const unsigned row_bytes = (unsigned)HoWo * 4u;          // byte stride between channels
+
+    // half of a 32x32 accumulator tile (8 values per lane) at a time: v = acc*scale + shift, then
+    // mask/residual/activation, then 8 stores.  Half tiles + scheduling barriers keep the epilogue's
+    // register footprint under the K loop's, so the kernel stays at 6 waves/SIMD.
+    // FAST: the tile lies inside [0,Co) of a single output tensor -> uniform base + 32-bit offsets,
+    // no per-element predicates.
+    auto finish = [&](float (&v)[8], const float (&rv)[8], const float (&mv)[8]) {
+        if (DGRAD) {
+            // dx = (dgrad term) * [mask > 0] + accum : ReLU backward of the producer of x and the
+            // residual-branch gradient, both fused into the store
+            if (has_mask) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
+            }
+            if (has_res) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+            }
+        } else {
+            if (has_res) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+            }
+            if (act == DYNMM_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            } else if (act == DYNMM_ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
+            }
+        }
+    };
+    auto scaled = [&](float (&v)[8], int mi, int ni, int cl0, int h) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j4 = 2 * h + q;
+            const float4 sc = *reinterpret_cast<const float4*>(&sc_lds[cl0 + 8 * j4]);
+            const float4 sh = *reinterpret_cast<const float4*>(&sh_lds[cl0 + 8 * j4]);
+            v[4 * q + 0] = acc[mi][ni][4 * j4 + 0] * sc.x + sh.x;
+            v[4 * q + 1] = acc[mi][ni][4 * j4 + 1] * sc.y + sh.y;
+            v[4 * q + 2] = acc[mi][ni][4 * j4 + 2] * sc.z + sh.z;
+            v[4 * q + 3] = acc[mi][ni][4 * j4 + 3] * sc.w + sh.w;
+        }
+    };
+
+    const bool fast_out = single_out && (co0 + TCO <= a.Co);
 #pragma unroll
     for (int ni = 0; ni < MPIX; ++ni) {
         const int m = pix0 + wave_pix * WPIX + ni * 32 + l31;
         if (m >= a.M) continue;
-        const int n = m / HoWo;
-        const int rem = m - n * HoWo;
+        const unsigned n = (unsigned)(m / HoWo);
+        const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
+            const int cl0 = wave_co * WCO + mi * 32 + 4 * khalf;          // tile-local channel of j = 0
+            if (fast_out) {
+                const unsigned off0 = ((n * (unsigned)a.Co + (unsigned)(co0 + cl0)) * (unsigned)HoWo + rem) * 4u;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int co = co0 + wave_co * WCO + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
-                if (co >= a.Co) continue;
-                float v = acc[mi][ni][j];
-                if (a.scale) v *= a.scale[co];
-                if (a.shift) v += a.shift[co];
-                size_t idx;
-                float* out;
-                if (co < co_split) {
-                    idx = ((size_t)n * co_split + co) * HoWo + rem;
-                    out = a.y;
-                } else {
-                    idx = ((size_t)n * co_rest + (co - co_split)) * HoWo + rem;
-                    out = a.y2;
+                for (int h = 0; h < 2; ++h) {
+                    float v[8], rv[8], mv[8];
+                    // element e of this half: j = 8h + e  ->  channel offset (e & 3) + 8 * (2h + (e >> 2))
+                    if (has_mask) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            mv[e] = ldg_f32(mask_p, off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes);
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            rv[e] = ldg_f32(res_p, off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes);
+                    }
+                    scaled(v, mi, ni, cl0, h);
+                    finish(v, rv, mv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
+                                                  (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (DGRAD) {
-                    // dx = (dgrad term) * [mask > 0] + accum : ReLU backward of the producer of x and
-                    // the residual-branch gradient, both fused into the store
-                    if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
-                    if (a.residual) v += a.residual[idx];
-                } else {
-                    if (a.residual) v += a.residual[idx];
-                    v = act_fwd(v, a.act);
+            } else {
+                // channel tail (Co % TCO != 0) and/or two output tensors (dgrad of a dual-input conv):
+                // rare shapes; element-at-a-time keeps the register budget of the kernel at the fast path's
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const unsigned co = (unsigned)(co0 + cl0 + (j & 3) + 8 * (j >> 2));
+                    if (co >= (unsigned)a.Co) continue;
+                    size_t idx;
+                    float* out;
+                    if (single_out || co < co_split) {
+                        idx = ((size_t)n * co_split + co) * HoWo + rem;
+                        out = y1_p;
+                    } else {
+                        idx = ((size_t)n * co_rest + (co - co_split)) * HoWo + rem;
+                        out = y2_p;
+                    }
+                    const int cl = cl0 + (j & 3) + 8 * (j >> 2);
+                    float x = acc[mi][ni][j] * sc_lds[cl] + sh_lds[cl];
+                    if (DGRAD) {
+                        if (has_mask) x = mask_p[idx] > 0.f ? x : 0.f;
+                        if (has_res) x += res_p[idx];
+                    } else {
+                        if (has_res) x += res_p[idx];
+                        x = act_fwd(x, act);
+                    }
+                    out[idx] = x;
                 }
-                out[idx] = v;
             }
         }
     }
+#ifdef DYNMM_TRACE
+    __builtin_amdgcn_s_waitcnt(0);          // stores acknowledged
+    __syncthreads();
+    DYNMM_TRACE_MARK(3);
+    if (g_trace && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_trace[(size_t)blockIdx.x * 6 + 4] = hw;
+        g_trace[(size_t)blockIdx.x * 6 + 5] = xcc;
+    }
+#endif
 }
+
+#ifdef DYNMM_TRACE
+}  // namespace dynmm
+extern "C" int dynmm_debug_set_trace(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(dynmm::g_trace), &p, sizeof(p));
+}
+namespace dynmm {
+#endif
 
 // Tuning knobs for experiments (read once; unset = built-in choice):
 //   DYNMM_IGEMM_TPIX=64|128      pixel tile of the Co>64 configuration
@@ -378,7 +511,7 @@ struct WgradArgs {
 };
 
 template <int TCO, int TK, int WCO, int WK, bool DUAL>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
     constexpr int BP = 32, LDP = BP + 1;     // +1 pad: column reads of the [row][pixel] tiles
     constexpr int MCO = WCO / 32, MK = WK / 32;
     constexpr int WAVES_K = TK / WK;
@@ -397,6 +530,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     const int co0 = (tile % a.n_co_tiles) * TCO;
     const int k0 = (tile / a.n_co_tiles) * TK;
     const int split = blockIdx.y;
+#ifdef DYNMM_TRACE
+    const size_t trace_row = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+    if (g_trace && threadIdx.x == 0) { g_trace[trace_row] = wall_clock64(); g_trace[trace_row + 1] = g_trace[trace_row]; }
+#endif
 
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
     const int p = t & 31, rg = t >> 5;
@@ -430,16 +567,24 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     }
 
-    float rgv[G_PER], rxv[X_PER];
-    unsigned vmask = 0;      // validity of the tile held in rgv/rxv: bit i = x row i, bit 31 = pixel < M
+    // Two register stages: the loads of step st+2 are issued while step st computes and step st+1 still
+    // sits in registers, so every global load has two MFMA blocks (2 x 64 MFMAs) to land.  The kernel is
+    // bound by bytes-in-flight x latency (2 workgroups/CU at 180 VGPRs); the second stage doubles the
+    // bytes in flight at no occupancy cost.
+    struct Stage {
+        float g[G_PER], x[X_PER];
+        unsigned vmask;      // validity of the held tile: bit i = x row i, bit 31 = pixel < M
+    };
+    Stage r0, r1;
+    r0.vmask = r1.vmask = 0;
     const int step_begin = split * a.steps_per_split;
     const int total_steps = (a.M + BP - 1) / BP;
     const int step_end = min(total_steps, step_begin + a.steps_per_split);
 
     // Loads are issued unconditionally from clamped (always mapped) addresses and the zero-fill of
     // padding / out-of-range lanes is deferred to store_step(): nothing consumes a loaded value
-    // before the MFMA block, so the whole global-load latency hides under the 64 MFMAs of a step.
-    auto load_step = [&](int st) {
+    // before the MFMA block, so the whole global-load latency hides under the MFMAs.
+    auto load_step = [&](int st, Stage& r) {
         const int m = st * BP + p;
         const bool ok = m < a.M;
         int n = 0, oh = 0, ow = 0, rem = 0;
@@ -451,7 +596,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
         const unsigned gv = ((unsigned)(n * a.Co) * (unsigned)HoWo + (unsigned)rem) * 4u;
 #pragma unroll
-        for (int i = 0; i < G_PER; ++i) rgv[i] = ldg_f32(a.dy, gv + goff[i]);
+        for (int i = 0; i < G_PER; ++i) r.g[i] = ldg_f32(a.dy, gv + goff[i]);
         const int ihb = oh * a.SH - a.PH, iwb = ow * a.SW - a.PW;
         const int xb1 = n * a.c_split * HW + ihb * a.W + iwb;     // may be negative at the borders
         const int xb2 = DUAL ? n * c2 * HW + ihb * a.W + iwb : 0;
@@ -459,23 +604,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < X_PER; ++i) {
             const int d = xrs[i];
-            const int r = d & 0xff, s = (d >> 8) & 0xff;
-            const bool valid = ok && (d >> 17) && (unsigned)(ihb + r) < (unsigned)a.H &&
-                               (unsigned)(iwb + s) < (unsigned)a.W;
+            const int r_ = d & 0xff, s_ = (d >> 8) & 0xff;
+            const bool valid = ok && (d >> 17) && (unsigned)(ihb + r_) < (unsigned)a.H &&
+                               (unsigned)(iwb + s_) < (unsigned)a.W;
             const bool second = DUAL && ((d >> 16) & 1);
             const int e = (second ? xb2 : xb1) + xoff[i];
             const unsigned vo = valid ? (unsigned)e * 4u : 0u;
-            rxv[i] = ldg_f32(second ? a.x2 : a.x, vo);
+            r.x[i] = ldg_f32(second ? a.x2 : a.x, vo);
             vm |= valid ? (1u << i) : 0u;
         }
-        vmask = vm;
+        r.vmask = vm;
     };
-    auto store_step = [&]() {
-        const bool ok = (vmask >> 31) != 0;
+    auto store_step = [&](const Stage& r) {
+        const bool ok = (r.vmask >> 31) != 0;
 #pragma unroll
-        for (int i = 0; i < G_PER; ++i) Gs[rg + 8 * i][p] = ok ? rgv[i] : 0.f;
+        for (int i = 0; i < G_PER; ++i) Gs[rg + 8 * i][p] = ok ? r.g[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((vmask >> i) & 1u) ? rxv[i] : 0.f;
+        for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((r.vmask >> i) & 1u) ? r.x[i] : 0.f;
     };
 
     f32x16 acc[MCO][MK];
@@ -487,12 +632,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
     if (step_begin < step_end) {
-        load_step(step_begin);
-        store_step();
+        load_step(step_begin, r0);
+        store_step(r0);
     }
+    if (step_begin + 1 < step_end) load_step(step_begin + 1, r1);
     __syncthreads();
-    for (int st = step_begin; st < step_end; ++st) {
-        if (st + 1 < step_end) load_step(st + 1);
+    // LDS holds step st; `nxt` holds step st+1 (maybe still in flight); `fre` is free for step st+2
+    auto one_step = [&](int st, Stage& fre, Stage& nxt) {
+        if (st + 2 < step_end) load_step(st + 2, fre);
 #pragma unroll
         for (int pp = 0; pp < BP / 2; ++pp) {
             float af[MCO], bf[MK];
@@ -507,10 +654,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
-        if (st + 1 < step_end) store_step();
+        if (st + 1 < step_end) store_step(nxt);
         __syncthreads();
+    };
+    for (int st = step_begin; st < step_end; st += 2) {
+        one_step(st, r0, r1);
+        if (st + 1 < step_end) one_step(st + 1, r1, r0);
     }
 
+#ifdef DYNMM_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[trace_row + 2] = wall_clock64();
+#endif
     const int KHKW = a.KH * a.KW;
     float* out = a.out + (size_t)split * a.Co * a.K;
 #pragma unroll
@@ -527,6 +681,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
                 if (co < a.Co) out[((size_t)co * a.Ci + ci) * KHKW + tap] = acc[mi][ni][j];
             }
     }
+#ifdef DYNMM_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (g_trace && threadIdx.x == 0) g_trace[trace_row + 3] = wall_clock64();
+#endif
 }
 
 struct WgradPlan {
