@@ -508,10 +508,12 @@ struct WgradArgs {
     int M, K;
     int n_co_tiles, n_k_tiles;
     int steps_per_split;   // 32-pixel steps handled by one workgroup
+    unsigned magic_wo;     // floor(2^32 / Wo) + 1 when Ho*Wo*Wo < 2^32 (exact rem / Wo by mulhi), else 0
 };
 
-template <int TCO, int TK, int WCO, int WK, bool DUAL>
+template <int TCO, int TK, int WCO, int WK, bool DUAL, bool FAST>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
+    static_assert(!(DUAL && FAST), "FAST is the single-input, Ci % 64 == 0 specialisation");
     constexpr int BP = 32, LDP = BP + 1;     // +1 pad: column reads of the [row][pixel] tiles
     constexpr int MCO = WCO / 32, MK = WK / 32;
     constexpr int WAVES_K = TK / WK;
@@ -532,7 +534,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
     const int split = blockIdx.y;
 #ifdef DYNMM_TRACE
     const size_t trace_row = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
-    if (g_trace && threadIdx.x == 0) { g_trace[trace_row] = wall_clock64(); g_trace[trace_row + 1] = g_trace[trace_row]; }
+    if (g_trace && threadIdx.x == 0) { g_trace[trace_row] = wall_clock64(); g_trace[trace_row + 1] = g_trace[trace_row]; g_trace[trace_row + 4] = clock64(); }
 #endif
 
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
@@ -567,16 +569,41 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
         }
     }
 
-    // Two register stages: the loads of step st+2 are issued while step st computes and step st+1 still
-    // sits in registers, so every global load has two MFMA blocks (2 x 64 MFMAs) to land.  The kernel is
-    // bound by bytes-in-flight x latency (2 workgroups/CU at 180 VGPRs); the second stage doubles the
-    // bytes in flight at no occupancy cost.
+    // FAST (Ci % 64 == 0, one input tensor): this thread's rows [0,8) lie in one filter tap and rows
+    // [8,16) in one tap (TK = 128 rows = 2 x 64, taps change at multiples of Ci), so padding validity and
+    // the tap shift are evaluated twice per step instead of 16 times, and an invalid group simply reads
+    // the un-shifted (always mapped) position: no per-row select.  ~100 VALU per step instead of ~400 —
+    // with only 2 waves/SIMD that address arithmetic was not hidden behind the other wave's MFMAs.
+    int f_r[2] = {0, 0}, f_s[2] = {0, 0};
+    bool f_ok[2] = {false, false};
+    unsigned xoffb[X_PER];
+    if (FAST) {
+#pragma unroll
+        for (int gidx = 0; gidx < 2; ++gidx) {
+            const int k = k0 + rg + 64 * gidx;
+            if (k < a.K && gidx * 8 < X_PER) {
+                const int tap = k / a.Ci;
+                f_r[gidx] = tap / a.KW;
+                f_s[gidx] = tap - f_r[gidx] * a.KW;
+                f_ok[gidx] = true;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i) xoffb[i] = (xrs[i] >> 17) ? (unsigned)xoff[i] * 4u : 0u;
+    }
+    // running pixel position of this lane (FAST): m = n * HoWo + rem
+    int f_m = split * a.steps_per_split * BP + p;
+    int f_n = f_m / HoWo;
+    int f_rem = f_m - f_n * HoWo;
+
+    // One register stage of global prefetch (a second stage was measured: no gain — the kernel is not
+    // bound by global-load latency but by LDS-fragment latency inside the MFMA block, see below).
     struct Stage {
         float g[G_PER], x[X_PER];
         unsigned vmask;      // validity of the held tile: bit i = x row i, bit 31 = pixel < M
     };
-    Stage r0, r1;
-    r0.vmask = r1.vmask = 0;
+    Stage r0;
+    r0.vmask = 0;
     const int step_begin = split * a.steps_per_split;
     const int total_steps = (a.M + BP - 1) / BP;
     const int step_end = min(total_steps, step_begin + a.steps_per_split);
@@ -585,6 +612,34 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
     // padding / out-of-range lanes is deferred to store_step(): nothing consumes a loaded value
     // before the MFMA block, so the whole global-load latency hides under the MFMAs.
     auto load_step = [&](int st, Stage& r) {
+        if (FAST) {
+            const bool ok = f_m < a.M;
+            const int n = ok ? f_n : 0, rem = ok ? f_rem : 0;
+            const int oh = a.magic_wo ? (int)__umulhi((unsigned)rem, a.magic_wo) : rem / a.Wo;
+            const int ow = rem - oh * a.Wo;
+            const unsigned gv = ((unsigned)(n * a.Co) * (unsigned)HoWo + (unsigned)rem) * 4u;
+#pragma unroll
+            for (int i = 0; i < G_PER; ++i) r.g[i] = ldg_f32(a.dy, gv + goff[i]);
+            const int ihb = oh * a.SH - a.PH, iwb = ow * a.SW - a.PW;
+            const int img = n * a.Ci * HW;
+            const int shift = ihb * a.W + iwb;
+            unsigned base[2];
+            unsigned vm = ok ? 0x80000000u : 0u;
+#pragma unroll
+            for (int gidx = 0; gidx < 2; ++gidx) {
+                const bool v = ok && f_ok[gidx] && (unsigned)(ihb + f_r[gidx]) < (unsigned)a.H &&
+                               (unsigned)(iwb + f_s[gidx]) < (unsigned)a.W;
+                base[gidx] = (unsigned)(img + (v ? shift : 0)) * 4u;     // invalid tap: un-shifted, always mapped
+                vm |= v ? (1u << gidx) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < X_PER; ++i) r.x[i] = ldg_f32(a.x, base[i >> 3] + xoffb[i]);
+            r.vmask = vm;
+            f_m += BP;
+            f_rem += BP;
+            while (f_rem >= HoWo) { f_rem -= HoWo; ++f_n; }
+            return;
+        }
         const int m = st * BP + p;
         const bool ok = m < a.M;
         int n = 0, oh = 0, ow = 0, rem = 0;
@@ -619,8 +674,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
         const bool ok = (r.vmask >> 31) != 0;
 #pragma unroll
         for (int i = 0; i < G_PER; ++i) Gs[rg + 8 * i][p] = ok ? r.g[i] : 0.f;
+        if (FAST) {
+            const bool v0 = (r.vmask & 1u) != 0, v1 = (r.vmask & 2u) != 0;
 #pragma unroll
-        for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((r.vmask >> i) & 1u) ? r.x[i] : 0.f;
+            for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((i >> 3) ? v1 : v0) ? r.x[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((r.vmask >> i) & 1u) ? r.x[i] : 0.f;
+        }
     };
 
     f32x16 acc[MCO][MK];
@@ -631,35 +692,50 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
+    // MFMA block of one step: 16 k-pairs x (MCO x MK) MFMAs.  The A/B fragments of k-pair q+1 are read
+    // from LDS BEFORE the MFMAs of k-pair q issue (two fragment sets).
+    // Measured and rejected on MI355X (-DDYNMM_TRACE timelines, scratch/trace/): a second register stage
+    // of global prefetch, double-buffered LDS with one barrier per step and all loads / LDS writes
+    // interleaved between the MFMAs (with hand-counted vmcnt via asm loads, because hipcc drains vmcnt
+    // to 0 before every new batch of loads in a loop), fragments two k-pairs ahead: all within +-3 % of
+    // this simple loop.  The shader clock sits at ~1.93 GHz in this kernel (2.38 GHz in a pure-MFMA
+    // loop, scratch/mfma/peak.hip), i.e. the sustainable fp32 MFMA rate here is ~126 TFLOP/s, not 157.
+    auto frags = [&](int pp, float (&af)[MCO], float (&bf)[MK]) {
+#pragma unroll
+        for (int mi = 0; mi < MCO; ++mi) af[mi] = Gs[wave_co * WCO + mi * 32 + l31][2 * pp + khalf];
+#pragma unroll
+        for (int ni = 0; ni < MK; ++ni) bf[ni] = Xs[wave_k * WK + ni * 32 + l31][2 * pp + khalf];
+    };
+    auto mfmas = [&](const float (&af)[MCO], const float (&bf)[MK]) {
+#pragma unroll
+        for (int mi = 0; mi < MCO; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < MK; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    };
     if (step_begin < step_end) {
         load_step(step_begin, r0);
         store_step(r0);
     }
-    if (step_begin + 1 < step_end) load_step(step_begin + 1, r1);
     __syncthreads();
-    // LDS holds step st; `nxt` holds step st+1 (maybe still in flight); `fre` is free for step st+2
-    auto one_step = [&](int st, Stage& fre, Stage& nxt) {
-        if (st + 2 < step_end) load_step(st + 2, fre);
+    for (int st = step_begin; st < step_end; ++st) {
+        if (st + 1 < step_end) load_step(st + 1, r0);
+        float af0[MCO], bf0[MK], af1[MCO], bf1[MK];
+        frags(0, af0, bf0);
 #pragma unroll
-        for (int pp = 0; pp < BP / 2; ++pp) {
-            float af[MCO], bf[MK];
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi) af[mi] = Gs[wave_co * WCO + mi * 32 + l31][2 * pp + khalf];
-#pragma unroll
-            for (int ni = 0; ni < MK; ++ni) bf[ni] = Xs[wave_k * WK + ni * 32 + l31][2 * pp + khalf];
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < MK; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int pp = 0; pp < BP / 2; pp += 2) {
+            frags(pp + 1, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp + 2 < BP / 2) frags(pp + 2, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        if (st + 1 < step_end) store_step(nxt);
+        if (st + 1 < step_end) store_step(r0);
         __syncthreads();
-    };
-    for (int st = step_begin; st < step_end; st += 2) {
-        one_step(st, r0, r1);
-        if (st + 1 < step_end) one_step(st + 1, r1, r0);
     }
 
 #ifdef DYNMM_TRACE
@@ -684,7 +760,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 #ifdef DYNMM_TRACE
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (g_trace && threadIdx.x == 0) g_trace[trace_row + 3] = wall_clock64();
+    if (g_trace && threadIdx.x == 0) { g_trace[trace_row + 3] = wall_clock64(); g_trace[trace_row + 5] = clock64(); }
 #endif
 }
 
@@ -860,12 +936,16 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(p.n_co_tiles * p.n_k_tiles), (unsigned)p.splits);
     const bool dual = x2 != nullptr;
+    const bool fast = !dual && (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
+    a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
 #define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
     do {                                                                                              \
         if (dual)                                                                                     \
-            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, true>), grid, dim3(256), 0, st, a);  \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, true, false>), grid, dim3(256), 0, st, a);  \
+        else if (fast)                                                                                \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false, true>), grid, dim3(256), 0, st, a);  \
         else                                                                                          \
-            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false>), grid, dim3(256), 0, st, a); \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false, false>), grid, dim3(256), 0, st, a); \
     } while (0)
     if (p.tco == 128)
         DYNMM_WGRAD_LAUNCH(128, 128, 64, 64);

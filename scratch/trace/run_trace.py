@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from dynmm_amd import lib as L
-lib = C.CDLL(os.path.join(HERE, 'libdynmm_trace.so'))
+lib = C.CDLL(os.path.join(HERE, os.environ.get('TRACE_LIB', 'libdynmm_trace.so')))
 for name, (res, args) in L.SIGNATURES.items():
     f = getattr(lib, name); f.restype = res; f.argtypes = args
 lib.dynmm_debug_set_trace.argtypes = [C.c_void_p]

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from dynmm_amd import lib as L
-lib = C.CDLL(os.path.join(HERE, 'libdynmm_trace.so'))
+lib = C.CDLL(os.path.join(HERE, os.environ.get('TRACE_LIB', 'libdynmm_trace.so')))
 for name, (res, args) in L.SIGNATURES.items():
     f = getattr(lib, name); f.restype = res; f.argtypes = args
 lib.dynmm_debug_set_trace.argtypes = [C.c_void_p]
@@ -48,4 +48,7 @@ for (Cc, H, W, KH, KW) in ((128, 60, 80, 3, 1), (256, 30, 40, 3, 1), (64, 120, 1
     for nm, a, bb in (('loop', 0, 2), ('epilogue', 2, 3)):
         d = rel[:, bb] - rel[:, a]
         print('   %-9s us  mean %.2f p50 %.2f p95 %.2f max %.2f' % (nm, d.mean(), np.median(d), np.percentile(d, 95), d.max()))
+    dw_ = (t[:, 3] - t[:, 0]).astype(np.float64) / 100.0
+    dc_ = (t[:, 5] - t[:, 4]).astype(np.float64)
+    print('   clock64 ticks per us (MHz): mean %.1f min %.1f max %.1f' % ((dc_ / dw_).mean(), (dc_ / dw_).min(), (dc_ / dw_).max()))
     print('   start times: p50 %.1f p95 %.1f max %.1f' % (np.median(rel[:, 0]), np.percentile(rel[:, 0], 95), rel[:, 0].max()))
