@@ -354,7 +354,9 @@ __global__ void __launch_bounds__(256, (TCO * TPIX <= 8192 ? 6 : 2)) conv_igemm_
         }
     };
 
-    const bool fast_out = single_out && (co0 + TCO <= a.Co);
+    // batched path: one output tensor, and channel validity decidable per group of 4 consecutive channels
+    const bool full_co = co0 + TCO <= a.Co;
+    const bool fast_out = single_out && (full_co || (a.Co & 3) == 0);
 #pragma unroll
     for (int ni = 0; ni < MPIX; ++ni) {
         const int m = pix0 + wave_pix * WPIX + ni * 32 + l31;
@@ -370,22 +372,31 @@ __global__ void __launch_bounds__(256, (TCO * TPIX <= 8192 ? 6 : 2)) conv_igemm_
                 for (int h = 0; h < 2; ++h) {
                     float v[8], rv[8], mv[8];
                     // element e of this half: j = 8h + e  ->  channel offset (e & 3) + 8 * (2h + (e >> 2))
+                    // the half's two groups of 4 consecutive channels; in a partial channel tile a group
+                    // is either entirely inside [0,Co) or entirely outside (Co % 4 == 0)
+                    const bool g0 = full_co || co0 + cl0 + 8 * (2 * h) < a.Co;
+                    const bool g1 = full_co || co0 + cl0 + 8 * (2 * h + 1) < a.Co;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { mv[e] = 1.f; rv[e] = 0.f; }
                     if (has_mask) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            mv[e] = ldg_f32(mask_p, off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes);
+                            if ((e >> 2) ? g1 : g0)
+                                mv[e] = ldg_f32(mask_p, off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes);
                     }
                     if (has_res) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            rv[e] = ldg_f32(res_p, off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes);
+                            if ((e >> 2) ? g1 : g0)
+                                rv[e] = ldg_f32(res_p, off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes);
                     }
                     scaled(v, mi, ni, cl0, h);
                     finish(v, rv, mv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
-                                                  (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
+                        if ((e >> 2) ? g1 : g0)
+                            *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
+                                                      (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -478,6 +489,11 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
         // prefetch both lost for the same reason: they cost occupancy.)
         if (force_tpix == 128)
             DYNMM_IGEMM_LAUNCH(128, 128, 64, 64);
+        else if (force_tpix == 32 ||
+                 (force_tpix == 0 && ceil_div(a.Co, 128) * ceil_div(a.M, 64) < 3 * 256))
+            // fewer than 3 tiles per CU (C=512 @ 15x20: 600 tiles): halve the tile so the work spreads
+            // evenly — 188.6 -> 174.6 us; at >= 4.7 tiles/CU the 128x64 tile's lower L2 traffic wins.
+            DYNMM_IGEMM_LAUNCH(128, 32, 32, 32);
         else
             DYNMM_IGEMM_LAUNCH(128, 64, 64, 32);
     } else if (a.Co > 32) {

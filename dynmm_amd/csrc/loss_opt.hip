@@ -8,6 +8,17 @@ namespace dynmm {
 
 constexpr int kMaxClasses = 64;
 
+// One pixel per thread, its C logits held in registers (CMAX compile-time bound): every logit is read
+// from memory exactly once and all C loads of a pixel are in flight together.  (The first version re-read
+// the channel column once per pass — max, sum, output — from L2: 850 / 1625 us fwd / bwd on the 40x480x640
+// logits of a batch of 32, against ~350 / ~700 us at the HBM roofline.)
+template <int CMAX>
+__device__ __forceinline__ void load_logits(const float* __restrict__ xn, int C, int HW, int p, float (&v)[CMAX]) {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) v[c] = c < C ? xn[(size_t)c * HW + p] : -INFINITY;
+}
+
+template <int CMAX>
 __global__ void __launch_bounds__(256) ce2d_fwd_kernel(const float* __restrict__ x,
                                                        const unsigned char* __restrict__ target,
                                                        const float* __restrict__ cw,
@@ -20,13 +31,20 @@ __global__ void __launch_bounds__(256) ce2d_fwd_kernel(const float* __restrict__
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         const int t = (int)tn[p] - 1;
         if (t < 0 || t >= C) continue;   // void (ignore_index = -1 after the shift)
+        float v[CMAX];
+        load_logits<CMAX>(xn, C, HW, p, v);
         float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, xn[(size_t)c * HW + p]);
-        float den = 0.f;
-        for (int c = 0; c < C; ++c) den += expf(xn[(size_t)c * HW + p] - mx);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) mx = fmaxf(mx, v[c]);
+        float den = 0.f, xt = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            den += expf(v[c] - mx);            // exp(-inf) = 0 for the padding slots
+            xt = c == t ? v[c] : xt;
+        }
         const float lse = logf(den) + mx;
         const float w = cw[t];
-        ls += w * (lse - xn[(size_t)t * HW + p]);
+        ls += w * (lse - xt);
         ws += w;
     }
     const float tl = block_reduce_sum_256<float>(ls, red);
@@ -37,6 +55,7 @@ __global__ void __launch_bounds__(256) ce2d_fwd_kernel(const float* __restrict__
     }
 }
 
+template <int CMAX>
 __global__ void __launch_bounds__(256) ce2d_bwd_kernel(const float* __restrict__ x,
                                                        const unsigned char* __restrict__ target,
                                                        const float* __restrict__ cw,
@@ -50,19 +69,27 @@ __global__ void __launch_bounds__(256) ce2d_bwd_kernel(const float* __restrict__
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         const int t = (int)tn[p] - 1;
         if (t < 0 || t >= C) {
-            for (int c = 0; c < C; ++c) dn[(size_t)c * HW + p] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) dn[(size_t)c * HW + p] = 0.f;
             continue;
         }
+        float v[CMAX];
+        load_logits<CMAX>(xn, C, HW, p, v);
         float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, xn[(size_t)c * HW + p]);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) mx = fmaxf(mx, v[c]);
         float den = 0.f;
-        for (int c = 0; c < C; ++c) den += expf(xn[(size_t)c * HW + p] - mx);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            v[c] = expf(v[c] - mx);
+            den += v[c];
+        }
         const float k = cw[t] * gs;
         const float inv = 1.f / den;
-        for (int c = 0; c < C; ++c) {
-            const float sm = expf(xn[(size_t)c * HW + p] - mx) * inv;
-            dn[(size_t)c * HW + p] = k * (sm - (c == t ? 1.f : 0.f));
-        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) dn[(size_t)c * HW + p] = k * (v[c] * inv - (c == t ? 1.f : 0.f));
     }
 }
 
@@ -143,7 +170,10 @@ extern "C" int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const
     DYNMM_HIP_TRY(hipMemsetAsync(loss_sum_wsum, 0, 2 * sizeof(double), st));
     int bx = ceil_div(HW, 256);
     if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(ce2d_fwd_kernel, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW);
+    if (C <= 40)
+        hipLaunchKernelGGL(ce2d_fwd_kernel<40>, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW);
+    else
+        hipLaunchKernelGGL(ce2d_fwd_kernel<kMaxClasses>, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -155,8 +185,12 @@ extern "C" int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const
         return DYNMM_EINVAL;
     int bx = ceil_div(HW, 256);
     if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(ce2d_bwd_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, target, cw,
-                       gscale, dx, C, HW);
+    if (C <= 40)
+        hipLaunchKernelGGL(ce2d_bwd_kernel<40>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, target, cw,
+                           gscale, dx, C, HW);
+    else
+        hipLaunchKernelGGL(ce2d_bwd_kernel<kMaxClasses>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, target,
+                           cw, gscale, dx, C, HW);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

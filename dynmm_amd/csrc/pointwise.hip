@@ -68,6 +68,51 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// W % 4 == 0: four consecutive input pixels per thread (one 16-byte store); their windows are the
+// 2 pooled rows x 3 pooled columns around them, fetched once (the scalar version above did a divide,
+// up to 4 byte-gathers and a 4-byte store per pixel: 738 us on 32x64x240x320 vs ~190 us of HBM time).
+__global__ void __launch_bounds__(256) maxpool_bwd4_kernel(const float* __restrict__ g,
+                                                           const signed char* __restrict__ idx,
+                                                           float* __restrict__ dx, int H, int W,
+                                                           int Ho, int Wo) {
+    const size_t plane = blockIdx.x;
+    const float* gp = g + plane * Ho * Wo;
+    const signed char* ip = idx + plane * Ho * Wo;
+    float* dp = dx + plane * (size_t)H * W;
+    const int Wq = W / 4, nq = H * Wq;
+    const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
+    for (int q = beg + threadIdx.x; q < end; q += 256) {
+        const int ih = q / Wq, iw0 = (q - ih * Wq) * 4;
+        const int oh0 = ih / 2, oh1 = min(Ho - 1, (ih + 1) / 2);      // the (at most) two pooled rows
+        const int ow0 = iw0 / 2;                                      // pooled columns ow0 .. ow0+2
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int oh = rr ? oh1 : oh0;
+            if (rr && oh1 == oh0) break;
+            const int r = ih - (2 * oh - 1);                          // tap row of this input row in window oh
+            if (r < 0 || r > 2) continue;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const int ow = ow0 + cc;
+                if (ow >= Wo) continue;
+                const int code = ip[oh * Wo + ow];
+                const float gv = gp[oh * Wo + ow];
+                // window ow covers input columns 2*ow-1 .. 2*ow+1, i.e. local pixels 2*cc-1 .. 2*cc+1
+                const int s = code - r * 3;                           // tap column the max came from, if in row r
+                const int local = 2 * cc - 1 + s;
+                if (s >= 0 && s <= 2 && local >= 0 && local < 4) {
+                    if (local == 0) out[0] += gv;
+                    else if (local == 1) out[1] += gv;
+                    else if (local == 2) out[2] += gv;
+                    else out[3] += gv;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dp + (size_t)ih * W + iw0) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // adaptive average pool (windows [floor(o*I/O), ceil((o+1)*I/O)) ) — tiny maps only (PPM).
 // ------------------------------------------------------------------------------------------------
@@ -541,7 +586,10 @@ extern "C" int dynmm_maxpool3x3s2_bwd(const float* g, const signed char* idx, fl
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !idx || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     dim3 grid(N * C, plane_chunks(H * W, kChunk));
-    hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);
+    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15u) == 0)
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

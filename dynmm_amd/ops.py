@@ -121,8 +121,11 @@ def _grad_dst(param, like=None):
 PROFILE = None
 
 
-def _tile(co):
-    return '128x64' if co > 64 else ('64x128' if co > 32 else '32x256')
+def _tile(co, m=1 << 30):
+    """Tile the library picks (conv_igemm.hip: launch_igemm) for a GEMM with `co` rows and `m` pixels."""
+    if co > 64:
+        return '128x32' if -(-co // 128) * -(-m // 64) < 3 * 256 else '128x64'
+    return '64x128' if co > 32 else '32x256'
 
 
 def _timed(kind, g, call):
@@ -131,7 +134,8 @@ def _timed(kind, g, call):
     co = g.Ci if kind == 'dgrad' else g.Co
     gemm_ci = g.Co if kind == 'dgrad' else g.Ci
     generic = ',generic' if (kind != 'wgrad' and (gemm_ci % 16 != 0 or (g.c_split < g.Ci and g.c_split % 16 != 0))) else ''
-    name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co)}{generic}>'
+    m = g.N * (g.H * g.W if kind == 'dgrad' else g.Ho * g.Wo)
+    name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co, m)}{generic}>'
     flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

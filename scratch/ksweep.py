@@ -5,11 +5,11 @@ from dynmm_amd import ops, lib as L
 lib = L.load()
 N = 32
 st = torch.cuda.current_stream().cuda_stream
-for (Cc, H, W) in ((128, 60, 80), (256, 30, 40)):
+for (Cc, H, W) in ((128, 60, 80), (256, 30, 40), (512, 15, 20)):
     x = torch.randn(N, Cc, H, W, device='cuda')
     b = torch.zeros(Cc, device='cuda')
     y = torch.empty_like(x)
-    for KH in (1, 3, 5, 7, 9):
+    for KH in (1, 3):
         w = torch.randn(Cc, Cc, KH, 1, device='cuda') * 0.05
         g = L.ConvGeom(N, Cc, H, W, Cc, H, W, KH, 1, 1, 1, KH // 2, 0, Cc)
         wp = torch.empty(KH * Cc * Cc, device='cuda')
