@@ -68,7 +68,7 @@ __device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: start, pr
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
 template <int TCO, int TPIX, int WCO, int WPIX, bool DGRAD, bool GENERIC>
-__global__ void __launch_bounds__(256, (TCO * TPIX <= 8192 ? 6 : 2)) conv_igemm_kernel(const IgemmArgs a) {
+__global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 : 6))) conv_igemm_kernel(const IgemmArgs a) {
     constexpr int BK = 16;
     constexpr int MCO = WCO / 32, MPIX = WPIX / 32;
     constexpr int WAVES_PIX = TPIX / WPIX;
@@ -517,6 +517,7 @@ struct WgradArgs {
     const float* x2;
     const float* dy;
     float* out;            // slabs [splits][Co*K] in the layout of w: [Co][Ci][KH][KW]
+    float* out_bias;       // optional bias-gradient slabs [splits][Co] (sum over pixels of dy), or nullptr
     int N, Ci, H, W;
     int Co, Ho, Wo;
     int KH, KW, SH, SW, PH, PW;
@@ -734,8 +735,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
         store_step(r0);
     }
     __syncthreads();
+    // bias gradient (optional): the k-tile-0 workgroups also sum their dy tile over the pixels — the tile
+    // is in LDS anyway, so the separate full pass over dy that the bias gradient used to cost disappears
+    const bool do_bias = a.out_bias != nullptr && (tile / a.n_co_tiles) == 0;
+    float bsum = 0.f;
     for (int st = step_begin; st < step_end; ++st) {
         if (st + 1 < step_end) load_step(st + 1, r0);
+        if (do_bias && t < TCO) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < BP; q += 2) { s0 += Gs[t][q]; s1 += Gs[t][q + 1]; }
+            bsum += s0 + s1;
+        }
         float af0[MCO], bf0[MK], af1[MCO], bf1[MK];
         frags(0, af0, bf0);
 #pragma unroll
@@ -757,6 +768,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 #ifdef DYNMM_TRACE
     if (g_trace && threadIdx.x == 0) g_trace[trace_row + 2] = wall_clock64();
 #endif
+    if (do_bias && t < TCO && co0 + t < a.Co) a.out_bias[(size_t)split * a.Co + co0 + t] = bsum;
     const int KHKW = a.KH * a.KW;
     float* out = a.out + (size_t)split * a.Co * a.K;
 #pragma unroll
@@ -809,12 +821,17 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
 // out[i] = sum_s slabs[s][i], deterministic.  64 columns (V floats each) x 4 slab-groups per
 // workgroup: four independent load streams per column are in flight, partials meet in LDS and are
 // added in a fixed order (no atomics => bit-reproducible weight gradients).
+// Workgroups >= nb1 reduce an optional second region (the bias-gradient slabs) in the same launch.
 template <int V>
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                           float* __restrict__ out, int n, int nslabs) {
+                                                           float* __restrict__ out, int n, int nslabs,
+                                                           const float* __restrict__ slabs2,
+                                                           float* __restrict__ out2, int n2, int nb1) {
     __shared__ float part[4][64][V];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = (blockIdx.x * 64 + tx) * V;
+    int bx = blockIdx.x;
+    if (bx >= nb1) { bx -= nb1; slabs = slabs2; out = out2; n = n2; }
+    const int i = (bx * 64 + tx) * V;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -838,13 +855,21 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
     }
 }
 
-static void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipStream_t st) {
+static void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipStream_t st,
+                                const float* slabs2 = nullptr, float* out2 = nullptr, int n2 = 0) {
     const bool v4 = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15u) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
-    if (v4)
-        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(ceil_div(n / 4, 64)), dim3(256), 0, st, slabs, out, n, nslabs);
-    else
-        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(ceil_div(n, 64)), dim3(256), 0, st, slabs, out, n, nslabs);
+                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
+                    (n2 == 0 || ((n2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs2) & 15u) == 0) &&
+                                 ((reinterpret_cast<uintptr_t>(out2) & 15u) == 0)));
+    if (v4) {
+        const int nb1 = ceil_div(n / 4, 64), nb2 = n2 ? ceil_div(n2 / 4, 64) : 0;
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(nb1 + nb2), dim3(256), 0, st, slabs, out, n, nslabs, slabs2,
+                           out2, n2, nb1);
+    } else {
+        const int nb1 = ceil_div(n, 64), nb2 = n2 ? ceil_div(n2, 64) : 0;
+        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(nb1 + nb2), dim3(256), 0, st, slabs, out, n, nslabs, slabs2,
+                           out2, n2, nb1);
+    }
 }
 
 // wf[(tap*Ci+ci)*CoP + co], wd[(tap*Co+co)*CiP + ci]; padding columns are never consumed.
@@ -928,10 +953,12 @@ extern "C" size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     const WgradPlan p = plan_wgrad(g);
     if (p.splits <= 1) return 0;
-    return (size_t)p.splits * g->Co * g->Ci * g->KH * g->KW * sizeof(float);
+    // [splits][Co*K] weight-gradient slabs, then [splits][Co] bias-gradient slabs (16-byte aligned start)
+    const size_t wslab = ((size_t)p.splits * g->Co * g->Ci * g->KH * g->KW + 3) & ~(size_t)3;
+    return (wslab + (size_t)p.splits * g->Co) * sizeof(float);
 }
 
-extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw,
+extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias,
                                   void* workspace, size_t workspace_bytes,
                                   const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
@@ -943,6 +970,9 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     WgradArgs a{};
     a.x = x; a.x2 = x2; a.dy = dy;
     a.out = p.splits > 1 ? (float*)workspace : dw;
+    const size_t wslab = ((size_t)p.splits * g->Co * g->Ci * g->KH * g->KW + 3) & ~(size_t)3;
+    float* bias_slabs = p.splits > 1 ? (float*)workspace + wslab : dbias;
+    a.out_bias = dbias ? bias_slabs : nullptr;
     a.N = g->N; a.Ci = g->Ci; a.H = g->H; a.W = g->W; a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
     a.c_split = g->c_split;
@@ -972,7 +1002,8 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
 #undef DYNMM_WGRAD_LAUNCH
     DYNMM_LAUNCH_CHECK();
     if (p.splits > 1) {
-        launch_reduce_slabs((const float*)workspace, dw, g->Co * a.K, p.splits, st);
+        launch_reduce_slabs((const float*)workspace, dw, g->Co * a.K, p.splits, st, dbias ? bias_slabs : nullptr,
+                            dbias, dbias ? g->Co : 0);
         DYNMM_LAUNCH_CHECK();
     }
     return DYNMM_OK;

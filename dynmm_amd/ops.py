@@ -251,12 +251,15 @@ class _Conv2d(Function):
         dbias = None
         act = L.ACT_NONE if ctx.defer_mask else ctx.act     # deferred: gy arrives already masked
         dbias_ret = None
-        if act != L.ACT_NONE or ctx.has_bias:
+        # The bias gradient (sum of the masked gy over pixels) rides along with the weight-gradient kernel,
+        # which stages every gy tile anyway; only when the weights take no gradient does it need its own pass.
+        bias_in_wgrad = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.has_bias:
+            dbias, dbias_ret = _grad_dst(ctx.b_param)
+        if act != L.ACT_NONE or (ctx.has_bias and not bias_in_wgrad):
             ge = torch.empty_like(gy) if act != L.ACT_NONE else None
-            if ctx.has_bias:
-                dbias, dbias_ret = _grad_dst(ctx.b_param)
-            L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), _p(dbias), g.N, g.Co, g.Ho * g.Wo,
-                                           act, st), 'act_bwd_bias')
+            L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), None if bias_in_wgrad else _p(dbias), g.N, g.Co,
+                                           g.Ho * g.Wo, act, st), 'act_bwd_bias')
             if ge is not None:
                 gy = ge
         dx = dx2 = None
@@ -282,12 +285,13 @@ class _Conv2d(Function):
                 ws_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(ws_stream):
                     ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
-                    L.check(lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes, C.byref(g),
-                                                   ws_stream.cuda_stream), 'conv2d_wgrad')
+                    L.check(lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(dbias) if bias_in_wgrad else None,
+                                                   _p(ws), nbytes, C.byref(g), ws_stream.cuda_stream), 'conv2d_wgrad')
                 _INFLIGHT.append((x, x2, gy))
             else:
                 ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)
-                L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw), _p(ws), nbytes,
+                L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw),
+                                                                          _p(dbias) if bias_in_wgrad else None, _p(ws), nbytes,
                                                                           C.byref(g), st)), 'conv2d_wgrad')
         return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None
 

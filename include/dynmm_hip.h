@@ -78,9 +78,11 @@ int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask
                        float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
 
 /* dw[Co,Ci,KH,KW] = sum_{n,oh,ow} dy * x(window).  Split over the pixel range into partial slabs in
- * `workspace` (>= dynmm_conv2d_wgrad_workspace_bytes), reduced deterministically. */
+ * `workspace` (>= dynmm_conv2d_wgrad_workspace_bytes), reduced deterministically.
+ * dbias (optional, [Co]) = sum_{n,oh,ow} dy: the bias gradient of the same conv, produced from the dy tiles
+ * the kernel stages anyway (no separate pass over dy). */
 size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g);
-int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw,
+int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias,
                        void* workspace, size_t workspace_bytes,
                        const dynmm_conv_geom* g, void* stream);
 

@@ -22,7 +22,7 @@ for (Cc, H, W, KH, KW) in ((128, 60, 80, 3, 1), (256, 30, 40, 3, 1), (64, 120, 1
     tr = torch.zeros(8192, 6, dtype=torch.int64, device='cuda')
 
     def run():
-        return lib.dynmm_conv2d_wgrad(x.data_ptr(), None, gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, C.byref(g), st)
+        return lib.dynmm_conv2d_wgrad(x.data_ptr(), None, gy.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nbytes, C.byref(g), st)
     lib.dynmm_debug_set_trace(None)
     for _ in range(3):
         run()
