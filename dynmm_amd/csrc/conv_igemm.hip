@@ -587,18 +587,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
     }
 
     // FAST (Ci % 64 == 0, one input tensor): this thread's rows [0,8) lie in one filter tap and rows
-    // [8,16) in one tap (TK = 128 rows = 2 x 64, taps change at multiples of Ci), so padding validity and
+    // [8,16) in one tap (TK rows = TK/64 groups of 64, taps change at multiples of Ci), so padding validity and
     // the tap shift are evaluated twice per step instead of 16 times, and an invalid group simply reads
     // the un-shifted (always mapped) position: no per-row select.  ~100 VALU per step instead of ~400 —
     // with only 2 waves/SIMD that address arithmetic was not hidden behind the other wave's MFMAs.
-    int f_r[2] = {0, 0}, f_s[2] = {0, 0};
-    bool f_ok[2] = {false, false};
+    constexpr int NG = X_PER / 8;          // groups of 8 rows (= 64 k values) sharing one filter tap
+    int f_r[NG], f_s[NG];
+    bool f_ok[NG];
     unsigned xoffb[X_PER];
+#pragma unroll
+    for (int gidx = 0; gidx < NG; ++gidx) { f_r[gidx] = 0; f_s[gidx] = 0; f_ok[gidx] = false; }
     if (FAST) {
 #pragma unroll
-        for (int gidx = 0; gidx < 2; ++gidx) {
+        for (int gidx = 0; gidx < NG; ++gidx) {
             const int k = k0 + rg + 64 * gidx;
-            if (k < a.K && gidx * 8 < X_PER) {
+            if (k < a.K) {
                 const int tap = k / a.Ci;
                 f_r[gidx] = tap / a.KW;
                 f_s[gidx] = tap - f_r[gidx] * a.KW;
@@ -640,10 +643,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
             const int ihb = oh * a.SH - a.PH, iwb = ow * a.SW - a.PW;
             const int img = n * a.Ci * HW;
             const int shift = ihb * a.W + iwb;
-            unsigned base[2];
+            unsigned base[NG];
             unsigned vm = ok ? 0x80000000u : 0u;
 #pragma unroll
-            for (int gidx = 0; gidx < 2; ++gidx) {
+            for (int gidx = 0; gidx < NG; ++gidx) {
                 const bool v = ok && f_ok[gidx] && (unsigned)(ihb + f_r[gidx]) < (unsigned)a.H &&
                                (unsigned)(iwb + f_s[gidx]) < (unsigned)a.W;
                 base[gidx] = (unsigned)(img + (v ? shift : 0)) * 4u;     // invalid tap: un-shifted, always mapped
@@ -692,9 +695,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < G_PER; ++i) Gs[rg + 8 * i][p] = ok ? r.g[i] : 0.f;
         if (FAST) {
-            const bool v0 = (r.vmask & 1u) != 0, v1 = (r.vmask & 2u) != 0;
 #pragma unroll
-            for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((i >> 3) ? v1 : v0) ? r.x[i] : 0.f;
+            for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((r.vmask >> (i >> 3)) & 1u) ? r.x[i] : 0.f;
         } else {
 #pragma unroll
             for (int i = 0; i < X_PER; ++i) Xs[rg + 8 * i][p] = ((r.vmask >> i) & 1u) ? r.x[i] : 0.f;
@@ -799,8 +801,9 @@ struct WgradPlan {
 static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     WgradPlan p;
     p.tco = g->Co > 64 ? 128 : (g->Co > 32 ? 64 : 32);
-    p.tk = 128;
     const int K = g->KH * g->KW * g->Ci;
+    // C=64 three-tap convs (K = 192): one 64co x 192k tile instead of 128 + a half-empty 128
+    p.tk = (p.tco == 64 && K % 192 == 0 && g->Ci % 64 == 0 && g->c_split == g->Ci) ? 192 : 128;
     p.n_co_tiles = ceil_div(g->Co, p.tco);
     p.n_k_tiles = ceil_div(K, p.tk);
     const int M = g->N * g->Ho * g->Wo;
@@ -995,6 +998,8 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     } while (0)
     if (p.tco == 128)
         DYNMM_WGRAD_LAUNCH(128, 128, 64, 64);
+    else if (p.tco == 64 && p.tk == 192)
+        DYNMM_WGRAD_LAUNCH(64, 192, 32, 96);
     else if (p.tco == 64)
         DYNMM_WGRAD_LAUNCH(64, 128, 64, 32);
     else
