@@ -187,6 +187,7 @@ def main():
     else:
         model.eval()
         model.compact = not args.no_compact
+        model.dual_stream = not args.single_stream      # depth-encoder stages on a second HIP stream
         if args.branches == 'all4':
             model.baseline = True                 # configs[1]: static fuse, gate forced on
         else:
@@ -303,7 +304,7 @@ def main():
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'height': args.height, 'width': args.width,
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if graph is not None else 'eager',
-                       'streams': 1 if (args.single_stream or not train) else 3,
+                       'streams': 1 if args.single_stream else (3 if train else 2),
                        'model_tflops': round(value * gflop_img / 1e3, 2),
                        'model_frac_of_fp32_mfma_peak': round(value * gflop_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)},
             'roofline': roofline, 'cpu_baseline': cpu,

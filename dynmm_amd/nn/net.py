@@ -230,6 +230,15 @@ class SkipGateESANet(nn.Module):
                     sk = getattr(self, f'skip_layer{j}')
                     skips.append(sk[0](fuse) if len(sk) else fuse)
                 continue
+            if compacted and self.dual_stream and all(branch[n] >= j for n in alive) and len(alive) == bs:
+                # every sample still fuses at this stage: same two-stream overlap as the dense path
+                r, d = encoder_stage_pair(self, j, r if j == 1 else fuse, d)
+                self.last_stage_batch.append(bs)
+                fuse = ops.se_fuse_blend(r, d, self._se(j))
+                if j < 4:
+                    sk = getattr(self, f'skip_layer{j}')
+                    skips.append(sk[0](fuse) if len(sk) else fuse)
+                continue
             r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
             if not compacted:
                 d = getattr(ed, f'forward_layer{j}')(d)
