@@ -39,8 +39,10 @@ def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr):
                 'conv_igemm_dgrad<128x64>': 'conv_igemm_kernel<128, 64, 64, 32, true, false>',
                 'conv_igemm_fwd<64x128>': 'conv_igemm_kernel<64, 128, 32, 64, false, false>',
                 'conv_igemm_dgrad<64x128>': 'conv_igemm_kernel<64, 128, 32, 64, true, false>',
-                'conv_wgrad<co128>': 'conv_wgrad_kernel<128, 128, 64, 64, false>',
-                'conv_wgrad<co64>': 'conv_wgrad_kernel<64, 128, 64, 32, false>'}
+                'conv_igemm_fwd<128x32>': 'conv_igemm_kernel<128, 32, 32, 32, false, false>',
+                'conv_igemm_dgrad<128x32>': 'conv_igemm_kernel<128, 32, 32, 32, true, false>',
+                'conv_wgrad<co128>': 'conv_wgrad_kernel<128, 128, 64, 64, false, true>',
+                'conv_wgrad<co64>': 'conv_wgrad_kernel<64, 192, 32, 96, false, true>'}
     out = {'note': 'mean per launch over one bench step (batch 32); raw FETCH_SIZE+WRITE_SIZE, KiB->bytes. 4 B/lane '
                    'gathers are an uncalibrated width for FETCH_SIZE on gfx950: *_if_fetch_x2 is the upper bound.'}
     for bench_name, sub in variants.items():

@@ -12,3 +12,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream > $O/pmc_sq.log 2>&1
 ls -la $O $O/*/ | head -40
 tail -1 $O/single_stdout.log | cut -c1-200
+cd $R
+python profiles/summarize_rocpd.py $O/single/bench_results.db $O/single.md > /dev/null
+python profiles/summarize_rocpd.py $O/multi/bench_results.db $O/multi.md > /dev/null
+python profiles/summarize_pmc.py $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv $O/pmc_sq/p_counter_collection.csv $O/pmc.md $O/pmc.json conv_igemm > $O/pmc_summary.log 2>&1
