@@ -47,6 +47,10 @@ CONV_CASES = [
     (2, 8, 28, 38, 8, (5, 5), (2, 2), (0, 0), True, None),
     (2, 1024, 3, 4, 128, (1, 1), (1, 1), (0, 0), False, None),
     (1, 64, 120, 160, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),
+    (2, 192, 10, 12, 64, (3, 3), (1, 1), (1, 1), True, None),       # Ci = 3 x 64: wgrad tap groups, 64x192 tile
+    (1, 64, 7, 9, 256, (1, 3), (1, 1), (0, 1), True, 'relu'),        # ragged M (63 pixels), bias via wgrad
+    (3, 128, 9, 11, 72, (3, 1), (2, 1), (1, 0), True, None),         # Co tail 72 = 64 + 8 in a 128-wide tile
+    (2, 64, 6, 40, 512, (1, 3), (1, 2), (0, 1), True, None),         # 128x32 tile (small grid), stride-2 dgrad
 ]
 
 
