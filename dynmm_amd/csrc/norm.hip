@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
         if (residual) vload<V>(residual + base + i, r);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float o = v[j] * sc + sh;
+            float o = fmaf(v[j], sc, sh);       // (the backward re-evaluates exactly this expression)
             if (residual) o += r[j];
             v[j] = act_fwd(o, act);
         }
@@ -98,11 +98,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
 template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
     const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
-    const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ sums,
-    int N, int C, int HW, int act) {
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, double* __restrict__ sums, int N, int C, int HW, int act) {
     __shared__ float red[4];
     const int c = blockIdx.x, S = gridDim.y;
     const float mu = mean[c], is = invstd[c];
+    // y == nullptr (ReLU, no residual): the mask [y > 0] is re-derived from x with the forward's own
+    // arithmetic, fma(x, sc, sh) > 0 — one tensor read less in each backward pass
+    const bool remask = act != DYNMM_ACT_NONE && y == nullptr;
+    const float sc = remask ? gamma[c] * is : 0.f;
+    const float sh = remask ? beta[c] - mu * sc : 0.f;
     float s1 = 0.f, s2 = 0.f;
     for (int n = blockIdx.y; n < N; n += S) {
         const size_t base = ((size_t)n * C + c) * HW;
@@ -111,9 +116,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
             float gv[V], yv[V], xv[V];
             vload<V>(g + base + i, gv);
             vload<V>(x + base + i, xv);
-            if (act != DYNMM_ACT_NONE) vload<V>(y + base + i, yv);
+            if (act != DYNMM_ACT_NONE && !remask) vload<V>(y + base + i, yv);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
+                if (remask) yv[j] = fmaf(xv[j], sc, sh);
                 const float ge = (act != DYNMM_ACT_NONE) ? act_bwd(gv[j], yv[j], act) : gv[j];
                 a1 += ge;
                 a2 += ge * (xv[j] - mu) * is;
@@ -133,12 +139,15 @@ template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dres,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int HW, int training,
-    int act, int chunk) {
+    const float* __restrict__ beta, const double* __restrict__ sums, float* __restrict__ dx,
+    float* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int HW,
+    int training, int act, int chunk) {
     const int plane = blockIdx.x;
     const int c = plane % C;
     const float mu = mean[c], is = invstd[c];
+    const bool remask = act != DYNMM_ACT_NONE && y == nullptr;
+    const float sc = remask ? gamma[c] * is : 0.f;
+    const float sh = remask ? beta[c] - mu * sc : 0.f;
     const float sg = (float)sums[c], sgx = (float)sums[C + c];
     if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
         if (dgamma) dgamma[c] = sgx;
@@ -155,9 +164,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
         float gv[V], yv[V], xv[V], o[V];
         vload<V>(g + base + i, gv);
         vload<V>(x + base + i, xv);
-        if (act != DYNMM_ACT_NONE) vload<V>(y + base + i, yv);
+        if (act != DYNMM_ACT_NONE && !remask) vload<V>(y + base + i, yv);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
+            if (remask) yv[j] = fmaf(xv[j], sc, sh);
             const float ge = (act != DYNMM_ACT_NONE) ? act_bwd(gv[j], yv[j], act) : gv[j];
             gv[j] = ge;
             o[j] = k0 * (ge - m1 - (xv[j] - mu) * is * m2);
@@ -260,42 +270,42 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
 }
 
 extern "C" int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x, const float* mean,
-                                   const float* invstd, double* sums, int N, int C, int HW, int act,
-                                   void* stream) {
+                                   const float* invstd, const float* gamma, const float* beta,
+                                   double* sums, int N, int C, int HW, int act, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
-    if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y && (act != DYNMM_ACT_RELU || !gamma || !beta)) return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
     dim3 grid(C, reduce_splits(N, C));
     if (can_vec4(HW, {g, y, x}))
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd, gamma, beta,
                            sums, N, C, HW, act);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd, gamma, beta,
                            sums, N, C, HW, act);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
 
 extern "C" int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x, const float* mean,
-                                  const float* invstd, const float* gamma, const double* sums,
-                                  float* dx, float* d_residual, float* dgamma, float* dbeta, int N,
-                                  int C, int HW, int training, int act, void* stream) {
+                                  const float* invstd, const float* gamma, const float* beta,
+                                  const double* sums, float* dx, float* d_residual, float* dgamma,
+                                  float* dbeta, int N, int C, int HW, int training, int act, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || HW <= 0)
         return DYNMM_EINVAL;
-    if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y && (act != DYNMM_ACT_RELU || !beta || d_residual)) return DYNMM_EINVAL;
     int nchunks;
     const int chunk = plane_chunk(HW, &nchunks);
     dim3 grid(N * C, nchunks);
     hipStream_t st = (hipStream_t)stream;
     if (can_vec4(HW, {g, y, x, dx, d_residual}))
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
-                           gamma, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
+                           gamma, beta, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
-                           gamma, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
+                           gamma, beta, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

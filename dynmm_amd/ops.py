@@ -373,7 +373,10 @@ class _BatchNormAct(Function):
         ctx.training = training
         ctx.link = link
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, gamma, mean, invstd)
+        # ReLU without residual: the backward re-derives the mask from x (bit-identical to this forward's
+        # fma) instead of reading y — one tensor read less in bn_bwd_reduce and in bn_bwd_apply
+        need_y = act != L.ACT_NONE and not (act == L.ACT_RELU and residual is None)
+        ctx.save_for_backward(x, y if need_y else None, gamma, mean, invstd, beta)
         ctx.g_param, ctx.b_param = gamma, beta
         return y
 
@@ -381,20 +384,20 @@ class _BatchNormAct(Function):
     def backward(ctx, gy):
         lib = _lib()
         st = _stream()
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         gy = _chk(gy, 'grad')
         N, Cc, H, W = x.shape
         HW = H * W
         dev = x.device
         sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
-        L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(sums),
+        L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
                                         N, Cc, HW, ctx.act, st), 'bn_bwd_reduce')
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[5]
         dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None
         dgamma, dgamma_ret = _grad_dst(ctx.g_param)
         dbeta, dbeta_ret = _grad_dst(ctx.b_param)
-        L.check(lib.dynmm_bn_bwd_apply(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
+        L.check(lib.dynmm_bn_bwd_apply(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
                                        _p(dx), _p(dres), _p(dgamma), _p(dbeta), N, Cc, HW,
                                        int(ctx.training), ctx.act, st), 'bn_bwd_apply')
         if need_res and dres is None:

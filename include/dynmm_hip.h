@@ -121,14 +121,17 @@ int dynmm_bn_apply(const float* x, const double* sums, const float* gamma, const
                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                    const float* residual, float* y, int N, int C, int HW,
                    float eps, float momentum, int training, int act, void* stream);
-/* backward: sums[2*C] <- (sum g_eff, sum g_eff*xhat), g_eff = g*act'(y). */
+/* backward: sums[2*C] <- (sum g_eff, sum g_eff*xhat), g_eff = g*act'(y).
+ * y may be NULL for act = ReLU when the forward had no residual: the mask [y > 0] is then re-derived from
+ * x as fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0 — bit-identical to the forward's own evaluation
+ * (gamma, beta required in that case) — which saves one tensor read in each of the two backward passes. */
 int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x,
-                        const float* mean, const float* invstd, double* sums,
-                        int N, int C, int HW, int act, void* stream);
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        double* sums, int N, int C, int HW, int act, void* stream);
 /* dx = gamma*invstd*(g_eff - sum_g/M - xhat*sum_gx/M) (training) or gamma*invstd*g_eff (eval);
  * d_residual = g_eff (optional); dgamma/dbeta from sums. */
 int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x,
-                       const float* mean, const float* invstd, const float* gamma,
+                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                        const double* sums, float* dx, float* d_residual,
                        float* dgamma, float* dbeta,
                        int N, int C, int HW, int training, int act, void* stream);
