@@ -802,8 +802,13 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     WgradPlan p;
     p.tco = g->Co > 64 ? 128 : (g->Co > 32 ? 64 : 32);
     const int K = g->KH * g->KW * g->Ci;
-    // C=64 three-tap convs (K = 192): one 64co x 192k tile instead of 128 + a half-empty 128
-    p.tk = (p.tco == 64 && K % 192 == 0 && g->Ci % 64 == 0 && g->c_split == g->Ci) ? 192 : 128;
+    // k-tile width for the 64-row configuration: 192 for the C=64 three-tap convs (K = 192: one tile instead
+    // of 128 + a half-empty 128) and for 128 < K <= 192 (RGB stem, K = 147); 64 for K <= 64 (depth stem, K = 49)
+    p.tk = 128;
+    if (p.tco == 64) {
+        if ((K % 192 == 0 && g->Ci % 64 == 0 && g->c_split == g->Ci) || (K > 128 && K <= 192)) p.tk = 192;
+        else if (K <= 64) p.tk = 64;
+    }
     p.n_co_tiles = ceil_div(g->Co, p.tco);
     p.n_k_tiles = ceil_div(K, p.tk);
     const int M = g->N * g->Ho * g->Wo;
@@ -1000,6 +1005,8 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
         DYNMM_WGRAD_LAUNCH(128, 128, 64, 64);
     else if (p.tco == 64 && p.tk == 192)
         DYNMM_WGRAD_LAUNCH(64, 192, 32, 96);
+    else if (p.tco == 64 && p.tk == 64)
+        DYNMM_WGRAD_LAUNCH(64, 64, 32, 32);
     else if (p.tco == 64)
         DYNMM_WGRAD_LAUNCH(64, 128, 64, 32);
     else

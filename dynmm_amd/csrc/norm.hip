@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
         }
     }
     const float sc = gamma[c] * invstd;
-    const float sh = beta[c] - mean * sc;
+    const float sh = fmaf(-mean, sc, beta[c]);      // explicit: bn_bwd_* re-evaluate exactly these two lines
     const size_t base = (size_t)plane * HW;
     const int beg = blockIdx.y * chunk;
     const int end = min(HW, beg + chunk);
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
     // arithmetic, fma(x, sc, sh) > 0 — one tensor read less in each backward pass
     const bool remask = act != DYNMM_ACT_NONE && y == nullptr;
     const float sc = remask ? gamma[c] * is : 0.f;
-    const float sh = remask ? beta[c] - mu * sc : 0.f;
+    const float sh = remask ? fmaf(-mu, sc, beta[c]) : 0.f;
     float s1 = 0.f, s2 = 0.f;
     for (int n = blockIdx.y; n < N; n += S) {
         const size_t base = ((size_t)n * C + c) * HW;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const float mu = mean[c], is = invstd[c];
     const bool remask = act != DYNMM_ACT_NONE && y == nullptr;
     const float sc = remask ? gamma[c] * is : 0.f;
-    const float sh = remask ? beta[c] - mu * sc : 0.f;
+    const float sh = remask ? fmaf(-mu, sc, beta[c]) : 0.f;
     const float sg = (float)sums[c], sgx = (float)sums[C + c];
     if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
         if (dgamma) dgamma[c] = sgx;
