@@ -40,6 +40,8 @@ struct IgemmArgs {
     int act;
     int M, K, CoP;
     int n_co_tiles, n_pix_tiles;
+    int subpix;            // DGRAD with stride > 1 and Ho % SH == Wo % SW == 0: output pixels are enumerated
+                           // parity class by parity class (see pix_decode), so a tile is (mostly) class-pure
 };
 
 // uniform (SGPR) base + 32-bit per-lane byte offset: lets the compiler pick the
@@ -103,16 +105,34 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
     if (q_glob > a.CoP / 4 - 1) q_glob = a.CoP / 4 - 1;  // rows past Co: finite junk, discarded below
     const unsigned a_voff = (unsigned)((a_active ? a_row0 : 0) * a.CoP + q_glob * 4) * 4u;
 
+    // GEMM pixel index m -> (n, oh, ow) of the output tensor.  Strided dgrad (a.subpix): within an image the
+    // SH*SW parity classes (oh % SH, ow % SW) are enumerated one after the other, because a filter tap only
+    // reaches the output pixels of ONE class — a tile inside a class can skip the other taps outright
+    // instead of multiplying zeros (sub-pixel decomposition of the transposed convolution).
+    auto pix_decode = [&](int m, int& n, int& oh, int& ow, int& cls) {
+        n = m / HoWo;
+        const int q = m - n * HoWo;
+        if (DGRAD && a.subpix) {
+            const int Wc = a.Wo / a.SW;
+            const int csz = HoWo / (a.SH * a.SW);
+            cls = q / csz;
+            const int q2 = q - cls * csz;
+            const int ohc = q2 / Wc;
+            const int ph = cls / a.SW;
+            oh = ohc * a.SH + ph;
+            ow = (q2 - ohc * Wc) * a.SW + (cls - ph * a.SW);
+        } else {
+            cls = 0;
+            oh = q / a.Wo;
+            ow = q - oh * a.Wo;
+        }
+    };
     const int b_col = t % TPIX, b_row0 = t / TPIX;
     const int m_b = pix0 + b_col;
     const bool m_ok = m_b < a.M;
-    int n_b = 0, oh_b = 0, ow_b = 0;
-    if (m_ok) {
-        n_b = m_b / HoWo;
-        const int rem = m_b - n_b * HoWo;
-        oh_b = rem / a.Wo;
-        ow_b = rem - oh_b * a.Wo;
-    }
+    int n_b = 0, oh_b = 0, ow_b = 0, cls_b = 0;
+    if (m_ok) pix_decode(m_b, n_b, oh_b, ow_b, cls_b);
+    (void)cls_b;
     const int c2 = a.Ci - a.c_in_split;
 
     auto in_coord = [&](int r, int s, int& ih, int& iw) -> bool {
@@ -168,7 +188,22 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
     if constexpr (!GENERIC) {
         // ---------------- fast path: Ci % 16 == 0, one filter tap per K-step ----------------
         const int cpt = a.Ci / BK;
-        const int nk = a.KH * a.KW * cpt;
+        // taps that can reach this tile: all of them, unless the tile lies inside one parity class
+        int live_ph = -1, live_pw = -1;
+        if (DGRAD && a.subpix) {
+            int n0, oh0, ow0, c0, n1, oh1, ow1, c1;
+            pix_decode(pix0, n0, oh0, ow0, c0);
+            pix_decode(min(pix0 + TPIX, a.M) - 1, n1, oh1, ow1, c1);
+            if (n0 == n1 && c0 == c1) { live_ph = c0 / a.SW; live_pw = c0 - live_ph * a.SW; }
+        }
+        auto tap_live = [&](int r, int s_) -> bool {
+            if (!(DGRAD && a.subpix) || live_ph < 0) return true;
+            return ((live_ph + a.PH - r) % a.SH == 0) && ((live_pw + a.PW - s_) % a.SW == 0);
+        };
+        int n_live = 0;
+        for (int r = 0; r < a.KH; ++r)
+            for (int s_ = 0; s_ < a.KW; ++s_) n_live += tap_live(r, s_) ? 1 : 0;
+        const int nk = n_live * cpt;
         // K-iteration state (wave-uniform) and the per-lane tap geometry
         int ci0 = 0, tr = 0, ts = 0, kbase = 0;
         bool tap_ok;
@@ -179,6 +214,14 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
             const unsigned pix = tap_ok ? (unsigned)(ih * a.W + iw) : 0u;
             voff1 = ((unsigned)(n_b * a.c_in_split + b_row0) * (unsigned)HW + pix) * 4u;
             voff2 = ((unsigned)(n_b * c2 + b_row0) * (unsigned)HW + pix) * 4u;
+        };
+        auto next_tap = [&]() {          // advance (tr, ts, kbase) to the next live tap, if any
+            do {
+                if (++ts == a.KW) { ts = 0; ++tr; }
+                if (tr >= a.KH) return;
+                if (tap_live(tr, ts)) break;
+                kbase += a.Ci;           // skipped tap: its Ci weight rows are never touched
+            } while (true);
         };
         bool ld_ok = false;             // validity of the tile currently held in rb[]
         auto load_tile = [&]() {
@@ -200,8 +243,8 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
             kbase += BK;
             if (ci0 >= a.Ci) {
                 ci0 = 0;
-                if (++ts == a.KW) { ts = 0; ++tr; }
-                set_tap();
+                next_tap();
+                if (tr < a.KH) set_tap();
             }
         };
         auto store_tile = [&](int buf) {
@@ -214,9 +257,15 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
             for (int i = 0; i < B_PER; ++i) Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = ld_ok ? rb[i] : 0.f;
         };
 
-        set_tap();
-        load_tile();
-        store_tile(0);
+        if (!tap_live(0, 0)) {           // first live tap
+            kbase += a.Ci;
+            next_tap();
+        }
+        if (nk > 0) {
+            set_tap();
+            load_tile();
+            store_tile(0);
+        }
         __syncthreads();
         DYNMM_TRACE_MARK(1);
         for (int kt = 0; kt < nk; ++kt) {
@@ -361,8 +410,10 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
     for (int ni = 0; ni < MPIX; ++ni) {
         const int m = pix0 + wave_pix * WPIX + ni * 32 + l31;
         if (m >= a.M) continue;
-        const unsigned n = (unsigned)(m / HoWo);
-        const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+        int n_e, oh_e, ow_e, cls_e;
+        pix_decode(m, n_e, oh_e, ow_e, cls_e);
+        const unsigned n = (unsigned)n_e;
+        const unsigned rem = (unsigned)(oh_e * a.Wo + ow_e);
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
             const int cl0 = wave_co * WCO + mi * 32 + 4 * khalf;          // tile-local channel of j = 0
@@ -469,6 +520,8 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Ci;
     a.CoP = (a.Co + 3) & ~3;
+    static const int no_subpix = env_int("DYNMM_NO_SUBPIX");
+    a.subpix = (DGRAD && !generic && !no_subpix && a.SH * a.SW > 1 && a.Ho % a.SH == 0 && a.Wo % a.SW == 0) ? 1 : 0;
 #define DYNMM_IGEMM_LAUNCH(TCO, TPIX, WCO, WPIX)                                               \
     do {                                                                                       \
         a.n_co_tiles = ceil_div(a.Co, TCO);                                                    \

@@ -51,6 +51,9 @@ CONV_CASES = [
     (1, 64, 7, 9, 256, (1, 3), (1, 1), (0, 1), True, 'relu'),        # ragged M (63 pixels), bias via wgrad
     (3, 128, 9, 11, 72, (3, 1), (2, 1), (1, 0), True, None),         # Co tail 72 = 64 + 8 in a 128-wide tile
     (2, 64, 6, 40, 512, (1, 3), (1, 2), (0, 1), True, None),         # 128x32 tile (small grid), stride-2 dgrad
+    (2, 64, 15, 21, 128, (3, 1), (2, 1), (1, 0), True, None),        # odd H: strided dgrad without sub-pixel classes
+    (2, 64, 6, 10, 128, (1, 3), (1, 2), (0, 1), False, None),        # parity classes of 30 pixels: tiles straddle classes
+    (3, 128, 8, 8, 64, (3, 3), (2, 2), (1, 1), False, None),         # 4 parity classes, 3x3: 1/2/2/4 live taps
 ]
 
 
