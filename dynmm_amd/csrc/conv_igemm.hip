@@ -57,7 +57,7 @@ __device__ __forceinline__ float4 ldg_f32x4(const float* sbase, unsigned voff_by
 // Per-workgroup phase timestamps for kernel-structure experiments (scratch/trace/): compiled in only
 // with -DDYNMM_TRACE, never in the shipped library.
 #ifdef DYNMM_TRACE
-__device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: start, prologue, loop, epilogue, HW_ID, XCC_ID
+__device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: wall clock at start, after prologue, after loop, after epilogue; shader clock at entry, exit
 #define DYNMM_TRACE_MARK(slot)                                                                  \
     do {                                                                                        \
         if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 6 + (slot)] = wall_clock64(); \
@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
     const int lane = t & 63, wave = t >> 6;
     const int wave_co = wave / WAVES_PIX, wave_pix = wave % WAVES_PIX;
     DYNMM_TRACE_MARK(0);
+#ifdef DYNMM_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 6 + 4] = clock64();   // shader clock at entry
+#endif
 
     // XCD-aware tile order: consecutive logical ids (same XCD) walk the co-tiles of one pixel tile
     // first, so the gathered input tile is re-used out of that XCD's L2.
@@ -484,13 +487,7 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
     __builtin_amdgcn_s_waitcnt(0);          // stores acknowledged
     __syncthreads();
     DYNMM_TRACE_MARK(3);
-    if (g_trace && threadIdx.x == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_trace[(size_t)blockIdx.x * 6 + 4] = hw;
-        g_trace[(size_t)blockIdx.x * 6 + 5] = xcc;
-    }
+    if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 6 + 5] = clock64();   // shader clock at exit
 #endif
 }
 

@@ -53,6 +53,9 @@ for (Cc, H, W, KH, KW) in shapes:
     for nm, a, bb in (('prologue', 0, 1), ('loop', 1, 2), ('epilogue', 2, 3)):
         d = rel[:, bb] - rel[:, a]
         print('   %-9s us  mean %.2f p50 %.2f p95 %.2f max %.2f' % (nm, d.mean(), np.median(d), np.percentile(d, 95), d.max()))
+    dw_ = (t[:, 3] - t[:, 0]).astype(np.float64) / 100.0
+    dc_ = (t[:, 5] - t[:, 4]).astype(np.float64)
+    print('   shader clock (MHz): mean %.0f' % (dc_ / dw_).mean())
     T = rel[:, 3].max()
     bw = 2.0
     bins = np.arange(0, T + bw, bw)
