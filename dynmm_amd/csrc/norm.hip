@@ -14,7 +14,10 @@ static inline int reduce_splits(int N, int C) {
     return s;
 }
 
-// sums[c] += sum x ; sums[C+c] += sum x^2
+// (A "last workgroup adds the partials" reduction without the memset was built and measured: its two
+// __threadfence()s per workgroup are L2 write-backs on gfx950 and cost 12 ms per step — fp64 atomics into a
+// zeroed buffer stay.)
+// sums[c] = sum x ; sums[C+c] = sum x^2
 template <int V>
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x,
                                                        double* __restrict__ sums,
@@ -46,11 +49,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     const float* __restrict__ x, const double* __restrict__ sums, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, const float* __restrict__ residual,
-    float* __restrict__ y, int N, int C, int HW, float eps, float momentum, int training, int act,
-    int chunk) {
+    float* __restrict__ y, long long* __restrict__ num_batches_tracked, int N, int C, int HW, float eps,
+    float momentum, int training, int act, int chunk) {
     const int plane = blockIdx.x;
     const int c = plane % C;
     float mean, invstd;
+    if (training && num_batches_tracked && plane == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *num_batches_tracked += 1;          // nn.BatchNorm2d's step counter, without a launch of its own
     if (training) {
         const double M = (double)N * HW;
         const double mu = sums[c] / M;
@@ -247,8 +252,8 @@ extern "C" int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW
 extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* gamma,
                               const float* beta, float* running_mean, float* running_var,
                               float* save_mean, float* save_invstd, const float* residual, float* y,
-                              int N, int C, int HW, float eps, float momentum, int training, int act,
-                              void* stream) {
+                              long long* num_batches_tracked, int N, int C, int HW, float eps, float momentum,
+                              int training, int act, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (training && (!sums || (long long)N * HW <= 1)) return DYNMM_EINVAL;
@@ -259,12 +264,12 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
     hipStream_t st = (hipStream_t)stream;
     if (can_vec4(HW, {x, residual, y}))
         hipLaunchKernelGGL(bn_apply_kernel<4>, grid, dim3(256), 0, st, x, sums, gamma, beta,
-                           running_mean, running_var, save_mean, save_invstd, residual, y, N, C, HW,
-                           eps, momentum, training, act, chunk);
+                           running_mean, running_var, save_mean, save_invstd, residual, y,
+                           num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk);
     else
         hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, st, x, sums, gamma, beta,
-                           running_mean, running_var, save_mean, save_invstd, residual, y, N, C, HW,
-                           eps, momentum, training, act, chunk);
+                           running_mean, running_var, save_mean, save_invstd, residual, y,
+                           num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

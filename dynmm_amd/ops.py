@@ -349,7 +349,7 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
 # ------------------------------------------------------------------------------------------------
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt):
         lib = _lib()
         st = _stream()
         x, residual = _chk(x, 'x'), _chk(residual, 'residual')
@@ -367,7 +367,7 @@ class _BatchNormAct(Function):
         invstd = torch.empty(Cc, device=dev, dtype=torch.float32)
         y = torch.empty_like(x)
         L.check(lib.dynmm_bn_apply(_p(x), _p(sums), _p(gamma), _p(beta), _p(running_mean),
-                                   _p(running_var), _p(mean), _p(invstd), _p(residual), _p(y),
+                                   _p(running_var), _p(mean), _p(invstd), _p(residual), _p(y), _p(nbt),
                                    N, Cc, HW, eps, momentum, int(training), act, st), 'bn_apply')
         ctx.act = act
         ctx.training = training
@@ -404,17 +404,18 @@ class _BatchNormAct(Function):
             dres = gy            # no activation: the residual branch receives the gradient unchanged
         if ctx.link is not None and dres is not None:
             ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
-        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None
+        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
     """act(BatchNorm2d(x) + residual) using the parameters/buffers of the nn.BatchNorm2d `bn`.
     `link`: GradLink that carries the residual's gradient to the op that consumes the same tensor."""
     training = bn.training if training is None else training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if training else None       # incremented inside the normalise kernel
+    if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+        raise L.DynmmHipError('BatchNorm num_batches_tracked must be an int64 tensor on the HIP device')
     return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
-                               bool(training), float(bn.momentum), float(bn.eps), ACT[act], link)
+                               bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt)
 
 
 # ------------------------------------------------------------------------------------------------

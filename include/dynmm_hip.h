@@ -115,11 +115,12 @@ int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbia
 int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, void* stream);
 /* y = act( (x-mean)*invstd*gamma + beta + residual ).
  * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
- *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does.
+ *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and
+ *             increments *num_batches_tracked (int64, optional) as nn.BatchNorm2d does.
  * training=0: uses running_mean/var; sums / save_* may be NULL. */
 int dynmm_bn_apply(const float* x, const double* sums, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                   const float* residual, float* y, int N, int C, int HW,
+                   const float* residual, float* y, long long* num_batches_tracked, int N, int C, int HW,
                    float eps, float momentum, int training, int act, void* stream);
 /* backward: sums[2*C] <- (sum g_eff, sum g_eff*xhat), g_eff = g*act'(y).
  * y may be NULL for act = ReLU when the forward had no residual: the mask [y > 0] is then re-derived from
