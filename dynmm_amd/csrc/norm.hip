@@ -235,11 +235,12 @@ static inline int plane_chunk(int HW, int* nchunks) {
 
 using namespace dynmm;
 
-extern "C" int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, void* stream) {
+extern "C" int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, int sums_are_zero,
+                              void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
+    if (!sums_are_zero) DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
     dim3 grid(C, reduce_splits(N, C));
     if (can_vec4(HW, {x}))
         hipLaunchKernelGGL(bn_stats_kernel<4>, grid, dim3(256), 0, st, x, sums, N, C, HW);
@@ -276,12 +277,13 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
 
 extern "C" int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x, const float* mean,
                                    const float* invstd, const float* gamma, const float* beta,
-                                   double* sums, int N, int C, int HW, int act, void* stream) {
+                                   double* sums, int N, int C, int HW, int act, int sums_are_zero,
+                                   void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (act != DYNMM_ACT_NONE && !y && (act != DYNMM_ACT_RELU || !gamma || !beta)) return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
+    if (!sums_are_zero) DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
     dim3 grid(C, reduce_splits(N, C));
     if (can_vec4(HW, {g, y, x}))
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd, gamma, beta,

@@ -43,9 +43,9 @@ SIGNATURES = {
     'dynmm_conv2d_fwd_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_dgrad_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_act_bwd_bias': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
-    'dynmm_bn_stats': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_stats': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_apply': (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f]),
-    'dynmm_bn_bwd_reduce': (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_bwd_reduce': (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_bwd_apply': (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_fold': (c_i, [c_f] * 7 + [c_i, c_fl, c_f]),
     'dynmm_maxpool3x3s2_fwd': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),

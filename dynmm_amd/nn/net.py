@@ -193,6 +193,8 @@ class SkipGateESANet(nn.Module):
     def forward(self, rgb, depth, test=False, return_weight=False):
         er, ed = self.encoder_rgb, self.encoder_depth
         tab = self._flop_table(rgb.device)
+        if self.training:
+            ops.begin_step()
         r = er.forward_first_conv(rgb)
         d = ed.forward_first_conv(depth)
         fuse = ops.se_fuse_blend(r, d, self._se(0))                 # stem fusion is always on

@@ -200,6 +200,8 @@ class SkipESANet(nn.Module):
         er, ed = self.encoder_rgb, self.encoder_depth
         self.last_aux = [None] * 4
         self.last_stage_batch = None
+        if self.training:
+            ops.begin_step()
         if (self.compact and (test or self.hard_gate) and not self.training and not torch.is_grad_enabled()
                 and not self.ini_stage and not self.random_policy and list(self.block_rule) == [2, 2, 2, 2]):
             return self._forward_compact(rgb, depth, test)

@@ -347,6 +347,37 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
 # ------------------------------------------------------------------------------------------------
 # batch norm (+ residual + activation)
 # ------------------------------------------------------------------------------------------------
+# Zeroed fp64 accumulators for the per-channel BatchNorm reductions come from an arena that is cleared by ONE
+# memset per step (begin_step(), called by the models at the start of a training forward) instead of one
+# memset launch per BatchNorm call (~200 per step).  Slices are handed out by a bump pointer and never reused
+# within a step; when the arena runs out (or begin_step() is never called) a call falls back to its own memset.
+_ARENA = {'buf': None, 'off': 0, 'elems': 1 << 19}
+
+
+def begin_step():
+    """Start of a training step on the current stream: re-arm the zero arena.  Safe whenever no BatchNorm
+    kernel of an earlier step is still in flight on another stream (the models join their side streams)."""
+    a = _ARENA
+    if a['buf'] is not None and a['off'] > 0:
+        a['buf'][:a['off']].zero_()
+    a['off'] = 0
+
+
+def _zero_sums(n, device):
+    """(tensor of n zero doubles, is_zero flag)."""
+    a = _ARENA
+    if a['buf'] is None or a['buf'].device != device:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty(n, device=device, dtype=torch.float64), 0
+        a['buf'] = torch.zeros(a['elems'], device=device, dtype=torch.float64)
+        a['off'] = 0
+    if a['off'] + n > a['elems']:
+        return torch.empty(n, device=device, dtype=torch.float64), 0
+    t = a['buf'][a['off']:a['off'] + n]
+    a['off'] += n
+    return t, 1
+
+
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt):
@@ -361,8 +392,8 @@ class _BatchNormAct(Function):
         if training and N * HW <= 1:
             raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
         if training:
-            sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
-            L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, st), 'bn_stats')
+            sums, zeroed = _zero_sums(2 * Cc, dev)
+            L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, zeroed, st), 'bn_stats')
         mean = torch.empty(Cc, device=dev, dtype=torch.float32)
         invstd = torch.empty(Cc, device=dev, dtype=torch.float32)
         y = torch.empty_like(x)
@@ -389,9 +420,9 @@ class _BatchNormAct(Function):
         N, Cc, H, W = x.shape
         HW = H * W
         dev = x.device
-        sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
+        sums, zeroed = _zero_sums(2 * Cc, dev)
         L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-                                        N, Cc, HW, ctx.act, st), 'bn_bwd_reduce')
+                                        N, Cc, HW, ctx.act, zeroed, st), 'bn_bwd_reduce')
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[5]
         dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None

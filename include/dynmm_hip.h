@@ -111,8 +111,10 @@ int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbia
                        int N, int C, int HW, int act, void* stream);
 
 /* ---- BatchNorm2d (src/models/resnet.py:59,110; model_utils.py:22; …globalgate.py:381,384) ---- */
-/* per-channel sum / sum of squares over (N,HW) into sums[2*C] (double). */
-int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, void* stream);
+/* per-channel sum / sum of squares over (N,HW) into sums[2*C] (double).  sums_are_zero != 0: the caller
+ * hands in a buffer that is already zero (e.g. a slice of an arena cleared once per step) and the memset
+ * launch is skipped. */
+int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, int sums_are_zero, void* stream);
 /* y = act( (x-mean)*invstd*gamma + beta + residual ).
  * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
  *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and
@@ -128,7 +130,7 @@ int dynmm_bn_apply(const float* x, const double* sums, const float* gamma, const
  * (gamma, beta required in that case) — which saves one tensor read in each of the two backward passes. */
 int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x,
                         const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        double* sums, int N, int C, int HW, int act, void* stream);
+                        double* sums, int N, int C, int HW, int act, int sums_are_zero, void* stream);
 /* dx = gamma*invstd*(g_eff - sum_g/M - xhat*sum_gx/M) (training) or gamma*invstd*g_eff (eval);
  * d_residual = g_eff (optional); dgamma/dbeta from sums. */
 int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x,
