@@ -568,6 +568,7 @@ class _Upsample2xDw(Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.has_skip = skip is not None
+        ctx.w_param, ctx.b_param = weight, bias
         return y
 
     @staticmethod
@@ -577,11 +578,14 @@ class _Upsample2xDw(Function):
         g = _chk(g, 'grad')
         N, Cc, H, W = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
-        db = torch.empty(Cc, device=g.device, dtype=torch.float32) if (ctx.has_bias and dw is not None) else None
+        dw = dw_ret = db = db_ret = None
+        if ctx.needs_input_grad[1]:
+            dw, dw_ret = _grad_dst(ctx.w_param)
+            if ctx.has_bias:
+                db, db_ret = _grad_dst(ctx.b_param)
         L.check(lib.dynmm_upsample2x_dw3x3_bwd(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), N, Cc, H, W,
                                                _stream()), 'upsample_bwd')
-        return dx, dw, db, (g if ctx.has_skip else None)
+        return dx, dw_ret, db_ret, (g if ctx.has_skip else None)
 
 
 def upsample2x_dw3x3(x, weight, bias, skip=None):
@@ -633,6 +637,7 @@ class _SEFuseBlend(Function):
         ctx.use_se = use_se
         ctx.col = col
         ctx.n_params = len(params)
+        ctx.param_objs = list(params)
         ctx.save_for_backward(rgb, depth, wcum, a, b, sr, sd, hr, hd, gr, gd, *params)
         return out
 
@@ -648,11 +653,12 @@ class _SEFuseBlend(Function):
         f32 = dict(device=g.device, dtype=torch.float32)
         da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
         L.check(lib.dynmm_axpby_bwd_reduce(_p(g), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, HW, st), 'axpby_bwd_reduce')
-        dparams = [None] * ctx.n_params
+        dparams = dparams_ret = [None] * ctx.n_params
         dsr = dsd = None
         parr = dparr = None
         if ctx.use_se:
-            dparams = [torch.empty_like(p) for p in params]
+            pairs = [_grad_dst(po) for po in ctx.param_objs]     # straight into the flat .grad views when possible
+            dparams, dparams_ret = [d for d, _ in pairs], [r for _, r in pairs]
             parr, dparr = _ptr_array(params), _ptr_array(dparams)
             dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
         dwcum = None
@@ -669,7 +675,7 @@ class _SEFuseBlend(Function):
         drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
         L.check(lib.dynmm_axpby_bwd_apply(_p(g), _p(a), _p(b), _p(dsr), _p(dsd), 1.0 / HW,
                                           _p(drgb), _p(ddepth), N * Cc, HW, st), 'axpby_bwd_apply')
-        return (drgb, ddepth, dwcum, None, None, *dparams)
+        return (drgb, ddepth, dwcum, None, None, *dparams_ret)
 
 
 def se_fuse_blend(rgb, depth, se_params=None, wcum=None, col=0):
@@ -732,6 +738,7 @@ class _ReweighFuse(Function):
         out = torch.empty_like(rgb)
         L.check(lib.dynmm_axpby_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(out), N * Cc, HW, st), 'axpby_fwd')
         ctx.cfg = (int(blend_mode), bool(gate), float(temp), len(params))
+        ctx.param_objs = list(params)
         ctx.save_for_backward(rgb, depth, wblend, prev, a, b, sr, sd, h, gg, aux, *params)
         if gate:
             ctx.mark_non_differentiable(aux)
@@ -757,12 +764,13 @@ class _ReweighFuse(Function):
             L.check(lib.dynmm_axpby_bwd_reduce(_p(g), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, HW, st),
                     'axpby_bwd_reduce')
             d_wblend = torch.empty((N, 2), **f32)
-        dparams = [None] * n_params
+        dparams = dparams_ret = [None] * n_params
         dsr = dsd = d_prev = parr = dparr = None
         gate_bwd = gate and d_wnext is not None
         if gate_bwd:
             d_wnext = _chk(d_wnext, 'd_wnext')
-            dparams = [torch.empty_like(p_) for p_ in params]
+            pairs = [_grad_dst(po) for po in ctx.param_objs]
+            dparams, dparams_ret = [d for d, _ in pairs], [r for _, r in pairs]
             parr, dparr = _ptr_array(params), _ptr_array(dparams)
             dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
             if prev is not None and ctx.needs_input_grad[3]:
@@ -774,7 +782,7 @@ class _ReweighFuse(Function):
         drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
         L.check(lib.dynmm_axpby_bwd_apply(_p(g), _p(a), _p(b), _p(dsr), _p(dsd), 1.0 / HW,
                                           _p(drgb), _p(ddepth), N * Cc, HW, st), 'axpby_bwd_apply')
-        return (drgb, ddepth, d_wblend, d_prev, None, None, None, None, None, *dparams)
+        return (drgb, ddepth, d_wblend, d_prev, None, None, None, None, None, *dparams_ret)
 
 
 def reweigh_fuse(rgb, depth, wblend=None, blend_mode=1, gate_params=None, temp=1.0, hard=False, prev=None,
@@ -806,6 +814,7 @@ class _GateHead(Function):
         L.check(lib.dynmm_gate_head_fwd(_p(pooled), _p(fc), _p(weight), _p(wcum), _p(soft), _p(loss),
                                         _p(flop_table), N, J, float(temp), int(hard), 0, _stream()), 'gate_head_fwd')
         ctx.temp = float(temp)
+        ctx.fc_param = fc
         ctx.save_for_backward(pooled, fc, soft, flop_table)
         return weight, wcum, loss
 
@@ -817,11 +826,11 @@ class _GateHead(Function):
         J = pooled.numel() // N
         d_weight, d_wcum, d_loss = _chk(d_weight), _chk(d_wcum), _chk(d_loss)
         d_pooled = torch.empty_like(pooled)
-        d_fc = torch.empty_like(fc)
+        d_fc, d_fc_ret = _grad_dst(ctx.fc_param)
         L.check(lib.dynmm_gate_head_bwd(_p(d_weight), _p(d_wcum), _p(d_loss), _p(pooled), _p(fc), _p(soft),
                                         _p(flop_table), _p(d_pooled), _p(d_fc), N, J, ctx.temp, _stream()),
                 'gate_head_bwd')
-        return d_pooled, d_fc, None, None, None
+        return d_pooled, d_fc_ret, None, None, None
 
 
 def gate_head(pooled, fc_weight, flop_table, temp, hard):
