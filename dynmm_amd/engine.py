@@ -50,6 +50,7 @@ class SGDNesterov:
 
     def step(self):
         lib = L.load()
+        ops.note_mutation()                 # parameters are rewritten through raw pointers
         L.check(lib.dynmm_sgd_nesterov(self.p.data_ptr(), self.g.data_ptr(), self.buf.data_ptr(),
                                        C.c_size_t(self.p.numel()), self.lr.data_ptr(), self.momentum,
                                        self.weight_decay, 1.0, torch.cuda.current_stream().cuda_stream),
@@ -132,6 +133,7 @@ class TrainStep:
         for a, b in zip(s_t, targets):
             a.copy_(b)
         self._graph.replay()
+        ops.note_mutation()                 # the replayed step updated running statistics / parameters
         if self.reducer.world > 1:
             self.reducer.finish()
             self.opt.step()

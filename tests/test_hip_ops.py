@@ -386,3 +386,34 @@ def test_conv2d_split_precision(ops, precision, tol, gtol, case):
     assert rel(y_inf, y_ref) < tol and rel(y, y_ref) < tol
     assert rel(xg.grad, xr.grad) < gtol
     assert rel(wg.grad, wr.grad) < GTOL           # weight gradients stay on the fp32 kernel
+
+
+def test_fused_eval_cache_follows_parameter_changes(ops):
+    """conv2d_fused_eval caches the packed weights / folded BN per layer; every way the tensors can change
+    (in-place torch ops, a training forward that rewrites the running statistics inside our kernel, a new
+    storage after .to()/load_state_dict) must invalidate it."""
+    conv = torch.nn.Conv2d(64, 64, (3, 1), padding=(1, 0)).cuda()
+    bn = torch.nn.BatchNorm2d(64, eps=1e-3).cuda()
+    x = rnd(2, 64, 8, 8, seed=1).cuda()
+
+    def hip():
+        bn.eval()
+        with torch.no_grad():
+            return ops.conv2d_fused_eval(x, conv.weight, conv.bias, bn, 'relu', None, 1, (1, 0))
+
+    def ref():
+        bn.eval()
+        with torch.no_grad():
+            return F.relu(bn(F.conv2d(x, conv.weight, conv.bias, 1, (1, 0))))
+    assert rel(hip(), ref().cpu()) < TOL
+    assert rel(hip(), ref().cpu()) < TOL                      # cached path
+    with torch.no_grad():
+        conv.weight.mul_(1.5)                                  # in-place: version counter
+    assert rel(hip(), ref().cpu()) < TOL
+    bn.train()
+    ops.batch_norm_act(rnd(4, 64, 8, 8, seed=2).cuda() * 3 + 1, bn, 'relu')   # running stats rewritten in-kernel
+    assert float(bn.running_mean.abs().max()) > 0.05
+    assert rel(hip(), ref().cpu()) < TOL
+    sd = {k: v.clone() + 0.25 for k, v in bn.state_dict().items() if v.dtype.is_floating_point}
+    bn.load_state_dict(sd, strict=False)
+    assert rel(hip(), ref().cpu()) < TOL
