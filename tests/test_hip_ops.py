@@ -417,3 +417,21 @@ def test_fused_eval_cache_follows_parameter_changes(ops):
     sd = {k: v.clone() + 0.25 for k, v in bn.state_dict().items() if v.dtype.is_floating_point}
     bn.load_state_dict(sd, strict=False)
     assert rel(hip(), ref().cpu()) < TOL
+
+
+def test_conv_gradients_are_run_to_run_reproducible(ops):
+    """Weight / bias gradients come from slab partials reduced in a fixed order (no float atomics) and the
+    dgrad has no split-K at all: repeated launches must be bit-identical."""
+    x = rnd(4, 128, 30, 40, seed=1).cuda()
+    w = (rnd(128, 128, 3, 1, seed=2) * 0.05).cuda()
+    b = (rnd(128, seed=3) * 0.1).cuda()
+    gy = rnd(4, 128, 30, 40, seed=4).cuda()
+    res = []
+    for _ in range(3):
+        xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv2d(xg, wg, bg, 1, (1, 0), 'relu')
+        y.backward(gy)
+        res.append((y.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone()))
+    for r in res[1:]:
+        for a, bb in zip(res[0], r):
+            assert torch.equal(a, bb)
