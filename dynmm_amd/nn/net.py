@@ -202,15 +202,18 @@ class SkipGateESANet(nn.Module):
         d = ops.max_pool_3x3_s2(d)
 
         bs = r.shape[0]
+        host_branch = None                                           # branch per sample when the host already knows it
         if self.baseline:                                            # …globalgate.py:264-266
             onehot = torch.zeros(bs, 5, device=rgb.device)
             onehot[:, 4] = 1
             weight, wcum, loss = ops.gate_from_weight(onehot, tab)
+            host_branch = [4] * bs
         elif self.ini_stage:                                         # …globalgate.py:267-270 (CPU RNG)
             onehot = torch.zeros(bs, 5)
             idx = torch.randint(0, 5, (bs,)) if self.ini_branches is None else torch.as_tensor(self.ini_branches)[:bs]
             onehot[torch.arange(bs), idx] = 1
             weight, wcum, loss = ops.gate_from_weight(onehot.to(rgb.device), tab)
+            host_branch = [int(v) for v in idx.tolist()]
         else:
             pooled = self.gate_layer.features(r, d)
             weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate)
@@ -219,7 +222,8 @@ class SkipGateESANet(nn.Module):
 
         one_hot = self.baseline or self.ini_stage or self.hard_gate
         compacted = self.compact and one_hot and not self.training and not torch.is_grad_enabled()
-        branch = weight.argmax(1).tolist() if compacted else None     # ONE host sync per forward
+        # hard gates: ONE device->host read per forward; baseline / ini_stage decisions were made on the host
+        branch = (host_branch if host_branch is not None else weight.argmax(1).tolist()) if compacted else None
         alive = list(range(bs))                  # samples whose depth features are still being computed
         self.last_stage_batch = [] if compacted else None
 
