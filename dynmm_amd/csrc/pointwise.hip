@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) upsample_fwd_kernel(const float* __restri
 __global__ void __launch_bounds__(256) upsample_bwd_dx_kernel(const float* __restrict__ g,
                                                               const float* __restrict__ wgt,
                                                               float* __restrict__ dx, int C, int H,
-                                                              int W) {
+                                                              int W, int pairs) {
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % C);
     const int H2 = 2 * H, W2 = 2 * W;
@@ -325,6 +325,29 @@ __global__ void __launch_bounds__(256) upsample_bwd_dx_kernel(const float* __res
             e[a][bb] = s;
         }
     const int HW = H * W;
+    if (pairs) {
+        // two adjacent input pixels per lane: their 4x6 patch of g is one 16-byte load + two edge scalars per
+        // row, and the result is one 8-byte store (half the load instructions of the one-pixel form below)
+        const int Wh = W / 2, items = H * Wh;
+        const int beg = blockIdx.y * (kChunk / 2), end = min(items, beg + kChunk / 2);
+        for (int it = beg + threadIdx.x; it < end; it += 256) {
+            const int ih = it / Wh, iw = (it - ih * Wh) * 2;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int oh = 2 * ih + a - 1;
+                if (oh < 0 || oh >= H2) continue;
+                const float* row = gp + (size_t)oh * W2;
+                const float4 m = *reinterpret_cast<const float4*>(row + 2 * iw);       // cols 2iw .. 2iw+3
+                const float lft = iw > 0 ? row[2 * iw - 1] : 0.f;
+                const float rgt = iw + 2 < W ? row[2 * iw + 4] : 0.f;
+                s0 += e[a][0] * lft + e[a][1] * m.x + e[a][2] * m.y + e[a][3] * m.z;
+                s1 += e[a][0] * m.y + e[a][1] * m.z + e[a][2] * m.w + e[a][3] * rgt;
+            }
+            *reinterpret_cast<float2*>(dx + plane * HW + (size_t)ih * W + iw) = make_float2(s0, s1);
+        }
+        return;
+    }
     const int beg = blockIdx.y * kChunk, end = min(HW, beg + kChunk);
     for (int i = beg + threadIdx.x; i < end; i += 256) {
         const int ih = i / W, iw = i - ih * W;
@@ -655,7 +678,8 @@ extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const 
     if (!g || !w || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     if (dx) {
         dim3 grid(N * C, plane_chunks(H * W, kChunk));
-        hipLaunchKernelGGL(upsample_bwd_dx_kernel, grid, dim3(256), 0, ST, g, w, dx, C, H, W);
+        const int pairs = (W % 2 == 0) && aligned16(g) && ((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
+        hipLaunchKernelGGL(upsample_bwd_dx_kernel, grid, dim3(256), 0, ST, g, w, dx, C, H, W, pairs);
         DYNMM_LAUNCH_CHECK();
     }
     if (dw) {
