@@ -49,15 +49,21 @@ CFGS = {
     'P_add': dict(encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='add'),
     'S_se': dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='SE-add'),
     'S_add': dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='add'),
+    # the reference constructor's defaults: ResNet-18 encoders, BasicBlock, one decoder block per module
+    'R18_se': dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='SE-add', encoder='resnet18',
+                   nr_decoder_blocks=[1, 1, 1]),
 }
 MODES = ['eval_baseline', 'eval_soft', 'eval_hard', 'eval_ini', 'train_soft', 'train_hard']
 STRIDE = 8
 
 
 def build(cfg, h, w):
-    m = SkipGateESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34',
-                       encoder_depth='resnet34', channels_decoder=[128, 128, 128],
-                       nr_decoder_blocks=[3, 3, 3], pretrained_on_imagenet=False, **CFGS[cfg])
+    kw = dict(CFGS[cfg])
+    enc = kw.pop('encoder', 'resnet34')
+    nb = kw.pop('nr_decoder_blocks', [3, 3, 3])
+    m = SkipGateESANet(height=h, width=w, num_classes=40, encoder_rgb=enc,
+                       encoder_depth=enc, channels_decoder=[128, 128, 128],
+                       nr_decoder_blocks=nb, pretrained_on_imagenet=False, **kw)
     synth.fill_state_dict(m.state_dict(), seed=0)
     return m
 
@@ -122,6 +128,8 @@ def run_mode(cfg, h, w, n, mode):
             sd = m.state_dict()
             for name in ('encoder_rgb.bn1', 'encoder_depth.layer3.2.bn2', 'gate_layer.conv.4',
                          'context_module.features.0.1.bn', 'decoder.decoder_module_3.conv3x3.bn'):
+                if name + '.running_mean' not in sd:          # e.g. layer3.2 does not exist in ResNet-18
+                    continue
                 res['rm:' + name] = sd[name + '.running_mean'].numpy().copy()
                 res['rv:' + name] = sd[name + '.running_var'].numpy().copy()
         else:
@@ -346,6 +354,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'contract':
         contract_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'r18':
+        model_fixture('R18_se', 96, 128, 2, ['eval_hard', 'train_soft'])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'skip':
         skip_fixture()
         sys.exit(0)
@@ -360,6 +371,7 @@ if __name__ == '__main__':
     model_fixture('S_se', 96, 128, 2, ['eval_hard', 'train_soft'])
     model_fixture('S_add', 96, 128, 2, ['eval_baseline'])
     model_fixture('P_se', 160, 192, 3, ['eval_hard', 'train_soft'])
+    model_fixture('R18_se', 96, 128, 2, ['eval_hard', 'train_soft'])
     nyu8_fixture()
     skip_fixture()
     print('done')

@@ -10,6 +10,7 @@ CFGS = {
     'P_add': O.Config(encoder_block='NonBottleneck1D', fuse='add'),
     'S_se': O.Config(encoder_block='BasicBlock', fuse='SE-add'),
     'S_add': O.Config(encoder_block='BasicBlock', fuse='add'),
+    'R18_se': O.Config(encoder='resnet18', encoder_block='BasicBlock', fuse='SE-add', nr_decoder_blocks=[1, 1, 1]),
 }
 
 
@@ -18,7 +19,8 @@ def state_dict_template(cfg: O.Config):
     (the reference is not importable on the GPU box).  Checked against the reference's 907-entry
     contract in tests/test_contract.py."""
     from dynmm_amd.nn.net import SkipGateESANet
-    m = SkipGateESANet(height=96, width=128, encoder_block=cfg.encoder_block,
+    m = SkipGateESANet(height=96, width=128, encoder_rgb=cfg.encoder, encoder_depth=cfg.encoder,
+                       encoder_block=cfg.encoder_block,
                        fuse_depth_in_rgb_encoder=cfg.fuse, channels_decoder=cfg.channels_decoder,
                        nr_decoder_blocks=cfg.nr_decoder_blocks, num_classes=cfg.num_classes)
     return {k: v.clone() for k, v in m.state_dict().items()}

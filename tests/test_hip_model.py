@@ -22,7 +22,9 @@ GRAD_FULL_TOL = 0.25
 def hip_model(cfg_name, h, w, seed=0):
     from dynmm_amd.nn.net import SkipGateESANet
     cfg = Hh.CFGS[cfg_name]
-    m = SkipGateESANet(height=h, width=w, encoder_block=cfg.encoder_block, fuse_depth_in_rgb_encoder=cfg.fuse)
+    m = SkipGateESANet(height=h, width=w, encoder_rgb=cfg.encoder, encoder_depth=cfg.encoder,
+                       encoder_block=cfg.encoder_block, fuse_depth_in_rgb_encoder=cfg.fuse,
+                       nr_decoder_blocks=cfg.nr_decoder_blocks)
     synth.fill_state_dict(m.state_dict(), seed)
     return m.cuda()
 
@@ -49,7 +51,8 @@ class fixed_randint:
         torch.randint = self.real
 
 
-MODEL_FIXTURES = [('P_se', 96, 128), ('P_add', 96, 128), ('S_se', 96, 128), ('S_add', 96, 128), ('P_se', 160, 192)]
+MODEL_FIXTURES = [('P_se', 96, 128), ('P_add', 96, 128), ('S_se', 96, 128), ('S_add', 96, 128), ('P_se', 160, 192),
+                  ('R18_se', 96, 128)]
 
 
 @pytest.mark.parametrize('cfg,h,w', MODEL_FIXTURES)
