@@ -3,11 +3,17 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one synthetic batch: forward (dual ResNet-34
-NonBottleneck1D encoders, SE fusion, global gate with soft DiffSoftmax gates tau=1, PPM, ESANet
-decoder, 4 training outputs) + weighted multi-scale CE + FLOP regulariser + full backward, batch
-32/GPU at 480x640 (BASELINE.json configs[2], the configuration `metric` is quoted on).  N>1 = pure
-data parallel, weak scaling, gradients all-reduced over RCCL.  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one synthetic batch resident in HBM: zero grads, forward (dual
+ResNet-34 NonBottleneck1D encoders, SE fusion, global gate with soft DiffSoftmax gates tau=1, PPM, ESANet
+decoder, 4 training outputs), weighted multi-scale CE + FLOP regulariser, full backward, [gradient all-reduce],
+fused SGD-Nesterov update — batch 32/GPU at 480x640 (BASELINE.json configs[2], the configuration `metric` is
+quoted on).  N>1 = pure data parallel, weak scaling, gradient buckets all-reduced over RCCL while backward is
+still running.  Prints ONE JSON line on rank 0; besides the contract's fields it carries
+  roofline      dominant implicit-GEMM kernel vs the fp32 MFMA peak (HIP events on the launch stream),
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch CPU path) on this host's cores,
+  parity        the HIP step vs that same oracle run (logits, losses, gradient cosine) — same inputs,
+  extra         configs[1] (fwd-only, batch 16, gate forced on) and configs[3]-style hard-gate lines measured
+                in the same process.
 """
 import argparse
 import json
@@ -15,18 +21,23 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from dynmm_amd import dp, ops, synth                        # noqa: E402
+from dynmm_amd import dp, engine, ops, synth                # noqa: E402
 from dynmm_amd.nn.net import SkipGateESANet                 # noqa: E402
 from dynmm_amd.nn.net_skip import SkipESANet                # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 GFLOP_PER_IMG_FWD_BWD = {'P': 222.98, 'S': 300.8}   # BASELINE.md §2 (conv MACs x2, fwd+bwd)
+GFLOP_PER_IMG_FWD = {'P': 74.67, 'S': 100.62}
+TRAFFIC_NOTE = ('raw FETCH_SIZE+WRITE_SIZE per launch from profiles/pmc_dominant_kernel.json (separate --pmc passes); '
+                'the guide\'s x2 FETCH correction is calibrated for 16 B/lane streams only and this kernel gathers '
+                '4 B/lane, so the read side is uncalibrated: treat as a lower bound / for A-B ratios')
 
 
 def parse():
@@ -42,20 +53,27 @@ def parse():
                     help="gate: SkipGateESANet (global gate, the north-star line); skip: SkipESANet (per-stage Gumbel "
                          "gates, block_rule 2222) — a side measurement, SURVEY.md §8f-3")
     ap.add_argument('--mode', default='train', choices=['train', 'fwd'],
-                    help="train: fwd+bwd soft gates (configs[2]); fwd: eval forward, gate forced on (configs[1])")
+                    help="train: fwd+bwd+update (configs[2]; with --hard: configs[3]); fwd: eval forward (configs[1])")
+    ap.add_argument('--hard', action='store_true',
+                    help='--mode train: hard one-hot gates with a FIXED synthetic branch distribution (--branches), '
+                         'the per-GPU part of BASELINE configs[3]')
     ap.add_argument('--branches', default='all4', choices=['all4', 'uniform', 'all0'],
-                    help='--mode fwd only: per-sample gate branch (hard one-hot); uniform = k = n %% 5. '
-                         'With K16 compaction depth stage j runs on the samples with k >= j only')
+                    help='per-sample gate branch (hard one-hot): all4 = every sample fuses at every stage, uniform = '
+                         'k = n %% 5, all0 = every sample skips depth after the stem.  With compaction depth stage j '
+                         'runs on the samples with k >= j only')
+    ap.add_argument('--compact', action='store_true',
+                    help='--mode train --hard: gate-decision compaction in TRAINING (approximate: BatchNorm statistics '
+                         'of depth stage j are taken over the samples that run it; see DESIGN.md §K16)')
     ap.add_argument('--no-compact', action='store_true', help='--mode fwd: disable K16 compaction (dense reference semantics)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step as one hipGraph.  Default is eager multi-stream launches: the step is '
                          'GPU-bound at batch 32 (eager == graph on one stream) and the 3-stream schedule '
                          '(RGB encoder | depth encoder | weight gradients) overlaps better un-captured')
-    ap.add_argument('--no-graph', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--single-stream', action='store_true', help='disable the depth-encoder and wgrad side streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary lines (configs[1] fwd-only, hard-gate)')
     return ap.parse_args()
 
 
@@ -72,75 +90,162 @@ def make_model(cfg, h, w, device, kind='gate'):
 
 
 def make_batch(n, h, w, device, seed):
-    g = torch.Generator(device=device).manual_seed(seed)
-    rgb = torch.randn(n, 3, h, w, device=device, generator=g)
-    depth = torch.randn(n, 1, h, w, device=device, generator=g)
-    labels = [torch.randint(0, 41, (n, h // s, w // s), device=device, generator=g, dtype=torch.uint8)
-              for s in (1, 8, 16, 32)]
-    return rgb, depth, labels
+    """Synthetic batch generated on the host (so the CPU oracle can see the same values) and made resident."""
+    g = torch.Generator().manual_seed(seed)
+    rgb = torch.randn(n, 3, h, w, generator=g)
+    depth = torch.randn(n, 1, h, w, generator=g)
+    labels = [torch.randint(0, 41, (n, h // s, w // s), generator=g, dtype=torch.uint8) for s in (1, 8, 16, 32)]
+    return rgb.to(device), depth.to(device), [t.to(device) for t in labels]
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's PyTorch CPU path, pinned to it by tests/golden) timed on
-    this host's cores on a bounded sample of the same workload."""
+def branches_for(kind, n):
+    return [(i % 5) if kind == 'uniform' else (4 if kind == 'all4' else 0) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle on this host's cores) + parity of the HIP step against that same run
+# ---------------------------------------------------------------------------------------------------
+def host_cpu():
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name') and model == 'unknown':
+                model = ln.split(':', 1)[1].strip()
+            elif ln.startswith('physical id'):
+                phys = ln.split(':', 1)[1].strip()
+            elif ln.startswith('core id'):
+                core = ln.split(':', 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
+
+
+def cpu_baseline_and_parity(args, device):
+    """Times the oracle's step on a bounded sample (batch args.cpu_batch of the same workload) for several thread
+    counts and keeps the best; the last oracle run is also the checker for one HIP step on identical inputs."""
     from oracle import dynmm_oracle as O
     n = args.cpu_batch
     cfg = O.Config(encoder_block='NonBottleneck1D' if args.config == 'P' else 'BasicBlock', fuse='SE-add')
     m = make_model(args.config, args.height, args.width, 'cpu', args.model)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k]
-    rgb, depth, labels = make_batch(n, args.height, args.width, 'cpu', 1234)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+    rgb, depth, labels = make_batch(n, args.height, args.width, 'cpu', 4321)
     cw = torch.linspace(0.5, 2.0, 40)
-    cores = torch.get_num_threads()
-
     noise = [torch.empty(n, 2).exponential_() for _ in range(4)]
+    train = args.mode == 'train'
+    keep = {}
 
     def one():
-        if args.mode == 'fwd':
+        sd_run = {k: (v.detach().clone() if 'running_' in k or not v.dtype.is_floating_point else v) for k, v in sd.items()}
+        if not train:
             with torch.no_grad():
                 if args.model == 'skip':
-                    O.forward_skip(sd, rgb, depth, cfg, noise, test=True)
+                    keep['out'] = O.forward_skip(sd_run, rgb, depth, cfg, noise, test=True)
                 else:
-                    O.forward(sd, rgb, depth, cfg, test=True, baseline=True)
+                    keep['out'] = O.forward(sd_run, rgb, depth, cfg, test=True, baseline=True)
             return
-        for p in params:
+        for p in params.values():
             p.grad = None
         if args.model == 'skip':
-            outs, lf = O.forward_skip(sd, rgb, depth, cfg, noise, training=True), 0.0
+            outs, lf = O.forward_skip(sd_run, rgb, depth, cfg, noise, training=True), torch.zeros(())
         else:
-            outs, lf = O.forward(sd, rgb, depth, cfg, training=True, temp=1.0)
+            outs, lf = O.forward(sd_run, rgb, depth, cfg, training=True, temp=1.0)
         losses = O.cross_entropy_2d(outs, labels, cw)
-        (sum(losses) + lf).backward()
+        total = sum(losses) + torch.clamp(lf, min=0.0)
+        total.backward()
+        keep.update(out=outs[0].detach(), losses=torch.stack([l.detach() for l in losses]), lf=lf.detach(),
+                    total=total.detach())
 
-    one()
+    model_name, phys, logical = host_cpu()
+    default_threads = torch.get_num_threads()
+    cands = sorted({t for t in (phys, 64, 32, 16, default_threads) if 1 <= t <= logical}, reverse=True)
+    sweep, best = {}, None
+    one()                                              # warm-up (allocator, oneDNN primitive caches)
+    for t in cands:
+        torch.set_num_threads(t)
+        one()                                          # settle the thread pool at this width
+        t0 = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t0
+        sweep[t] = round(n / dt, 4)
+        if best is None or dt < best[1]:
+            best = (t, dt)
+    torch.set_num_threads(best[0])
     times = []
-    for _ in range(3):
+    for _ in range(2):
         t0 = time.perf_counter()
         one()
         times.append(time.perf_counter() - t0)
-    med = sorted(times)[1]
-    return {'value': round(n / med, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle (PyTorch CPU fp32, {cores} threads), batch {n} of the same {args.height}x{args.width} '
-                      f'{args.mode} step, median of 3 after 1 warm-up'}
+    med = min(best[1], sorted(times)[0])
+    torch.set_num_threads(default_threads)
+    cpu = {'value': round(n / med, 4), 'unit': 'images/s', 'cores': best[0], 'kind': 'port',
+           'cpu_model': model_name, 'physical_cores': phys, 'logical_cpus': logical,
+           'threads_sweep_images_per_s': {str(k): v for k, v in sweep.items()},
+           'sample': f'oracle (PyTorch CPU fp32), batch {n} of the same {args.height}x{args.width} {args.mode} step '
+                     f'(fwd + weighted 4-scale CE + flop loss + bwd); thread sweep {cands}, best of 3 timed runs at the '
+                     f'winning width ({best[0]} threads)'}
+
+    # ---- parity: the HIP path on the same inputs, against the oracle run above ----
+    parity = None
+    if args.model == 'gate':
+        mh = make_model(args.config, args.height, args.width, device, args.model)
+        if train:
+            mh.train()
+            mh.temp, mh.hard_gate = 1.0, False
+            st = engine.TrainStep(mh, cw.numpy(), lr=0.0, loss_ratio=1.0, flop_budget=0.0, multi_stream=not args.single_stream)
+            got = {}
+            fwd = mh.forward
+
+            def spy(*a, **k):
+                r = fwd(*a, **k)
+                got['out'] = r[0][0].detach()
+                return r
+            mh.forward = spy
+            st._body(rgb.to(device), depth.to(device), [t.to(device) for t in labels])
+            torch.cuda.synchronize()
+            hp = dict(mh.named_parameters())
+            names = [k for k in params if params[k].grad is not None and k in hp]
+            a = torch.cat([hp[k].grad.detach().cpu().double().flatten() for k in names])
+            b = torch.cat([params[k].grad.double().flatten() for k in names])
+            parity = {
+                'logits_rel': float(((got['out'].cpu() - keep['out']).abs().max() / keep['out'].abs().max()).item()),
+                'loss_abs': float((st.last['losses'].cpu() - keep['losses']).abs().max().item()),
+                'loss_flop_abs': float(abs(st.last['loss_flop'].item() - keep['lf'].item())),
+                'total_rel': float(abs(st.last['total'].item() - keep['total'].item()) / abs(keep['total'].item())),
+                'grad_cos': float(torch.nn.functional.cosine_similarity(a, b, dim=0).item()),
+                'grad_norm_ratio': float((a.norm() / b.norm()).item()),
+                'batch': n,
+                'note': 'HIP TrainStep body vs the fp32 CPU oracle (the cpu_baseline run) on identical inputs/weights; '
+                        'fp32 gradients of this net carry ~1e-2 conditioning noise (fp32 vs fp64 oracle, DESIGN.md §1), '
+                        'per-tensor bars are in tests/test_hip_model.py'}
+            del st
+        else:
+            mh.eval()
+            mh.baseline = True
+            with torch.no_grad():
+                out = mh(rgb.to(device), depth.to(device), test=True)
+            parity = {'logits_rel': float(((out.cpu() - keep['out']).abs().max() / keep['out'].abs().max()).item()),
+                      'batch': n}
+        del mh
+        torch.cuda.empty_cache()
+    return cpu, parity
 
 
-model_ref = [None]
-
-
-def kernel_timing(step_fn):
+# ---------------------------------------------------------------------------------------------------
+# per-kernel timing (roofline leg)
+# ---------------------------------------------------------------------------------------------------
+def kernel_timing(step_fn, model):
     """One instrumented EAGER step: HIP events around every implicit-GEMM launch on the stream it is
     launched on.  Returns per-kernel-variant totals (launches, ms, algorithmic GFLOP)."""
     # isolated per-kernel durations: the instrumented pass runs on ONE stream (in the timed region the
     # RGB / depth / wgrad streams overlap, which inflates every individual kernel's wall duration)
-    saved = (ops.ASYNC_WGRAD, getattr(model_ref[0], 'dual_stream', False))
-    ops.ASYNC_WGRAD = False
-    model_ref[0].dual_stream = False
     torch.cuda.synchronize()
     ops.PROFILE = []
     step_fn()
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
-    ops.ASYNC_WGRAD, model_ref[0].dual_stream = saved
     agg, shapes = {}, {}
     for name, flops, e0, e1, shape in rec:
         ms = e0.elapsed_time(e1)
@@ -157,6 +262,118 @@ def kernel_timing(step_fn):
     return agg
 
 
+def roofline_of(agg):
+    if not agg:
+        return None
+    name, (launches, ms, flops) = max(agg.items(), key=lambda kv: kv[1][1])
+    achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+            'traffic_note': TRAFFIC_NOTE if traffic is not None else None,
+            'kernel': name, 'launches_per_step': launches,
+            'avg_launch_us': round(1000.0 * ms / launches, 2),
+            'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
+            'all_igemm_kernels': {k: {'launches': v[0], 'ms': round(v[1], 3),
+                                      'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                                  for k, v in sorted(agg.items())}}
+
+
+def timed(step, steps, warmup, world, device):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
+def train_workload(args, device, rank, world, hard=False, branches='all4', compact=False):
+    """(step callable, TrainStep, model).  The step is the product's own engine.TrainStep."""
+    model = make_model(args.config, args.height, args.width, device, args.model)
+    dp.broadcast_parameters(model)
+    rgb, depth, labels = make_batch(args.batch, args.height, args.width, device, 1234 + rank)
+    cw = np.linspace(0.5, 2.0, 40)
+    model.train()
+    model.hard_gate, model.temp = bool(hard), 1.0
+    if hard and args.model == 'gate':
+        # fixed synthetic branch distribution (SURVEY.md §8d): the gate network is evaluated and trained, its hard
+        # decision is replaced by the given branch per sample
+        model.branch_override = branches_for(branches, args.batch)
+        model.compact_train = bool(compact)
+    ts = engine.TrainStep(model, cw, lr=1e-4, momentum=0.9, weight_decay=1e-4, loss_ratio=1.0, flop_budget=0.0,
+                          use_graph=args.graph and not hard, multi_stream=not args.single_stream, overlap=True)
+
+    def step():
+        ts(rgb, depth, labels)
+    return step, ts, model
+
+
+def fwd_workload(args, device, batch, branches='all4', compact=True):
+    model = make_model(args.config, args.height, args.width, device, args.model)
+    rgb, depth, _ = make_batch(batch, args.height, args.width, device, 1234)
+    model.eval()
+    model.compact = compact
+    model.dual_stream = not args.single_stream      # depth-encoder stages on a second HIP stream
+    if args.model == 'gate':
+        if branches == 'all4':
+            model.baseline = True                 # configs[1]: static fuse, gate forced on
+        else:
+            model.ini_stage = True
+            model.ini_branches = branches_for(branches, batch)
+
+    def step():
+        with torch.no_grad():
+            return model(rgb, depth, test=True)
+    return step, model
+
+
+def measure_fwd(args, device, batch, branches, compact, steps, warmup, with_kernels=True):
+    step, model = fwd_workload(args, device, batch, branches, compact)
+    for _ in range(2):
+        step()
+    el = timed(step, steps, warmup, 1, device)
+    val = batch * steps / el
+    out = {'metric': 'images/sec fwd-only, 480x640 RGB-D', 'value': round(val, 2), 'unit': 'images/s',
+           'ms_per_step': round(1000 * el / steps, 3), 'batch': batch, 'branches': branches, 'compaction': bool(compact),
+           'stage_batch': getattr(model, 'last_stage_batch', None),
+           'model_tflops': round(val * GFLOP_PER_IMG_FWD[args.config] / 1e3, 2) if branches == 'all4' else None}
+    if with_kernels:
+        saved = model.dual_stream
+        model.dual_stream = False
+        r = roofline_of(kernel_timing(step, model))
+        model.dual_stream = saved
+        if r:
+            r.pop('all_igemm_kernels', None)
+            r['traffic'] = r['traffic_note'] = None
+            out['roofline'] = r
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -169,145 +386,119 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-
-    model = make_model(args.config, args.height, args.width, device, args.model)
-    model_ref[0] = model
-    dp.broadcast_parameters(model)
-    rgb, depth, labels = make_batch(args.batch, args.height, args.width, device, 1234 + rank)
-    cw = torch.linspace(0.5, 2.0, 40, device=device)
     train = args.mode == 'train'
-    reducer = None
+
+    ts = None
     if train:
-        model.train()
-        model.hard_gate, model.temp = False, 1.0
-        model.dual_stream = not args.single_stream
-        ops.ASYNC_WGRAD = not args.single_stream
-        reducer = dp.GradBucketReducer(model.parameters(), bucket_mb=32, overlap=False)
-        ops.DIRECT_GRAD = True      # kernels write parameter gradients straight into the flat buffer views
+        step, ts, model = train_workload(args, device, rank, world, args.hard, args.branches, args.compact)
     else:
-        model.eval()
-        model.compact = not args.no_compact
-        model.dual_stream = not args.single_stream      # depth-encoder stages on a second HIP stream
-        if args.branches == 'all4':
-            model.baseline = True                 # configs[1]: static fuse, gate forced on
-        else:
-            model.ini_stage = True
-            model.ini_branches = [(i % 5) if args.branches == 'uniform' else 0 for i in range(args.batch)]
-
-    def fwd_bwd():
-        if not train:
-            with torch.no_grad():
-                return model(rgb, depth, test=True)
-        reducer.zero()
-        if args.model == 'skip':
-            outs, total = model(rgb, depth), 0.0
-        else:
-            outs, total = model(rgb, depth)
-        for o, t in zip(outs, labels):
-            total = total + ops.cross_entropy_2d(o, t, cw)
-        total.backward()
-        ops.join_async()
-        return total
-
-    graph = None
-    use_graph = args.graph and (train or args.no_compact)   # compaction reads the branch on the host
-    # warm-up (also initialises lazily-created buffers before capture)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            fwd_bwd()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                fwd_bwd()
-        except Exception as e:   # capture is an optimisation of launch overhead, never a different compute path
-            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); using eager launches', file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    def step():
-        if graph is not None:
-            graph.replay()
-        else:
-            fwd_bwd()
-        if reducer is not None and world > 1:
-            reducer.finish()
-
-    for _ in range(args.warmup):
+        step, model = fwd_workload(args, device, args.batch, args.branches, not args.no_compact)
+    for _ in range(2):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
+    elapsed = timed(step, args.steps, args.warmup, world, device)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = args.batch * world * args.steps / elapsed
 
+    dp_info = None
+    if ts is not None and world > 1:
+        red = ts.reducer
+        dp_info = {'buckets': len(red.buckets), 'launched_during_backward': red.launched_in_backward,
+                   'bucket_mb': round(4 * max(e - s for s, e in red.buckets) / 2 ** 20, 1),
+                   'backend': dist.get_backend()}
+
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
-        agg = kernel_timing(fwd_bwd)
-        if agg:
-            name, (launches, ms, flops) = max(agg.items(), key=lambda kv: kv[1][1])
-            achieved = flops / (ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
-                except Exception:
-                    traffic = None
-            roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                        'kernel': name, 'launches_per_step': launches,
-                        'avg_launch_us': round(1000.0 * ms / launches, 2),
-                        'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
-                        'all_igemm_kernels': {k: {'launches': v[0], 'ms': round(v[1], 3),
-                                                  'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
-                                              for k, v in sorted(agg.items())}}
-    cpu = None
+        if ts is not None:
+            saved = (ts.multi_stream, getattr(model, 'dual_stream', False), ts.use_graph)
+            ts.multi_stream, model.dual_stream, ts.use_graph = False, False, False
+            roofline = roofline_of(kernel_timing(step, model))
+            ts.multi_stream, model.dual_stream, ts.use_graph = saved
+        else:
+            saved = getattr(model, 'dual_stream', False)
+            model.dual_stream = False
+            roofline = roofline_of(kernel_timing(step, model))
+            model.dual_stream = saved
+    stage_batch = getattr(model, 'last_stage_batch', None)
+    del step, ts, model
+    torch.cuda.empty_cache()
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and train and not args.hard and args.model == 'gate':
+        extra = {}
+        # configs[1]: fwd-only, batch 16, static fuse (gate forced on) — measured by the same driver run
+        extra['fwd_only'] = measure_fwd(args, device, 16, 'all4', True, max(10, args.steps), 3)
+        extra['fwd_only']['workload'] = 'configs[1]: fwd-only eval, batch 16, static fuse (gate forced on), BN folded'
+        # configs[3] (per-GPU part): hard gates, fixed uniform branch distribution, with / without compaction
+        d = measure_fwd(args, device, 32, 'uniform', False, max(10, args.steps), 3, with_kernels=False)
+        c = measure_fwd(args, device, 32, 'uniform', True, max(10, args.steps), 3, with_kernels=False)
+        extra['fwd_hard_uniform'] = {'dense': d, 'compacted': c, 'gain': round(c['value'] / d['value'], 4),
+                                     'workload': 'fwd-only eval, batch 32, hard one-hot gates, branch k = n % 5 per sample; '
+                                                 'compacted = depth stage j runs on the samples with k >= j only (exact)'}
+        sub = argparse.Namespace(**vars(args))
+        sub.graph = False
+        res = {}
+        for name, (br, cp) in {'dense_uniform': ('uniform', False), 'compact_uniform': ('uniform', True),
+                               'compact_all0': ('all0', True)}.items():
+            st2, ts2, m2 = train_workload(sub, device, rank, 1, True, br, cp)
+            for _ in range(2):
+                st2()
+            el = timed(st2, max(5, args.steps // 2), 2, 1, device)
+            k = max(5, args.steps // 2)
+            res[name] = {'value': round(args.batch * k / el, 2), 'ms_per_step': round(1000 * el / k, 3), 'branches': br,
+                         'compaction': cp, 'stage_batch': getattr(m2, 'last_stage_batch', None)}
+            del st2, ts2, m2
+            torch.cuda.empty_cache()
+        res['gain_uniform'] = round(res['compact_uniform']['value'] / res['dense_uniform']['value'], 4)
+        res['workload'] = ('configs[3] per GPU: fwd+bwd+update, batch 32, hard one-hot gates with a fixed branch '
+                           'distribution; compaction in training is APPROXIMATE (depth-stage BatchNorm statistics over the '
+                           'taken subset, straight-through gate gradient from the taken stages only) — DESIGN.md')
+        res['unit'] = 'images/s'
+        extra['train_hard'] = res
+
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+        cpu, parity = cpu_baseline_and_parity(args, device)
 
     if rank == 0:
-        gflop_img = GFLOP_PER_IMG_FWD_BWD[args.config] if train else {'P': 74.67, 'S': 100.62}[args.config]
+        gflop_img = GFLOP_PER_IMG_FWD_BWD[args.config] if train else GFLOP_PER_IMG_FWD[args.config]
+        dense_work = (not args.hard or args.branches == 'all4' or not args.compact) if train else \
+            (args.branches == 'all4' or args.no_compact)
+        if args.model == 'gate':
+            if train and not args.hard:
+                workload = ('configs[2]: zero-grad + fwd + weighted 4-scale CE + FLOP loss + bwd + fused SGD-Nesterov update, '
+                            '--dynamic --global-gate soft DiffSoftmax gates tau=1')
+            elif train:
+                workload = (f'configs[3] per GPU: fwd+bwd+update with hard one-hot gates, branches={args.branches}, '
+                            f'compaction={"on (approximate in training)" if args.compact else "off"}')
+            else:
+                workload = 'configs[1]: fwd-only eval, static fuse (gate forced on)' if args.branches == 'all4' else \
+                    f'fwd-only eval, hard gates, branches={args.branches}'
+        else:
+            workload = ('fwd+bwd --dynamic (per-stage Gumbel-softmax gates, block_rule 2222, soft tau=1), weighted 4-scale CE'
+                        if train else 'fwd-only eval test=True (hard Gumbel gates; depth stages run on the still-fusing '
+                                      'samples only unless --no-compact)')
         line = {
             'metric': 'images/sec fwd+bwd, 480x640 RGB-D, batch 32/GPU' if train else
                       'images/sec fwd-only, 480x640 RGB-D, gate forced on',
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': (('configs[2]: fwd+bwd --dynamic --global-gate soft DiffSoftmax gates tau=1, '
-                                     'weighted 4-scale CE + FLOP loss' if train else
-                                     'configs[1]: fwd-only eval, static fuse (gate forced on)') if args.model == 'gate' else
-                                    ('fwd+bwd --dynamic (per-stage Gumbel-softmax gates, block_rule 2222, soft tau=1), '
-                                     'weighted 4-scale CE' if train else 'fwd-only eval test=True (hard Gumbel gates; depth stages run on the still-fusing samples only '
-                                     'unless --no-compact)')),
+            'config': {'workload': workload,
                        'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
                               f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
-                       'branches': None if train else args.branches, 'compaction': None if train else (not args.no_compact),
+                       'branches': args.branches if (args.hard or not train) else None,
+                       'compaction': (args.compact if args.hard else None) if train else (not args.no_compact),
+                       'stage_batch': stage_batch,
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'height': args.height, 'width': args.width,
-                       'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if graph is not None else 'eager',
+                       'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else (3 if train else 2),
-                       'model_tflops': round(value * gflop_img / 1e3, 2),
-                       'model_frac_of_fp32_mfma_peak': round(value * gflop_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)},
-            'roofline': roofline, 'cpu_baseline': cpu,
+                       'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
+                       'dp': dp_info,
+                       'model_tflops': round(value * gflop_img / 1e3, 2) if dense_work else None,
+                       'model_frac_of_fp32_mfma_peak': round(value * gflop_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
+                       if dense_work else None},
+            'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'extra': extra,
         }
         print(json.dumps(line))
     if world > 1:

@@ -70,4 +70,9 @@ __device__ __forceinline__ float act_bwd(float g, float y, int act) {
     return g;
 }
 
+// out[i] = sum_s slabs[s][i] (+ an optional second region) in a fixed order: the deterministic tail of every
+// split reduction in the library (conv_igemm.hip).
+void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipStream_t st,
+                         const float* slabs2 = nullptr, float* out2 = nullptr, int n2 = 0);
+
 }  // namespace dynmm

@@ -913,8 +913,8 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
     }
 }
 
-static void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipStream_t st,
-                                const float* slabs2 = nullptr, float* out2 = nullptr, int n2 = 0) {
+void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipStream_t st,
+                         const float* slabs2, float* out2, int n2) {
     const bool v4 = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15u) == 0) &&
                     ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
                     (n2 == 0 || ((n2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs2) & 15u) == 0) &&

@@ -11,7 +11,6 @@ constexpr int kMaxC = 1024;
 constexpr int kMaxHid = 64;
 
 struct SeParams { const float* p[8]; };   // W1r b1r W2r b2r W1d b1d W2d b2d
-struct SeGrads { float* p[8]; };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
@@ -61,16 +60,18 @@ __global__ void __launch_bounds__(256) se_coeff_fwd_kernel(
     }
 }
 
-// backward of one modality's MLP for one sample.  dg[C] in LDS (grad wrt g), produces ds[C].
-__device__ void se_mlp_bwd(const float* dg, const float* s, const float* h, const float* g,
-                           const float* W1, const float* W2, float* dW1, float* db1, float* dW2,
-                           float* db2, float* dz2_lds, float* dh_lds, float* ds_out, int C, int Hd) {
+// backward of one modality's MLP for one sample.  dg[C] in LDS (grad wrt g), produces ds[C] and this
+// sample's pre-activation gradients dz2[C] (second layer) and dh[Hd] (first layer) in global scratch.  The
+// parameter gradients are sums over the samples of outer products of those with the saved activations; they
+// are formed by mlp_param_grad_kernel in a fixed sample order (no float atomics => bit-reproducible).
+__device__ void se_mlp_bwd(const float* dg, const float* h, const float* g, const float* W1, const float* W2,
+                           float* dz2_lds, float* dh_lds, float* dz2_out, float* dh_out, float* ds_out,
+                           int C, int Hd) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float gg = g[c];
         const float dz = dg[c] * gg * (1.f - gg);
         dz2_lds[c] = dz;
-        atomicAdd(&db2[c], dz);
-        for (int j = 0; j < Hd; ++j) atomicAdd(&dW2[c * Hd + j], dz * h[j]);
+        dz2_out[c] = dz;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
@@ -78,28 +79,86 @@ __device__ void se_mlp_bwd(const float* dg, const float* s, const float* h, cons
         for (int c = 0; c < C; ++c) acc += W2[c * Hd + j] * dz2_lds[c];
         acc = h[j] > 0.f ? acc : 0.f;
         dh_lds[j] = acc;
-        atomicAdd(&db1[j], acc);
+        dh_out[j] = acc;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
-        const float sc = s[c];
-        for (int j = 0; j < Hd; ++j) {
-            const float dh = dh_lds[j];
-            acc += W1[j * C + c] * dh;
-            atomicAdd(&dW1[j * C + c], dh * sc);
-        }
+        for (int j = 0; j < Hd; ++j) acc += W1[j * C + c] * dh_lds[j];
         ds_out[c] = acc;
     }
     __syncthreads();
+}
+
+// Parameter gradients of up to two excitation MLPs (blockIdx.y = which) from the per-sample scratch:
+//   dW1[j][c] = sum_n dh[n][j] s[n][c]   db1[j] = sum_n dh[n][j]
+//   dW2[c][j] = sum_n dz[n][c] h[n][j]   db2[c] = sum_n dz[n][c]          (n ascending: deterministic)
+struct MlpGradJob {
+    const float* s;    // [N][C]  layer-1 input (pooled features)
+    const float* h;    // [N][Hd] layer-1 output (post-ReLU)
+    const float* dz;   // [N][C]  scratch
+    const float* dh;   // [N][Hd] scratch
+    float* dW1; float* db1; float* dW2; float* db2;
+    int s2_split;      // > 0: s is the concatenation [s (first s2_split cols) ; s2] (reweigh gate)
+    const float* s2;
+};
+struct MlpGradJobs { MlpGradJob j[2]; };
+
+__global__ void __launch_bounds__(256) mlp_param_grad_kernel(MlpGradJobs jobs, int N, int C, int Hd) {
+    const MlpGradJob J = jobs.j[blockIdx.y];
+    const int e0 = blockIdx.x * 256 + threadIdx.x;
+    const int nW = Hd * C;
+    if (e0 < nW) {                                   // dW1[j][c]
+        const int j = e0 / C, c = e0 - j * C;
+        float acc = 0.f;
+        if (J.s2_split > 0) {
+            const int c1 = J.s2_split, c2 = C - c1;
+            for (int n = 0; n < N; ++n) {
+                const float sv = c < c1 ? J.s[(size_t)n * c1 + c] : J.s2[(size_t)n * c2 + (c - c1)];
+                acc += J.dh[(size_t)n * Hd + j] * sv;
+            }
+        } else {
+            for (int n = 0; n < N; ++n) acc += J.dh[(size_t)n * Hd + j] * J.s[(size_t)n * C + c];
+        }
+        J.dW1[e0] = acc;
+        return;
+    }
+    int e = e0 - nW;
+    if (e < Hd) {                                    // db1[j]
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += J.dh[(size_t)n * Hd + e];
+        J.db1[e] = acc;
+        return;
+    }
+    e -= Hd;
+    if (e < nW) {                                    // dW2[c][j]
+        const int c = e / Hd, j = e - c * Hd;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += J.dz[(size_t)n * C + c] * J.h[(size_t)n * Hd + j];
+        J.dW2[e] = acc;
+        return;
+    }
+    e -= nW;
+    if (e < C) {                                     // db2[c]
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += J.dz[(size_t)n * C + e];
+        J.db2[e] = acc;
+    }
+}
+
+static int launch_mlp_param_grad(const MlpGradJobs& jobs, int njobs, int N, int C, int Hd, hipStream_t st) {
+    const int total = 2 * Hd * C + Hd + C;
+    hipLaunchKernelGGL(mlp_param_grad_kernel, dim3(ceil_div(total, 256), njobs), dim3(256), 0, st, jobs, N, C, Hd);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
 }
 
 __global__ void __launch_bounds__(256) se_coeff_bwd_kernel(
     const float* __restrict__ da, const float* __restrict__ db, const float* __restrict__ sr,
     const float* __restrict__ sd, SeParams P, const float* __restrict__ wc, int wc_stride,
     const float* __restrict__ hr, const float* __restrict__ hd, const float* __restrict__ gr,
-    const float* __restrict__ gd, SeGrads G, float* __restrict__ dsr, float* __restrict__ dsd,
-    float* __restrict__ dwc, int dwc_stride, int C, int use_se) {
+    const float* __restrict__ gd, float* __restrict__ ws, float* __restrict__ dsr, float* __restrict__ dsd,
+    float* __restrict__ dwc, int dwc_stride, int N, int C, int use_se) {
     __shared__ float dg_lds[kMaxC];
     __shared__ float dz_lds[kMaxC];
     __shared__ float dh_lds[kMaxHid];
@@ -123,12 +182,15 @@ __global__ void __launch_bounds__(256) se_coeff_bwd_kernel(
     if (!use_se) return;
     for (int c = threadIdx.x; c < C; c += blockDim.x) dg_lds[c] = dan[c] * (1.f - w);
     __syncthreads();
-    se_mlp_bwd(dg_lds, sr + (size_t)n * C, hr + (size_t)n * Hd, gr + (size_t)n * C, P.p[0], P.p[2],
-               G.p[0], G.p[1], G.p[2], G.p[3], dz_lds, dh_lds, dsr + (size_t)n * C, C, Hd);
+    // scratch layout: dz_r [N][C] | dh_r [N][Hd] | dz_d [N][C] | dh_d [N][Hd]
+    float* const dz_r = ws, * const dh_r = dz_r + (size_t)N * C;
+    float* const dz_d = dh_r + (size_t)N * Hd, * const dh_d = dz_d + (size_t)N * C;
+    se_mlp_bwd(dg_lds, hr + (size_t)n * Hd, gr + (size_t)n * C, P.p[0], P.p[2], dz_lds, dh_lds,
+               dz_r + (size_t)n * C, dh_r + (size_t)n * Hd, dsr + (size_t)n * C, C, Hd);
     for (int c = threadIdx.x; c < C; c += blockDim.x) dg_lds[c] = dbn[c] * (1.f - w);
     __syncthreads();
-    se_mlp_bwd(dg_lds, sd + (size_t)n * C, hd + (size_t)n * Hd, gd + (size_t)n * C, P.p[4], P.p[6],
-               G.p[4], G.p[5], G.p[6], G.p[7], dz_lds, dh_lds, dsd + (size_t)n * C, C, Hd);
+    se_mlp_bwd(dg_lds, hd + (size_t)n * Hd, gd + (size_t)n * C, P.p[4], P.p[6], dz_lds, dh_lds,
+               dz_d + (size_t)n * C, dh_d + (size_t)n * Hd, dsd + (size_t)n * C, C, Hd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -139,7 +201,8 @@ constexpr int kBranches = 5;
 __global__ void __launch_bounds__(256) gate_head_fwd_kernel(
     const float* __restrict__ pooled, const float* __restrict__ fc, float* __restrict__ weight,
     float* __restrict__ wcum, float* __restrict__ soft, float* __restrict__ flop_loss,
-    const float* __restrict__ flop_table, int N, int J, float temp, int hard, int mode) {
+    const float* __restrict__ flop_table, const int* __restrict__ force_branch, int N, int J, float temp, int hard,
+    int mode) {
     __shared__ float red[4];
     float col[kBranches] = {0.f, 0.f, 0.f, 0.f, 0.f};   // this thread's partial column sums of weight
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -165,6 +228,9 @@ __global__ void __launch_bounds__(256) gate_head_fwd_kernel(
                 soft[(size_t)n * kBranches + k] = z[k];
                 if (z[k] > best) { best = z[k]; arg = k; }   // first maximum, as torch.max
             }
+            // benchmark / test knob: a FIXED branch per sample replaces the arg-max of the hard decision (the
+            // gate network, its soft output and its straight-through gradient are evaluated as usual)
+            if (force_branch) arg = min(max(force_branch[n], 0), kBranches - 1);
 #pragma unroll
             for (int k = 0; k < kBranches; ++k) {
                 // straight-through value: (y_hard - y_soft) + y_soft, evaluated in that order
@@ -197,11 +263,14 @@ __global__ void __launch_bounds__(256) gate_head_fwd_kernel(
     if (threadIdx.x == 0) flop_loss[0] = loss / (float)kBranches;
 }
 
+constexpr int kMaxGateN = 2048;
+
 __global__ void __launch_bounds__(256) gate_head_bwd_kernel(
     const float* __restrict__ d_weight, const float* __restrict__ d_wcum,
     const float* __restrict__ d_loss, const float* __restrict__ pooled, const float* __restrict__ fc,
     const float* __restrict__ soft, const float* __restrict__ flop_table,
     float* __restrict__ d_pooled, float* __restrict__ d_fc, int N, int J, float temp) {
+    __shared__ float dz_lds[kMaxGateN * kBranches];
     const float dl = d_loss ? d_loss[0] : 0.f;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float dw[kBranches];
@@ -224,18 +293,65 @@ __global__ void __launch_bounds__(256) gate_head_bwd_kernel(
         for (int k = 0; k < kBranches; ++k) dot += soft[(size_t)n * kBranches + k] * dw[k];
         float dz[kBranches];
 #pragma unroll
-        for (int k = 0; k < kBranches; ++k)
+        for (int k = 0; k < kBranches; ++k) {
             dz[k] = soft[(size_t)n * kBranches + k] * (dw[k] - dot) / temp;
+            dz_lds[n * kBranches + k] = dz[k];
+        }
         for (int j = 0; j < J; ++j) {
             float acc = 0.f;
-            const float pj = pooled[(size_t)n * J + j];
 #pragma unroll
-            for (int k = 0; k < kBranches; ++k) {
-                acc += dz[k] * fc[k * J + j];
-                atomicAdd(&d_fc[k * J + j], dz[k] * pj);
-            }
+            for (int k = 0; k < kBranches; ++k) acc += dz[k] * fc[k * J + j];
             d_pooled[(size_t)n * J + j] = acc;
         }
+    }
+    __syncthreads();
+    // d_fc[k][j] = sum_n dz[n][k] * pooled[n][j], samples in ascending order (deterministic, no atomics)
+    for (int e = threadIdx.x; e < kBranches * J; e += blockDim.x) {
+        const int k = e / J, j = e - k * J;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += dz_lds[n * kBranches + k] * pooled[(size_t)n * J + j];
+        d_fc[e] = acc;
+    }
+}
+
+
+// K16 — gate-decision compaction (new capability; the reference never skips compute, …globalgate.py:276-310).
+// From the one-hot gate weights [N,5]:  branch[n] = arg-max (first maximum);  order = the samples sorted by
+// branch, DESCENDING and stable;  inv = its inverse;  counts[j-1] = #{n : branch[n] >= j}, j = 1..4.
+// In the sorted batch the samples that still need depth stage j are the PREFIX of length counts[j-1], so every
+// depth-encoder stage runs on a contiguous prefix view — no per-stage gather / scatter, one small device-to-host
+// read (4 ints) per forward.  Single workgroup: N <= kMaxGateN.
+__global__ void __launch_bounds__(256) gate_decide_kernel(const float* __restrict__ weight, int* __restrict__ branch,
+                                                          int* __restrict__ order, int* __restrict__ inv,
+                                                          int* __restrict__ counts, int N) {
+    __shared__ unsigned char key[kMaxGateN];        // 4 - branch: ascending key == descending branch
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        int arg = 0;
+        float best = weight[(size_t)n * kBranches];
+#pragma unroll
+        for (int k = 1; k < kBranches; ++k) {
+            const float v = weight[(size_t)n * kBranches + k];
+            if (v > best) { best = v; arg = k; }
+        }
+        branch[n] = arg;
+        key[n] = (unsigned char)(kBranches - 1 - arg);
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int kn = key[n];
+        int pos = 0;
+        for (int m = 0; m < N; ++m) {
+            const int km = key[m];
+            pos += (km < kn || (km == kn && m < n)) ? 1 : 0;
+        }
+        order[pos] = n;
+        inv[n] = pos;
+    }
+    if (threadIdx.x < kBranches - 1) {
+        const int j = threadIdx.x + 1;                // stage j runs for branch >= j  <=>  key <= 4 - j
+        int c = 0;
+        for (int m = 0; m < N; ++m) c += (key[m] <= kBranches - 1 - j) ? 1 : 0;
+        counts[threadIdx.x] = c;
     }
 }
 
@@ -273,7 +389,6 @@ __device__ __forceinline__ float exp1_from_bits(uint32_t x) {
 }
 
 struct MlpParams { const float* p[4]; };   // W1[2C/16,2C] b1 W2[2C,2C/16] b2
-struct MlpGrads { float* p[4]; };
 
 __global__ void __launch_bounds__(256) reweigh_fwd_kernel(
     const float* __restrict__ sr, const float* __restrict__ sd, MlpParams P,
@@ -339,8 +454,8 @@ __global__ void __launch_bounds__(256) reweigh_bwd_kernel(
     const float* __restrict__ d_wnext, const float* __restrict__ da, const float* __restrict__ db,
     const float* __restrict__ sr, const float* __restrict__ sd, MlpParams P,
     const float* __restrict__ prev, int prev_stride, const float* __restrict__ h,
-    const float* __restrict__ g, const float* __restrict__ aux, MlpGrads G, float* __restrict__ dsr,
-    float* __restrict__ dsd, float* __restrict__ d_wblend, float* __restrict__ d_prev, float temp, int C) {
+    const float* __restrict__ g, const float* __restrict__ aux, float* __restrict__ ws, float* __restrict__ dsr,
+    float* __restrict__ dsd, float* __restrict__ d_wblend, float* __restrict__ d_prev, float temp, int N, int C) {
     __shared__ float p_lds[kMaxC];
     __shared__ float dg_lds[kMaxC];
     __shared__ float dz_lds[kMaxC];
@@ -382,8 +497,9 @@ __global__ void __launch_bounds__(256) reweigh_bwd_kernel(
     for (int c = threadIdx.x; c < C2; c += blockDim.x) dg_lds[c] = dsn * p_lds[c];
     __syncthreads();
     const float* gn = g + (size_t)n * C2;
-    se_mlp_bwd(dg_lds, p_lds, h + (size_t)n * Hd, gn, P.p[0], P.p[2], G.p[0], G.p[1], G.p[2], G.p[3],
-               dz_lds, dh_lds, ds_lds, C2, Hd);
+    float* const dz_g = ws, * const dh_g = ws + (size_t)N * C2;        // scratch: dz [N][2C] | dh [N][2C/16]
+    se_mlp_bwd(dg_lds, h + (size_t)n * Hd, gn, P.p[0], P.p[2], dz_lds, dh_lds, dz_g + (size_t)n * C2,
+               dh_g + (size_t)n * Hd, ds_lds, C2, Hd);
     for (int c = threadIdx.x; c < C2; c += blockDim.x) {
         const float v = ds_lds[c] + dsn * gn[c];
         if (c < C) dsr[(size_t)n * C + c] = v;
@@ -416,43 +532,63 @@ extern "C" int dynmm_se_coeff_fwd(const float* sr, const float* sd, const float*
     return DYNMM_OK;
 }
 
+extern "C" size_t dynmm_se_coeff_bwd_workspace_bytes(int N, int C) {
+    return sizeof(float) * 2 * (size_t)N * (size_t)(C + C / 16);
+}
+
 extern "C" int dynmm_se_coeff_bwd(const float* da, const float* db, const float* sr, const float* sd,
                                   const float* const* params, const float* wc, int wc_stride,
                                   const float* hr, const float* hd, const float* gr, const float* gd,
                                   float* const* dparams, float* dsr, float* dsd, float* dwc,
-                                  int dwc_stride, int N, int C, int use_se, void* stream) {
+                                  int dwc_stride, float* workspace, int N, int C, int use_se, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!da || !db || N <= 0 || C <= 0 || C > kMaxC) return DYNMM_EINVAL;
     SeParams P{};
-    SeGrads G{};
     hipStream_t st = (hipStream_t)stream;
     if (use_se) {
         if (!sr || !sd || !params || !dparams || !hr || !hd || !gr || !gd || !dsr || !dsd)
             return DYNMM_EINVAL;
+        if (!workspace) return DYNMM_EWORKSPACE;
         if (C % 16 != 0 || C / 16 > kMaxHid) return DYNMM_EUNSUPPORTED;
-        const int Hd = C / 16;
-        const size_t sizes[4] = {(size_t)Hd * C, (size_t)Hd, (size_t)C * Hd, (size_t)C};
         for (int i = 0; i < 8; ++i) {
             if (!params[i] || !dparams[i]) return DYNMM_EINVAL;
             P.p[i] = params[i];
-            G.p[i] = dparams[i];
-            DYNMM_HIP_TRY(hipMemsetAsync(dparams[i], 0, sizeof(float) * sizes[i % 4], st));
         }
     }
     hipLaunchKernelGGL(se_coeff_bwd_kernel, dim3(N), dim3(256), 0, st, da, db, sr, sd, P, wc,
-                       wc_stride, hr, hd, gr, gd, G, dsr, dsd, dwc, dwc_stride, C, use_se);
+                       wc_stride, hr, hd, gr, gd, workspace, dsr, dsd, dwc, dwc_stride, N, C, use_se);
     DYNMM_LAUNCH_CHECK();
+    if (use_se) {
+        const int Hd = C / 16;
+        float* dz_r = workspace, *dh_r = dz_r + (size_t)N * C, *dz_d = dh_r + (size_t)N * Hd, *dh_d = dz_d + (size_t)N * C;
+        MlpGradJobs jobs{};
+        jobs.j[0] = MlpGradJob{sr, hr, dz_r, dh_r, dparams[0], dparams[1], dparams[2], dparams[3], 0, nullptr};
+        jobs.j[1] = MlpGradJob{sd, hd, dz_d, dh_d, dparams[4], dparams[5], dparams[6], dparams[7], 0, nullptr};
+        return launch_mlp_param_grad(jobs, 2, N, C, Hd, st);
+    }
     return DYNMM_OK;
 }
 
 extern "C" int dynmm_gate_head_fwd(const float* pooled, const float* fc, float* weight, float* wcum,
-                                   float* soft, float* flop_loss, const float* flop_table, int N,
-                                   int J, float temp, int hard, int mode, void* stream) {
+                                   float* soft, float* flop_loss, const float* flop_table,
+                                   const int* force_branch, int N, int J, float temp, int hard, int mode,
+                                   void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!weight || !wcum || !soft || !flop_loss || !flop_table || N <= 0) return DYNMM_EINVAL;
     if (mode == 0 && (!pooled || !fc || J <= 0 || !(temp > 0.f))) return DYNMM_EINVAL;
     hipLaunchKernelGGL(gate_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pooled, fc,
-                       weight, wcum, soft, flop_loss, flop_table, N, J, temp, hard, mode);
+                       weight, wcum, soft, flop_loss, flop_table, force_branch, N, J, temp, hard, mode);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_gate_decide(const float* weight, int* branch, int* order, int* inv, int* counts, int N,
+                                 void* stream) {
+    (void)hipGetLastError();
+    if (!weight || !branch || !order || !inv || !counts || N <= 0) return DYNMM_EINVAL;
+    if (N > kMaxGateN) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(gate_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, weight, branch, order, inv,
+                       counts, N);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -464,8 +600,8 @@ extern "C" int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, c
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!pooled || !fc || !soft || !flop_table || !d_pooled || !d_fc || N <= 0 || J <= 0)
         return DYNMM_EINVAL;
+    if (N > kMaxGateN) return DYNMM_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    DYNMM_HIP_TRY(hipMemsetAsync(d_fc, 0, sizeof(float) * kBranches * J, st));
     hipLaunchKernelGGL(gate_head_bwd_kernel, dim3(1), dim3(256), 0, st, d_weight, d_wcum, d_loss,
                        pooled, fc, soft, flop_table, d_pooled, d_fc, N, J, temp);
     DYNMM_LAUNCH_CHECK();
@@ -497,33 +633,40 @@ extern "C" int dynmm_reweigh_fwd(const float* sr, const float* sd, const float* 
     return DYNMM_OK;
 }
 
+extern "C" size_t dynmm_reweigh_bwd_workspace_bytes(int N, int C) {
+    return sizeof(float) * (size_t)N * (size_t)(2 * C + (2 * C) / 16);
+}
+
 extern "C" int dynmm_reweigh_bwd(const float* d_wnext, const float* da, const float* db,
                                  const float* sr, const float* sd, const float* const* params,
                                  const float* prev, int prev_stride, const float* h, const float* g,
                                  const float* aux, float* const* dparams, float* dsr, float* dsd,
-                                 float* d_wblend, float* d_prev, float temp, int N, int C,
+                                 float* d_wblend, float* d_prev, float* workspace, float temp, int N, int C,
                                  void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (N <= 0 || C <= 0 || (!d_wnext && !d_wblend)) return DYNMM_EINVAL;
     if (d_wblend && (!da || !db)) return DYNMM_EINVAL;
     MlpParams P{};
-    MlpGrads G{};
     hipStream_t st = (hipStream_t)stream;
     if (d_wnext) {
         if (!sr || !sd || !params || !dparams || !h || !g || !aux || !dsr || !dsd || !(temp > 0.f))
             return DYNMM_EINVAL;
+        if (!workspace) return DYNMM_EWORKSPACE;
         if ((2 * C) % 16 != 0 || 2 * C > kMaxC || (2 * C) / 16 > kMaxHid) return DYNMM_EUNSUPPORTED;
-        const int C2 = 2 * C, Hd = C2 / 16;
-        const size_t sizes[4] = {(size_t)Hd * C2, (size_t)Hd, (size_t)C2 * Hd, (size_t)C2};
         for (int i = 0; i < 4; ++i) {
             if (!params[i] || !dparams[i]) return DYNMM_EINVAL;
             P.p[i] = params[i];
-            G.p[i] = dparams[i];
-            DYNMM_HIP_TRY(hipMemsetAsync(dparams[i], 0, sizeof(float) * sizes[i], st));
         }
     }
     hipLaunchKernelGGL(reweigh_bwd_kernel, dim3(N), dim3(256), 0, st, d_wnext, da, db, sr, sd, P, prev,
-                       prev_stride, h, g, aux, G, dsr, dsd, d_wblend, d_prev, temp, C);
+                       prev_stride, h, g, aux, workspace, dsr, dsd, d_wblend, d_prev, temp, N, C);
     DYNMM_LAUNCH_CHECK();
+    if (d_wnext) {
+        const int C2 = 2 * C, Hd = C2 / 16;
+        MlpGradJobs jobs{};
+        jobs.j[0] = MlpGradJob{sr, h, workspace, workspace + (size_t)N * C2, dparams[0], dparams[1], dparams[2],
+                               dparams[3], C, sd};
+        return launch_mlp_param_grad(jobs, 1, N, C2, Hd, st);
+    }
     return DYNMM_OK;
 }

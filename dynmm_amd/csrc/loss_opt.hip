@@ -93,14 +93,50 @@ __global__ void __launch_bounds__(256) ce2d_bwd_kernel(const float* __restrict__
     }
 }
 
+// Flat fused optimizer updates (train.py:554-579).  One kernel covers an element range [lo, hi) of the flat
+// parameter / gradient / state buffers (16-byte aligned bases): aligned groups of 4 go through dwordx4
+// accesses, the ragged edges of the range element by element.  Hyper-parameters that the training driver
+// changes between steps (learning rate, momentum / beta1 under OneCycleLR's cycle_momentum) live in a small
+// DEVICE array, so a step captured in a hipGraph sees the new values without re-capture.
+// NaN guard (train.py:334-335 checks the loss on the host every step): when `loss` is given and not finite
+// the update is skipped and *nan_flag receives 1 + the device step counter (first offender wins).
+struct OptRange {
+    size_t lo, hi;
+};
+
+template <typename F>
+__device__ __forceinline__ void for_range4(size_t lo, size_t hi, F&& f) {
+    // f(i, count): count == 4 for an aligned full group, else 1
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    const size_t lo4 = (lo + 3) & ~(size_t)3, hi4 = hi & ~(size_t)3;
+    if (lo4 >= hi4) {
+        for (size_t k = lo + tid; k < hi; k += nth) f(k, 1);
+        return;
+    }
+    for (size_t i = lo4 + tid * 4; i < hi4; i += nth * 4) f(i, 4);
+    if (tid < lo4 - lo) f(lo + tid, 1);
+    if (tid < hi - hi4) f(hi4 + tid, 1);
+}
+
+__device__ __forceinline__ bool loss_bad(const float* loss, int* nan_flag, const int* step) {
+    if (!loss) return false;
+    const float l = loss[0];
+    const bool bad = !(fabsf(l) <= 3.0e38f);        // NaN or +-inf
+    if (bad && nan_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicCAS(nan_flag, 0, 1 + (step ? step[0] : 0));
+    return bad;
+}
+
 __global__ void __launch_bounds__(256) sgd_nesterov_kernel(float* __restrict__ p,
                                                            const float* __restrict__ g,
-                                                           float* __restrict__ buf, size_t n,
-                                                           const float* __restrict__ lr,
-                                                           float momentum, float wd, float gscale) {
-    const float l = lr[0];
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
-        if (i + 4 <= n) {
+                                                           float* __restrict__ buf, OptRange r,
+                                                           const float* __restrict__ hyper,
+                                                           float wd, float gscale,
+                                                           const float* __restrict__ loss, int* nan_flag,
+                                                           const int* __restrict__ step) {
+    if (loss_bad(loss, nan_flag, step)) return;
+    const float l = hyper[0], momentum = hyper[1];
+    for_range4(r.lo, r.hi, [&](size_t i, int cnt) {
+        if (cnt == 4) {
             float pv[4], gv[4], bv[4];
             vload<4>(p + i, pv);
             vload<4>(g + i, gv);
@@ -114,14 +150,52 @@ __global__ void __launch_bounds__(256) sgd_nesterov_kernel(float* __restrict__ p
             vstore<4>(p + i, pv);
             vstore<4>(buf + i, bv);
         } else {
-            for (size_t k = i; k < n; ++k) {
-                const float d = g[k] * gscale + wd * p[k];
-                buf[k] = momentum * buf[k] + d;
-                p[k] -= l * (d + momentum * buf[k]);
-            }
+            const float d = g[i] * gscale + wd * p[i];
+            buf[i] = momentum * buf[i] + d;
+            p[i] -= l * (d + momentum * buf[i]);
         }
-    }
+    });
 }
+
+// torch.optim.Adam (L2 weight decay folded into the gradient, amsgrad off), train.py:564-570:
+//   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+//   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = step[0] (already incremented by dynmm_opt_tick)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, OptRange r,
+                                                   const float* __restrict__ hyper, const int* __restrict__ step,
+                                                   float wd, float gscale, const float* __restrict__ loss,
+                                                   int* nan_flag) {
+    if (loss_bad(loss, nan_flag, step)) return;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+    const double t = (double)step[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float rbc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    const float step_size = lr / bc1;
+    auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+        const float d = gv * gscale + wd * pv;
+        mv = b1 * mv + (1.f - b1) * d;
+        vv = b2 * vv + (1.f - b2) * d * d;
+        pv -= step_size * (mv / (sqrtf(vv) * rbc2 + eps));
+    };
+    for_range4(r.lo, r.hi, [&](size_t i, int cnt) {
+        if (cnt == 4) {
+            float pv[4], gv[4], mv[4], vv[4];
+            vload<4>(p + i, pv);
+            vload<4>(g + i, gv);
+            vload<4>(m + i, mv);
+            vload<4>(v + i, vv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) upd(pv[j], gv[j], mv[j], vv[j]);
+            vstore<4>(p + i, pv);
+            vstore<4>(m + i, mv);
+            vstore<4>(v + i, vv);
+        } else {
+            upd(p[i], g[i], m[i], v[i]);
+        }
+    });
+}
+
+__global__ void opt_tick_kernel(int* step) { step[0] += 1; }
 
 // eval.py:117-141 as ONE pass: bilinear resize (align_corners=False) of the 40-channel logits to the
 // label resolution, arg-max over classes, void mask (label 0), confusion-matrix increment
@@ -195,15 +269,41 @@ extern "C" int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const
     return DYNMM_OK;
 }
 
-extern "C" int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const float* lr,
-                                  float momentum, float weight_decay, float grad_scale, void* stream) {
-    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    if (!p || !g || !buf || !lr || n == 0) return DYNMM_EINVAL;
-    if (!aligned16(p) || !aligned16(g) || !aligned16(buf)) return DYNMM_EUNSUPPORTED;
+static unsigned opt_blocks(size_t n) {
     size_t blocks = ceil_div_sz(n, 1024);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       p, g, buf, n, lr, momentum, weight_decay, grad_scale);
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+extern "C" int dynmm_opt_tick(int* step, void* stream) {
+    (void)hipGetLastError();
+    if (!step) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t lo, size_t hi, const float* hyper,
+                                  float weight_decay, float grad_scale, const float* loss, int* nan_flag,
+                                  const int* step, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+    if (!p || !g || !buf || !hyper || hi <= lo) return DYNMM_EINVAL;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(buf)) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(opt_blocks(hi - lo)), dim3(256), 0, (hipStream_t)stream,
+                       p, g, buf, OptRange{lo, hi}, hyper, weight_decay, grad_scale, loss, nan_flag, step);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_adam(float* p, const float* g, float* m, float* v, size_t lo, size_t hi, const float* hyper,
+                          const int* step, float weight_decay, float grad_scale, const float* loss, int* nan_flag,
+                          void* stream) {
+    (void)hipGetLastError();
+    if (!p || !g || !m || !v || !hyper || !step || hi <= lo) return DYNMM_EINVAL;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(adam_kernel, dim3(opt_blocks(hi - lo)), dim3(256), 0, (hipStream_t)stream,
+                       p, g, m, v, OptRange{lo, hi}, hyper, step, weight_decay, grad_scale, loss, nan_flag);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

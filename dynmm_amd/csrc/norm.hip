@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(
     shift[c] = beta[c] + (b - rm[c]) * sc;
 }
 
-// g_out = act'(y) * g ; dbias[c] += sum g_out   (fp32 atomics: <= 2048/C partials per channel)
+// g_out = act'(y) * g ; dbias[split][c] = sum g_out over the split's samples (the splits are then summed in a
+// fixed order by launch_reduce_slabs: no float atomics)
 template <int V>
 __global__ void __launch_bounds__(256) act_bwd_bias_kernel(
     const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ gout,
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(
     }
     if (dbias) {
         const float t1 = block_reduce_sum_256<float>(s1, red);
-        if (threadIdx.x == 0) atomicAdd(&dbias[c], t1);
+        if (threadIdx.x == 0) dbias[(size_t)blockIdx.y * C + c] = t1;
     }
 }
 
@@ -329,19 +330,31 @@ extern "C" int dynmm_bn_fold(const float* gamma, const float* beta, const float*
     return DYNMM_OK;
 }
 
-extern "C" int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias,
+extern "C" size_t dynmm_act_bwd_bias_workspace_bytes(int N, int C) {
+    if (N <= 0 || C <= 0) return 0;
+    const int S = reduce_splits(N, C);
+    return S > 1 ? sizeof(float) * (size_t)S * C : 0;
+}
+
+extern "C" int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias, float* workspace,
                                   int N, int C, int HW, int act, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (act != DYNMM_ACT_NONE && !y) return DYNMM_EINVAL;
     if (!g_out && !dbias) return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dbias) DYNMM_HIP_TRY(hipMemsetAsync(dbias, 0, sizeof(float) * C, st));
-    dim3 grid(C, reduce_splits(N, C));
+    const int S = reduce_splits(N, C);
+    if (dbias && S > 1 && !workspace) return DYNMM_EWORKSPACE;
+    float* part = (dbias && S > 1) ? workspace : dbias;
+    dim3 grid(C, S);
     if (can_vec4(HW, {g, y, g_out}))
-        hipLaunchKernelGGL(act_bwd_bias_kernel<4>, grid, dim3(256), 0, st, g, y, g_out, dbias, N, C, HW, act);
+        hipLaunchKernelGGL(act_bwd_bias_kernel<4>, grid, dim3(256), 0, st, g, y, g_out, part, N, C, HW, act);
     else
-        hipLaunchKernelGGL(act_bwd_bias_kernel<1>, grid, dim3(256), 0, st, g, y, g_out, dbias, N, C, HW, act);
+        hipLaunchKernelGGL(act_bwd_bias_kernel<1>, grid, dim3(256), 0, st, g, y, g_out, part, N, C, HW, act);
     DYNMM_LAUNCH_CHECK();
+    if (dbias && S > 1) {
+        launch_reduce_slabs(part, dbias, C, S, st);
+        DYNMM_LAUNCH_CHECK();
+    }
     return DYNMM_OK;
 }

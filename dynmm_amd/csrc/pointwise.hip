@@ -367,8 +367,9 @@ __global__ void __launch_bounds__(256) upsample_bwd_dx_kernel(const float* __res
     }
 }
 
-// dw[c][r][s] += sum g*U ; db[c] += sum g.  grid (C, splits over n).  One lane owns 4 consecutive
-// outputs of a row (16-byte load of g) and the 3x4 input patch they see.
+// part_w[split][c][r][s] = sum g*U ; part_b[split][c] = sum g over this split's samples.  grid (C, splits
+// over n); the splits are summed in a fixed order by launch_reduce_slabs (no float atomics).  One lane owns
+// 4 consecutive outputs of a row (16-byte load of g) and the 3x4 input patch they see.
 __global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __restrict__ g,
                                                              const float* __restrict__ x,
                                                              float* __restrict__ dw,
@@ -428,8 +429,8 @@ __global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __rest
     for (int j = 0; j < 10; ++j) {
         const float t = block_reduce_sum_256<float>(acc[j], red);
         if (threadIdx.x == 0) {
-            if (j < 9) atomicAdd(&dw[c * 9 + j], t);
-            else if (db) atomicAdd(&db[c], t);
+            if (j < 9) dw[((size_t)blockIdx.y * C + c) * 9 + j] = t;
+            else if (db) db[(size_t)blockIdx.y * C + c] = t;
         }
     }
 }
@@ -534,7 +535,7 @@ template <int V>
 __global__ void __launch_bounds__(256) batch_gather_kernel(const float* __restrict__ src,
                                                            const int* __restrict__ idx,
                                                            float* __restrict__ dst, size_t row) {
-    const size_t s = (size_t)idx[blockIdx.y] * row, d = (size_t)blockIdx.y * row;
+    const size_t s = (size_t)(idx ? idx[blockIdx.y] : (int)blockIdx.y) * row, d = (size_t)blockIdx.y * row;
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < row; i += (size_t)gridDim.x * 256 * V) {
         float v[V];
         vload<V>(src + s + i, v);
@@ -566,7 +567,7 @@ using namespace dynmm;
 extern "C" int dynmm_batch_gather(const float* src, const int* idx, float* dst, int n_out, size_t row,
                                   void* stream) {
     (void)hipGetLastError();
-    if (!src || !idx || !dst || n_out <= 0 || row == 0) return DYNMM_EINVAL;
+    if (!src || !dst || n_out <= 0 || row == 0) return DYNMM_EINVAL;
     unsigned bx = (unsigned)((row / 4 + 255) / 256);
     if (bx > 64) bx = 64;
     if (bx < 1) bx = 1;
@@ -671,8 +672,21 @@ extern "C" int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const 
     return DYNMM_OK;
 }
 
+static int upsample_w_splits(int N, int C) {
+    int S = 2048 / C;
+    if (S < 1) S = 1;
+    if (S > N) S = N;
+    return S;
+}
+
+extern "C" size_t dynmm_upsample2x_dw3x3_bwd_workspace_bytes(int N, int C) {
+    if (N <= 0 || C <= 0) return 0;
+    const int S = upsample_w_splits(N, C);
+    return S > 1 ? sizeof(float) * (size_t)S * C * 10 : 0;
+}
+
 extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const float* w, float* dx,
-                                          float* dw, float* db, int N, int C, int H, int W,
+                                          float* dw, float* db, float* workspace, int N, int C, int H, int W,
                                           void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !w || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
@@ -684,13 +698,18 @@ extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const 
     }
     if (dw) {
         if (!x) return DYNMM_EINVAL;
-        DYNMM_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * 9 * C, ST));
-        if (db) DYNMM_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, ST));
-        int S = 2048 / C;
-        if (S < 1) S = 1;
-        if (S > N) S = N;
-        hipLaunchKernelGGL(upsample_bwd_w_kernel, dim3(C, S), dim3(256), 0, ST, g, x, dw, db, N, C, H, W);
-        DYNMM_LAUNCH_CHECK();
+        const int S = upsample_w_splits(N, C);
+        if (S == 1) {
+            hipLaunchKernelGGL(upsample_bwd_w_kernel, dim3(C, 1), dim3(256), 0, ST, g, x, dw, db, N, C, H, W);
+            DYNMM_LAUNCH_CHECK();
+        } else {
+            if (!workspace) return DYNMM_EWORKSPACE;
+            float* pw = workspace, *pb = workspace + (size_t)S * C * 9;
+            hipLaunchKernelGGL(upsample_bwd_w_kernel, dim3(C, S), dim3(256), 0, ST, g, x, pw, db ? pb : nullptr, N, C, H, W);
+            DYNMM_LAUNCH_CHECK();
+            launch_reduce_slabs(pw, dw, C * 9, S, ST, db ? pb : nullptr, db, db ? C : 0);
+            DYNMM_LAUNCH_CHECK();
+        }
     }
     return DYNMM_OK;
 }

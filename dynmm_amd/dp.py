@@ -47,9 +47,17 @@ class GradBucketReducer:
         self.overlap = overlap and self.world > 1
         self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda') else None
         self._hooks = []
+        self._streams = [dict() for _ in self.buckets]      # per bucket: producer streams seen this step
+        self.launched_in_backward = 0                        # buckets whose all-reduce started before finish()
+        self.launch_log = []                                 # (bucket, 'backward' | 'finish') of the last step
         if self.overlap:
+            # (a) plain autograd accumulation (torch modules): post-accumulate hooks;
+            # (b) the HIP kernels' in-place gradient protocol (ops.DIRECT_GRAD: autograd never sees these
+            #     gradients, so hooks never fire): ops reports every parameter whose gradient kernels are enqueued.
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+            from . import ops
+            ops.GRAD_READY_HOOK = self._on_grad_written
 
     # -- step protocol --------------------------------------------------------------------------
     def zero(self):
@@ -57,22 +65,42 @@ class GradBucketReducer:
         self.flat.zero_()
         self._pending = list(self._count)
         self._works = []
+        self._streams = [dict() for _ in self.buckets]
+        self.launched_in_backward = 0
+        self.launch_log = []
 
-    def _launch(self, b):
+    def _launch(self, b, where='finish'):
         s, e = self.buckets[b]
         chunk = self.flat[s:e]
+        self.launch_log.append((b, where))
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            for st in self._streams[b].values():         # side streams that wrote into this bucket (wgrad queue, depth encoder)
+                self._comm_stream.wait_stream(st)
             with torch.cuda.stream(self._comm_stream):
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _on_grad_ready(self, p):
-        b = self._bucket_of[p]
+    def _arrived(self, p):
+        b = self._bucket_of.get(p)
+        if b is None or self._pending[b] <= 0:
+            return
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            self._launch(b)
+            self.launched_in_backward += 1
+            self._launch(b, 'backward')
+
+    def _on_grad_ready(self, p):
+        self._arrived(p)
+
+    def _on_grad_written(self, p, streams):
+        b = self._bucket_of.get(p)
+        if b is None:
+            return
+        for st in streams:
+            self._streams[b][st.cuda_stream] = st
+        self._arrived(p)
 
     def finish(self):
         """After backward: make sure every bucket is reduced, then average."""
@@ -84,6 +112,7 @@ class GradBucketReducer:
         else:
             for b, left in enumerate(self._pending):   # params that received no grad this step
                 if left > 0:
+                    self._pending[b] = 0
                     self._launch(b)
         for w in self._works:
             w.wait()
@@ -96,6 +125,9 @@ class GradBucketReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        from . import ops
+        if ops.GRAD_READY_HOOK == self._on_grad_written:
+            ops.GRAD_READY_HOOK = None
 
 
 def broadcast_parameters(module, src=0, process_group=None):

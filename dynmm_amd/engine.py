@@ -1,13 +1,15 @@
 """The callers either side of the hot path, on the HIP path:
 
-  TrainStep  = FusionDynMM/train.py:289-324 — zero grads, forward, weighted multi-scale CE,
+  TrainStep  = FusionDynMM/train.py:289-335 — zero grads, forward, weighted multi-scale CE,
                total = sum(CE_s) + ratio*max(0, flop_loss - budget), backward, [DP all-reduce],
-               SGD-Nesterov — as ONE hipGraph-capturable sequence: parameters, gradients and momentum
-               live in flat fp32 buffers (every nn.Parameter / .grad is a view), the learning rate is a
-               device scalar, so a whole optimisation step replays with no host work.
+               optimizer step (SGD-Nesterov or Adam, train.py:554-579), NaN guard — as ONE
+               hipGraph-capturable sequence: trainable parameters, gradients and optimizer state live in
+               flat fp32 buffers (every nn.Parameter / .grad is a view); learning rate, momentum / beta1
+               and the step counter are DEVICE scalars, so a captured step replays with no host work.
   evaluate   = FusionDynMM/eval.py:104-146 — forward(test=True), bilinear resize to the label size,
                arg-max, void mask, confusion matrix, mIoU*100.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -17,127 +19,277 @@ from . import lib as L
 
 
 class FlatParameters:
-    """Re-home every parameter of `module` into one contiguous fp32 buffer (views keep state_dict,
-    load_state_dict and autograd working unchanged)."""
+    """Re-home the given parameters into one contiguous fp32 buffer (views keep state_dict,
+    load_state_dict and autograd working unchanged).  Layout = reverse parameter order, the order in
+    which dp.GradBucketReducer lays out the flat gradient buffer."""
 
-    def __init__(self, module):
-        self.params = [p for p in module.parameters()]
+    def __init__(self, params):
+        self.params = list(params)
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.empty(total, device=dev, dtype=torch.float32)
+        self.span = {}                      # id(param) -> (lo, hi) element range in the flat buffers
         off = 0
         with torch.no_grad():
-            for p in reversed(self.params):        # same order as dp.GradBucketReducer
+            for p in reversed(self.params):
                 n = p.numel()
                 self.flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + n].view_as(p)
+                self.span[id(p)] = (off, off + n)
                 off += n
 
 
-class SGDNesterov:
-    """Fused flat SGD with Nesterov momentum and L2 weight decay (torch.optim.SGD semantics,
-    train.py:557-563): one kernel over all parameters."""
+def _merge(spans):
+    out = []
+    for lo, hi in sorted(spans):
+        if out and lo <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], hi)
+        else:
+            out.append([lo, hi])
+    return [(a, b) for a, b in out]
 
-    def __init__(self, flat_params, flat_grads, lr, momentum=0.9, weight_decay=1e-4):
-        assert flat_params.numel() == flat_grads.numel()
-        self.p, self.g = flat_params, flat_grads
-        self.buf = torch.zeros_like(flat_params)
-        self.lr = torch.tensor([float(lr)], device=flat_params.device, dtype=torch.float32)
-        self.momentum, self.weight_decay = float(momentum), float(weight_decay)
 
+class _FlatOptimizer:
+    """Common part of the fused flat optimizers.
+
+    * torch.optim semantics for parameters that took no part in a step (`.grad is None` there): they are
+      skipped — no weight decay, no momentum update.  The kernels that write gradients report the
+      parameters they touched (ops.touched()); `step(touched)` updates only those element ranges.
+    * `groups`: {name: [params]} partitions the parameters into sets that may start receiving gradients
+      at different times (the gate vs everything else: ini_stage / baseline epochs, --freeze); Adam keeps
+      one device step counter per group so its bias correction matches torch's per-parameter counters.
+    * lr, momentum/beta1 are device scalars (OneCycleLR changes both every epoch, train.py:119-128).
+    * NaN guard: the total loss of the step is inspected on the device; a non-finite loss skips the update
+      and latches `nan_step` (train.py:334-335 raises on the host every step; here the host looks once
+      per epoch or whenever it wants with check_finite())."""
+
+    HYPER = 4
+
+    def __init__(self, flatp, flat_grads, groups=None):
+        assert flatp.flat.numel() == flat_grads.numel()
+        self.fp, self.p, self.g = flatp, flatp.flat, flat_grads
+        dev = self.p.device
+        self.hyper = torch.zeros(self.HYPER, device=dev, dtype=torch.float32)
+        self.nan_flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        groups = groups or {'all': list(flatp.params)}
+        self.group_of = {}
+        self.group_names = list(groups)
+        for gi, name in enumerate(self.group_names):
+            for q in groups[name]:
+                self.group_of[id(q)] = gi
+        self.steps = torch.zeros(max(1, len(self.group_names)), device=dev, dtype=torch.int32)
+        self._all = [id(q) for q in flatp.params]
+
+    # -- host-visible knobs (device scalars: visible to an already-captured graph) ------------------
     def set_lr(self, lr):
-        self.lr.fill_(float(lr))            # device scalar: visible to an already-captured graph
+        self.hyper[0:1].fill_(float(lr))
 
-    def step(self):
+    def set_momentum(self, m):
+        self.hyper[1:2].fill_(float(m))
+
+    def plan(self, touched=None):
+        """[(group index, [(lo, hi), ...])] for the touched parameter ids (None = every parameter)."""
+        ids = self._all if touched is None else [i for i in self._all if i in touched]
+        per = {}
+        for i in ids:
+            per.setdefault(self.group_of[i], []).append(self.fp.span[i])
+        return [(gi, _merge(sp)) for gi, sp in sorted(per.items())]
+
+    def step(self, touched=None, loss=None):
         lib = L.load()
         ops.note_mutation()                 # parameters are rewritten through raw pointers
+        st = torch.cuda.current_stream().cuda_stream
+        lp = None if loss is None else loss.data_ptr()
+        for gi, ranges in self.plan(touched):
+            sp = self.steps.data_ptr() + 4 * gi
+            L.check(lib.dynmm_opt_tick(sp, st), 'opt_tick')
+            for lo, hi in ranges:
+                self._launch(lib, lo, hi, sp, lp, st)
+
+    def check_finite(self):
+        """Raise the reference's error if any step since the last call saw a non-finite loss (one D2H read)."""
+        v = int(self.nan_flag.item())
+        if v:
+            self.nan_flag.zero_()
+            raise ValueError(f'Loss is None (non-finite total loss at optimizer step {v})')
+
+
+class SGDNesterov(_FlatOptimizer):
+    """torch.optim.SGD(nesterov=True, weight_decay=L2) — train.py:557-563 — as one kernel per touched range."""
+
+    def __init__(self, flatp, flat_grads, lr, momentum=0.9, weight_decay=1e-4, groups=None):
+        super().__init__(flatp, flat_grads, groups)
+        self.buf = torch.zeros_like(self.p)
+        self.weight_decay = float(weight_decay)
+        self.set_lr(lr)
+        self.set_momentum(momentum)
+
+    def _launch(self, lib, lo, hi, sp, lp, st):
         L.check(lib.dynmm_sgd_nesterov(self.p.data_ptr(), self.g.data_ptr(), self.buf.data_ptr(),
-                                       C.c_size_t(self.p.numel()), self.lr.data_ptr(), self.momentum,
-                                       self.weight_decay, 1.0, torch.cuda.current_stream().cuda_stream),
-                'sgd_nesterov')
+                                       C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), self.weight_decay,
+                                       1.0, lp, self.nan_flag.data_ptr(), sp, st), 'sgd_nesterov')
 
     def state_dict(self):
-        return {'momentum_buffer': self.buf, 'lr': self.lr}
+        return {'kind': 'SGD', 'momentum_buffer': self.buf, 'hyper': self.hyper, 'steps': self.steps}
+
+    def state_tensors(self):
+        return [self.buf, self.steps]
+
+
+class Adam(_FlatOptimizer):
+    """torch.optim.Adam(betas=(0.9, 0.999), eps=1e-8, weight_decay=L2) — train.py:564-570."""
+
+    def __init__(self, flatp, flat_grads, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, groups=None):
+        super().__init__(flatp, flat_grads, groups)
+        self.m, self.v = torch.zeros_like(self.p), torch.zeros_like(self.p)
+        self.weight_decay = float(weight_decay)
+        self.set_lr(lr)
+        self.set_momentum(betas[0])
+        self.hyper[2:3].fill_(float(betas[1]))
+        self.hyper[3:4].fill_(float(eps))
+
+    def _launch(self, lib, lo, hi, sp, lp, st):
+        L.check(lib.dynmm_adam(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                               C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), sp, self.weight_decay, 1.0,
+                               lp, self.nan_flag.data_ptr(), st), 'adam')
+
+    def state_dict(self):
+        return {'kind': 'Adam', 'exp_avg': self.m, 'exp_avg_sq': self.v, 'hyper': self.hyper, 'steps': self.steps}
+
+    def state_tensors(self):
+        return [self.m, self.v, self.steps]
+
+
+@contextlib.contextmanager
+def direct_gradients(async_wgrad):
+    """Scope of the in-place gradient protocol (ops.DIRECT_GRAD / ops.ASYNC_WGRAD): inside, backward kernels
+    OVERWRITE the `.grad` views (one backward per zero()) and return None to autograd; outside, every other
+    backward in the process keeps torch's accumulate semantics."""
+    saved = (ops.DIRECT_GRAD, ops.ASYNC_WGRAD)
+    ops.DIRECT_GRAD, ops.ASYNC_WGRAD = True, bool(async_wgrad)
+    try:
+        yield
+    finally:
+        ops.DIRECT_GRAD, ops.ASYNC_WGRAD = saved
 
 
 class TrainStep:
+    """One optimisation step of train.py's hot loop.  Build it AFTER model.freeze() when --freeze is used:
+    only parameters with requires_grad take part (flat buffers, reducer buckets and optimizer state cover
+    exactly those, as torch.optim skips parameters without gradients)."""
+
     def __init__(self, model, class_weight, lr, momentum=0.9, weight_decay=1e-4, loss_ratio=0.0,
-                 flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True):
+                 flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True, optimizer='SGD',
+                 overlap=True):
         self.model = model
         self.cw = torch.as_tensor(class_weight, dtype=torch.float32, device=next(model.parameters()).device)
-        self.flatp = FlatParameters(model)
-        self.reducer = dp.GradBucketReducer(model.parameters(), bucket_mb=bucket_mb, overlap=not use_graph)
-        frozen = [p for p in model.parameters() if not p.requires_grad]
-        if frozen:
-            raise NotImplementedError('TrainStep with frozen parameters: build it after model.freeze() is not '
-                                      'supported yet; use per-parameter torch.optim.SGD for --freeze runs')
-        self.opt = SGDNesterov(self.flatp.flat, self.reducer.flat, lr, momentum, weight_decay)
-        ops.DIRECT_GRAD = True      # one backward per zero(): gradients are written in place, not accumulated
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError('TrainStep: the model has no trainable parameter')
+        trainable = [p for _, p in named]
+        self.flatp = FlatParameters(trainable)
+        self.reducer = dp.GradBucketReducer(trainable, bucket_mb=bucket_mb, overlap=overlap and not use_graph)
+        groups = {'gate': [p for n, p in named if 'gate' in n], 'rest': [p for n, p in named if 'gate' not in n]}
+        groups = {k: v for k, v in groups.items() if v}
+        if optimizer == 'SGD':
+            self.opt = SGDNesterov(self.flatp, self.reducer.flat, lr, momentum, weight_decay, groups)
+        elif optimizer == 'Adam':
+            self.opt = Adam(self.flatp, self.reducer.flat, lr, weight_decay=weight_decay, groups=groups)
+        else:
+            raise NotImplementedError(f'Currently only SGD and Adam as optimizers are supported. Got {optimizer}')
         # 3-stream schedule: RGB encoder | depth encoder | conv weight gradients (see nn/net.py, ops.py)
-        ops.ASYNC_WGRAD = bool(multi_stream)
+        self.multi_stream = bool(multi_stream)
         if hasattr(model, 'dual_stream'):
-            model.dual_stream = bool(multi_stream)
+            model.dual_stream = self.multi_stream
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)
         self.use_graph = use_graph
-        self._graph = None
-        self._static = None
+        self._graphs = {}      # key -> (graph, static inputs, static outputs, touched set)
         self.last = None       # dict of device tensors: losses[4], loss_flop, total
+        self._touched = None
 
+    # ------------------------------------------------------------------------------------------------
     def _body(self, rgb, depth, targets):
-        self.reducer.zero()
-        res = self.model(rgb, depth)
-        if len(res) == 2 and isinstance(res[0], (tuple, list)):
-            outs, lf = res                                   # SkipGateESANet: ((out, out8, out16, out32), flop loss)
-        else:
-            outs, lf = res, torch.zeros((), device=rgb.device)   # SkipESANet: the four outputs only
-        losses = [ops.cross_entropy_2d(o, t, self.cw) for o, t in zip(outs, targets)]
-        seg = losses[0]
-        for l in losses[1:]:
-            seg = seg + l
-        total = seg + self.loss_ratio * torch.clamp(lf - self.flop_budget, min=0.0) if self.loss_ratio > 0 else seg
-        total.backward()
-        ops.join_async()
+        with direct_gradients(self.multi_stream):
+            ops.touched_reset()
+            self.reducer.zero()
+            res = self.model(rgb, depth)
+            if len(res) == 2 and isinstance(res[0], (tuple, list)):
+                outs, lf = res                                   # SkipGateESANet: ((out, out8, out16, out32), flop loss)
+            else:
+                outs, lf = res, torch.zeros((), device=rgb.device)   # SkipESANet: the four outputs only
+            losses = [ops.cross_entropy_2d(o, t, self.cw) for o, t in zip(outs, targets)]
+            seg = losses[0]
+            for l in losses[1:]:
+                seg = seg + l
+            total = seg + self.loss_ratio * torch.clamp(lf - self.flop_budget, min=0.0) if self.loss_ratio > 0 else seg
+            total.backward()
+            ops.join_async()
+            self._touched = ops.touched_ids()
         self.last = {'losses': torch.stack([l.detach() for l in losses]), 'loss_flop': lf.detach(),
-                     'total': total.detach()}
+                     'total': total.detach().reshape(1)}
+
+    def _finish(self):
+        self.reducer.finish()
+        self.opt.step(self._touched, self.last['total'])
+
+    def _graph_key(self, rgb, depth, targets):
+        m = self.model
+        return (tuple(rgb.shape), tuple(depth.shape), tuple(tuple(t.shape) for t in targets), bool(m.training),
+                float(getattr(m, 'temp', 0.0)), bool(getattr(m, 'hard_gate', False)), bool(getattr(m, 'baseline', False)),
+                tuple(getattr(m, 'block_rule', ()) or ()))
 
     def __call__(self, rgb, depth, targets):
         """targets: list of 4 label maps (0 = void), uint8/float/int, at scales 1, 1/8, 1/16, 1/32."""
         targets = [t if t.dtype == torch.uint8 else t.to(torch.uint8) for t in targets]
-        if not self.use_graph:
+        # ini_stage draws its branches with the host RNG on every call (…globalgate.py:267-270): a captured
+        # graph would freeze one draw, so those steps always run eagerly.
+        if not self.use_graph or getattr(self.model, 'ini_stage', False):
             self._body(rgb, depth, targets)
-            self.reducer.finish()
-            self.opt.step()
+            self._finish()
             return self.last
-        if self._graph is None:
-            self._static = (rgb.clone(), depth.clone(), [t.clone() for t in targets])
-            # snapshot BEFORE the side stream forks, so the warm-up cannot race the clones
-            sd = {k: v.clone() for k, v in self.model.state_dict().items()}
-            mom = self.opt.buf.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):       # warm-up outside capture (allocator, lazy init)
-                self._body(*self._static)
-            torch.cuda.current_stream().wait_stream(side)
-            self.model.load_state_dict(sd)       # undo the warm-up's BN running-stat updates
-            self.opt.buf.copy_(mom)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._body(*self._static)
-                if self.reducer.world == 1:
-                    self.opt.step()
-            self.model.load_state_dict(sd)
-            self.opt.buf.copy_(mom)
-        s_rgb, s_depth, s_t = self._static
+        # temp / hard_gate / baseline reach the kernels as by-value arguments or host branches: a capture is
+        # valid for one combination of them (and of the input shapes) only, so captures are keyed on it.
+        key = self._graph_key(rgb, depth, targets)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(rgb, depth, targets)
+            self._graphs[key] = entry
+        graph, (s_rgb, s_depth, s_t), s_last, touched = entry
         s_rgb.copy_(rgb)
         s_depth.copy_(depth)
         for a, b in zip(s_t, targets):
             a.copy_(b)
-        self._graph.replay()
+        graph.replay()
         ops.note_mutation()                 # the replayed step updated running statistics / parameters
+        self._touched = touched
+        self.last = {k: v.clone() for k, v in s_last.items()}     # the static tensors are overwritten by the next replay
         if self.reducer.world > 1:
-            self.reducer.finish()
-            self.opt.step()
+            self._finish()
         return self.last
+
+    def _capture(self, rgb, depth, targets):
+        static = (rgb.clone(), depth.clone(), [t.clone() for t in targets])
+        # snapshot BEFORE the side stream forks, so the warm-up cannot race the clones
+        sd = {k: v.clone() for k, v in self.model.state_dict().items()}
+        opt_state = [t.clone() for t in self.opt.state_tensors()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm-up outside capture (allocator, lazy init)
+            self._body(*static)
+        torch.cuda.current_stream().wait_stream(side)
+
+        def restore():
+            self.model.load_state_dict(sd)       # undo the BN running-stat updates of warm-up / capture
+            for t, c in zip(self.opt.state_tensors(), opt_state):
+                t.copy_(c)
+        restore()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._body(*static)
+            if self.reducer.world == 1:
+                self.opt.step(self._touched, self.last['total'])
+        restore()
+        return graph, static, self.last, self._touched
 
 
 @torch.no_grad()

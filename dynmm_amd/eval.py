@@ -5,12 +5,20 @@ flags, optional Gaussian-noise robustness runs (modes 0/1/2), mIoU*100 per run."
 import random
 import sys
 
+import numpy as np
 import torch
 
 from . import engine
 from .data import SyntheticRGBD
 from .src.args import ArgumentParserRGBDSegmentation
 from .src.build_model import build_model
+
+
+def set_seed(seed):
+    """src/utils.py set_seed as eval.py uses it before every noise-robustness run."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
 
 
 def main(argv=None):
@@ -32,6 +40,8 @@ def main(argv=None):
                          seed=77, device=device)
     results = []
     for r in range(args.num_runs):
+        set_seed(r)                                              # eval.py: per-run seed -> reproducible noise runs
+
         def batches():
             for s in data:
                 image, depth = s['image'], s['depth']

@@ -42,7 +42,8 @@ SIGNATURES = {
     'dynmm_pack_weight_bf16': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_conv2d_fwd_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_dgrad_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, _GP, c_f]),
-    'dynmm_act_bwd_bias': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_act_bwd_bias_workspace_bytes': (c_sz, [c_i, c_i]),
+    'dynmm_act_bwd_bias': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_stats': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_apply': (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f]),
     'dynmm_bn_bwd_reduce': (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_i, c_i, c_f]),
@@ -55,17 +56,21 @@ SIGNATURES = {
     'dynmm_nearest_into_fwd': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f]),
     'dynmm_nearest_into_bwd': (c_i, [c_f, c_f] + [c_i] * 8 + [c_f]),
     'dynmm_upsample2x_dw3x3_fwd': (c_i, [c_f] * 5 + [c_i] * 4 + [c_f]),
-    'dynmm_upsample2x_dw3x3_bwd': (c_i, [c_f] * 6 + [c_i] * 4 + [c_f]),
+    'dynmm_upsample2x_dw3x3_bwd_workspace_bytes': (c_sz, [c_i, c_i]),
+    'dynmm_upsample2x_dw3x3_bwd': (c_i, [c_f] * 7 + [c_i] * 4 + [c_f]),
     'dynmm_gap2_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_f]),
     'dynmm_se_coeff_fwd': (c_i, [c_f, c_f, _PP, c_f, c_i] + [c_f] * 6 + [c_i, c_i, c_i, c_f]),
-    'dynmm_se_coeff_bwd': (c_i, [c_f] * 4 + [_PP, c_f, c_i] + [c_f] * 4 + [_PP, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_se_coeff_bwd_workspace_bytes': (c_sz, [c_i, c_i]),
+    'dynmm_se_coeff_bwd': (c_i, [c_f] * 4 + [_PP, c_f, c_i] + [c_f] * 4 + [_PP, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_f]),
     'dynmm_axpby_fwd': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
     'dynmm_axpby_bwd_reduce': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
     'dynmm_axpby_bwd_apply': (c_i, [c_f] * 5 + [c_fl, c_f, c_f, c_i, c_i, c_f]),
     'dynmm_reweigh_fwd': (c_i, [c_f, c_f, _PP, c_f, c_i, c_f, c_i, c_f, C.c_ulonglong, C.c_ulonglong, c_fl, c_i]
                           + [c_f] * 6 + [c_i, c_i, c_f]),
-    'dynmm_reweigh_bwd': (c_i, [c_f] * 5 + [_PP, c_f, c_i, c_f, c_f, c_f, _PP, c_f, c_f, c_f, c_f, c_fl, c_i, c_i, c_f]),
-    'dynmm_gate_head_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_fl, c_i, c_i, c_f]),
+    'dynmm_reweigh_bwd_workspace_bytes': (c_sz, [c_i, c_i]),
+    'dynmm_reweigh_bwd': (c_i, [c_f] * 5 + [_PP, c_f, c_i, c_f, c_f, c_f, _PP, c_f, c_f, c_f, c_f, c_f, c_fl, c_i, c_i, c_f]),
+    'dynmm_gate_head_fwd': (c_i, [c_f] * 8 + [c_i, c_i, c_fl, c_i, c_i, c_f]),
+    'dynmm_gate_decide': (c_i, [c_f] * 5 + [c_i, c_f]),
     'dynmm_gate_head_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_fl, c_f]),
     'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_f]),
     'dynmm_ce2d_bwd': (c_i, [c_f] * 5 + [c_i, c_i, c_i, c_f]),
@@ -73,9 +78,12 @@ SIGNATURES = {
     'dynmm_batch_gather': (c_i, [c_f, c_f, c_f, c_i, c_sz, c_f]),
     'dynmm_batch_merge': (c_i, [c_f, c_f, c_f, c_f, c_i, c_sz, c_f]),
     'dynmm_reduce_slabs': (c_i, [c_f, c_f, c_i, c_i, c_f]),
-    'dynmm_sgd_nesterov': (c_i, [c_f, c_f, c_f, c_sz, c_f, c_fl, c_fl, c_fl, c_f]),
+    'dynmm_opt_tick': (c_i, [c_f, c_f]),
+    'dynmm_sgd_nesterov': (c_i, [c_f, c_f, c_f, c_sz, c_sz, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f]),
+    'dynmm_adam': (c_i, [c_f, c_f, c_f, c_f, c_sz, c_sz, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f]),
 }
 
+ABI_VERSION = 2
 _lib = None
 
 
@@ -116,7 +124,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.dynmm_abi_version() != 1:
+    if lib.dynmm_abi_version() != ABI_VERSION:
         raise DynmmHipError('libdynmm_hip.so ABI version mismatch')
     _lib = lib
     return lib

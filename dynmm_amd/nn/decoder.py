@@ -53,14 +53,21 @@ class Decoder(nn.Module):
         self.upsample1 = Upsample(num_classes)
         self.upsample2 = Upsample(num_classes)
 
-    def forward(self, enc_outs):
+    def forward(self, enc_outs, unpermute=None):
+        """unpermute = (index, inverse): the batch arrives in a permuted (branch-sorted, K16) order; the natural
+        order is restored on the 40-channel map in front of the two final up-samplings (3 MB/img instead of
+        49 MB/img; everything after it is per-sample) and on the small side outputs."""
         out, s16, s8, s4 = enc_outs
         out, o32 = self.decoder_module_1(out, s16)
         out, o16 = self.decoder_module_2(out, s8)
         out, o8 = self.decoder_module_3(out, s4)
         c = self.conv_out
         out = ops.conv2d(out, c.weight, c.bias, 1, 1)
+        if unpermute is not None:
+            out = ops.batch_permute(out, *unpermute)
         out = self.upsample2(self.upsample1(out))
         if self.training:
+            if unpermute is not None:
+                o8, o16, o32 = (ops.batch_permute(o, *unpermute) for o in (o8, o16, o32))
             return out, o8, o16, o32
         return out

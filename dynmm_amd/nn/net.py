@@ -149,7 +149,16 @@ class SkipGateESANet(nn.Module):
         # only on the samples whose branch takes it.  Exact up to fp32 rounding; never used when
         # gradients are recorded or BN is in training mode.
         self.compact = True
+        # Opt-in APPROXIMATE compaction while training with one-hot gates (BASELINE configs[3]): BatchNorm batch
+        # statistics of depth stage j are taken over the samples that run it, and the straight-through gate
+        # gradient of a stage comes from those samples only (the reference's dense forward would also need the
+        # depth features of the skipped samples).  RGB path, decoder and all losses are unchanged.
+        self.compact_train = False
         self.ini_branches = None          # optional fixed branch per sample for ini_stage (else CPU RNG)
+        # benchmark / test knob: with hard gates, a FIXED branch per sample replaces the arg-max decision while the
+        # gate network is still evaluated and trained (ops.gate_head force_branch)
+        self.branch_override = None
+        self._force_cache = None
         # Run the depth encoder's stages on a second HIP stream so its kernels' ramp-up / store-burst /
         # tail phases overlap with the RGB encoder's (both encoders are independent between fusion
         # points).  Autograd replays each backward node on its forward stream, so the backward gets
@@ -186,6 +195,12 @@ class SkipGateESANet(nn.Module):
             self._tab_cache[key] = self.depth_enc_flop.detach().to(device=device, dtype=torch.float32).contiguous()
         return self._tab_cache[key]
 
+    def _force_tensor(self, branches, device):
+        key = (tuple(branches), str(device))
+        if self._force_cache is None or self._force_cache[0] != key:
+            self._force_cache = (key, torch.tensor(branches, dtype=torch.int32, device=device))
+        return self._force_cache[1]
+
     def _se(self, j):
         return getattr(self, f'se_layer{j}').params8() if self.fuse_depth_in_rgb_encoder == 'SE-add' else None
 
@@ -215,64 +230,68 @@ class SkipGateESANet(nn.Module):
             weight, wcum, loss = ops.gate_from_weight(onehot.to(rgb.device), tab)
             host_branch = [int(v) for v in idx.tolist()]
         else:
+            force = None
+            if self.branch_override is not None and self.hard_gate:
+                host_branch = [int(v) for v in list(self.branch_override)[:bs]]
+                force = self._force_tensor(host_branch, rgb.device)
             pooled = self.gate_layer.features(r, d)
-            weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate)
+            weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate, force)
         if self.save_weight_info:
             self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
 
         one_hot = self.baseline or self.ini_stage or self.hard_gate
-        compacted = self.compact and one_hot and not self.training and not torch.is_grad_enabled()
-        # hard gates: ONE device->host read per forward; baseline / ini_stage decisions were made on the host
-        branch = (host_branch if host_branch is not None else weight.argmax(1).tolist()) if compacted else None
-        alive = list(range(bs))                  # samples whose depth features are still being computed
-        self.last_stage_batch = [] if compacted else None
-
+        infer = not self.training and not torch.is_grad_enabled()
+        compacted = one_hot and ((self.compact and infer) or (self.compact_train and not infer))
+        self.last_stage_batch = None
         skips = []
-        for j in (1, 2, 3, 4):
-            if self.dual_stream and not compacted:
-                r, d = encoder_stage_pair(self, j, r if j == 1 else fuse, d)
-                fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
+        unpermute = None
+        if compacted:
+            # K16: sort the batch by branch (descending, stable) ON THE DEVICE; the samples that still need depth
+            # stage j are then the prefix of length counts[j-1] — each stage runs on a prefix view.  The host needs
+            # only the 4 counts: known already for baseline / ini_stage / an injected distribution, otherwise ONE
+            # 16-byte device->host read per forward.
+            _, order, inv, counts_dev = ops.gate_decide(weight)
+            counts = [sum(1 for bch in host_branch if bch >= j) for j in (1, 2, 3, 4)] if host_branch is not None \
+                else [int(v) for v in counts_dev.tolist()]
+            presorted = host_branch is not None and all(x >= y for x, y in zip(host_branch, host_branch[1:]))
+            wc = None
+            if not presorted:
+                r, d = ops.batch_permute(r, order, inv), ops.batch_permute(d, order, inv)
+                unpermute = (inv, order)
+            if not infer and wcum.requires_grad:
+                wc = wcum if presorted else ops.batch_permute(wcum, order, inv)   # straight-through gate gradient
+            self.last_stage_batch = list(counts)
+            for j in (1, 2, 3, 4):
+                c = counts[j - 1]
+                r_in = r if j == 1 else fuse
+                if c > 0:
+                    d_in = d if d.shape[0] == c else d[:c]
+                    if self.dual_stream:
+                        r, d = encoder_stage_pair(self, j, r_in, d_in)
+                    else:
+                        r = getattr(er, f'forward_layer{j}')(r_in)
+                        d = getattr(ed, f'forward_layer{j}')(d_in)
+                    fuse = ops.se_fuse_blend(r, d, self._se(j), wc, j - 1, inplace=True)
+                else:
+                    r = getattr(er, f'forward_layer{j}')(r_in)
+                    fuse, d = r, None                # every sample skips depth from here on
                 if j < 4:
                     sk = getattr(self, f'skip_layer{j}')
                     skips.append(sk[0](fuse) if len(sk) else fuse)
-                continue
-            if compacted and self.dual_stream and all(branch[n] >= j for n in alive) and len(alive) == bs:
-                # every sample still fuses at this stage: same two-stream overlap as the dense path
-                r, d = encoder_stage_pair(self, j, r if j == 1 else fuse, d)
-                self.last_stage_batch.append(bs)
-                fuse = ops.se_fuse_blend(r, d, self._se(j))
-                if j < 4:
-                    sk = getattr(self, f'skip_layer{j}')
-                    skips.append(sk[0](fuse) if len(sk) else fuse)
-                continue
-            r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
-            if not compacted:
-                d = getattr(ed, f'forward_layer{j}')(d)
+        else:
+            for j in (1, 2, 3, 4):
+                if self.dual_stream:
+                    r, d = encoder_stage_pair(self, j, r if j == 1 else fuse, d)
+                else:
+                    r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
+                    d = getattr(ed, f'forward_layer{j}')(d)
                 # stage j<4: w*rgb + (1-w)*fused with w = sum_{k<j} weight[:,k];  stage 4: w = 1-weight[:,4]
                 fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
-            else:
-                keep = [pos for pos, n in enumerate(alive) if branch[n] >= j]
-                if len(keep) < len(alive) and keep:
-                    d = ops.batch_gather(d, torch.tensor(keep, dtype=torch.int32, device=r.device))
-                alive = [alive[pos] for pos in keep]
-                self.last_stage_batch.append(len(alive))
-                if not alive:
-                    fuse, d = r, None            # every sample skips depth from here on
-                else:
-                    d = getattr(ed, f'forward_layer{j}')(d)
-                    if len(alive) == bs:
-                        fuse = ops.se_fuse_blend(r, d, self._se(j))          # w = 0 for every sample
-                    else:
-                        idx = torch.tensor(alive, dtype=torch.int32, device=r.device)
-                        fused = ops.se_fuse_blend(ops.batch_gather(r, idx), d, self._se(j))
-                        mapping = torch.full((bs,), -1, dtype=torch.int32)
-                        mapping[alive] = torch.arange(len(alive), dtype=torch.int32)
-                        fuse = ops.batch_merge(r, fused, mapping.to(r.device))
-            if j < 4:
-                sk = getattr(self, f'skip_layer{j}')
-                skips.append(sk[0](fuse) if len(sk) else fuse)
+                if j < 4:
+                    sk = getattr(self, f'skip_layer{j}')
+                    skips.append(sk[0](fuse) if len(sk) else fuse)
         out = self.context_module(fuse)
-        out = self.decoder([out, skips[2], skips[1], skips[0]])
+        out = self.decoder([out, skips[2], skips[1], skips[0]], unpermute=unpermute)
 
         if test:
             return (out, weight) if return_weight else out

@@ -56,7 +56,6 @@ def _chk(t, name='tensor'):
 #            inference) because the kernels are operand-delivery bound, so 'fp32' stays the default.
 #   'bf16x6' 3 pieces / 6 products (24 bits, fp32-rounding class) — correct but slower than fp32 MFMA
 #            on MI355X (124 vs 110 ms/step); kept for reference.
-import os as _os
 PRECISION = _os.environ.get('DYNMM_PRECISION', 'fp32')
 _NSPLIT = {'bf16x3': 2, 'bf16x6': 3, 'auto': 2}
 
@@ -107,13 +106,49 @@ def join_async():
     _INFLIGHT.clear()
 
 
+# Bookkeeping of the in-place gradient protocol.  Every backward that writes a parameter gradient straight
+# into its `.grad` view registers the parameter in _PENDING (via _grad_dst) and, once the kernels that write
+# it are enqueued, calls _grads_enqueued(streams): the parameter joins the set of parameters touched in this
+# step (the flat optimizers update only those ranges, as torch.optim skips parameters whose grad is None) and
+# GRAD_READY_HOOK — installed by dp.GradBucketReducer — learns that the gradient will be complete once the
+# given streams reach this point, so a bucket's all-reduce can start while the rest of backward still runs.
+GRAD_READY_HOOK = None
+_PENDING = []
+_TOUCHED = set()
+
+
+def touched_reset():
+    _TOUCHED.clear()
+    _PENDING.clear()
+
+
+def touched_ids():
+    return frozenset(_TOUCHED)
+
+
 def _grad_dst(param, like=None):
     """(tensor to write the gradient into, value to return to autograd)."""
     if DIRECT_GRAD and param is not None and getattr(param, 'grad', None) is not None and param.grad.is_contiguous() \
             and param.grad.dtype == torch.float32:
+        _PENDING.append(param)
         return param.grad, None
     t = torch.empty_like(param if like is None else like)
     return t, t
+
+
+def _grads_enqueued(*streams):
+    """The kernels writing the gradients handed out by _grad_dst since the last call are enqueued on `streams`
+    (default: the current stream)."""
+    if not _PENDING:
+        return
+    hook = GRAD_READY_HOOK
+    if hook is not None:
+        ss = [s for s in streams if s is not None] or [torch.cuda.current_stream()]
+        for prm in _PENDING:
+            hook(prm, ss)
+    for prm in _PENDING:
+        _TOUCHED.add(id(prm))
+    _PENDING.clear()
 
 
 # Optional per-launch timing of the implicit-GEMM kernels (bench.py's roofline leg): when PROFILE is a
@@ -258,8 +293,12 @@ class _Conv2d(Function):
             dbias, dbias_ret = _grad_dst(ctx.b_param)
         if act != L.ACT_NONE or (ctx.has_bias and not bias_in_wgrad):
             ge = torch.empty_like(gy) if act != L.ACT_NONE else None
-            L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), None if bias_in_wgrad else _p(dbias), g.N, g.Co,
-                                           g.Ho * g.Wo, act, st), 'act_bwd_bias')
+            wsb = None
+            if not bias_in_wgrad and dbias is not None:
+                nb = lib.dynmm_act_bwd_bias_workspace_bytes(g.N, g.Co)
+                wsb = torch.empty(max(nb // 4, 1), device=gy.device, dtype=torch.float32)
+            L.check(lib.dynmm_act_bwd_bias(_p(gy), _p(y), _p(ge), None if bias_in_wgrad else _p(dbias), _p(wsb),
+                                           g.N, g.Co, g.Ho * g.Wo, act, st), 'act_bwd_bias')
             if ge is not None:
                 gy = ge
         dx = dx2 = None
@@ -277,6 +316,7 @@ class _Conv2d(Function):
                 L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
                                                                           _p(dx2), C.byref(g), st)), 'conv2d_dgrad')
         dw_ret = None
+        ws_stream = None
         if ctx.needs_input_grad[2]:
             dw, dw_ret = _grad_dst(ctx.w_param)
             nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
@@ -293,6 +333,7 @@ class _Conv2d(Function):
                 L.check(_timed('wgrad', g, lambda: lib.dynmm_conv2d_wgrad(_p(x), _p(x2), _p(gy), _p(dw),
                                                                           _p(dbias) if bias_in_wgrad else None, _p(ws), nbytes,
                                                                           C.byref(g), st)), 'conv2d_wgrad')
+        _grads_enqueued(torch.cuda.current_stream(), ws_stream)
         return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None
 
 
@@ -462,6 +503,7 @@ class _BatchNormAct(Function):
             dres = gy            # no activation: the residual branch receives the gradient unchanged
         if ctx.link is not None and dres is not None:
             ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
+        _grads_enqueued()
         return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None
 
 
@@ -610,8 +652,13 @@ class _Upsample2xDw(Function):
             dw, dw_ret = _grad_dst(ctx.w_param)
             if ctx.has_bias:
                 db, db_ret = _grad_dst(ctx.b_param)
-        L.check(lib.dynmm_upsample2x_dw3x3_bwd(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), N, Cc, H, W,
+        ws = None
+        if dw is not None:
+            nb = lib.dynmm_upsample2x_dw3x3_bwd_workspace_bytes(N, Cc)
+            ws = torch.empty(max(nb // 4, 1), device=g.device, dtype=torch.float32)
+        L.check(lib.dynmm_upsample2x_dw3x3_bwd(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), _p(ws), N, Cc, H, W,
                                                _stream()), 'upsample_bwd')
+        _grads_enqueued()
         return dx, dw_ret, db_ret, (g if ctx.has_skip else None)
 
 
@@ -630,15 +677,21 @@ def _ptr_array(tensors):
 
 class _SEFuseBlend(Function):
     """out = wc*rgb + (1-wc)*(SE_rgb(rgb) + SE_depth(depth))   ('add' mode: SE = identity).
-    wc = wcum[:, col] (per-sample scalar) or 0 when wcum is None."""
+    wc = wcum[:, col] (per-sample scalar) or 0 when wcum is None.
+
+    Compacted form (K16): `depth` holds only the first n_act samples of the (branch-sorted) batch; the fusion is
+    evaluated on that prefix and out[n_act:] = rgb[n_act:] (samples that skip this stage).  `inplace` (inference
+    only) writes the prefix into rgb's own storage, so skipped samples cost no memory traffic at all."""
 
     @staticmethod
-    def forward(ctx, rgb, depth, wcum, col, use_se, *params):
+    def forward(ctx, rgb, depth, wcum, col, use_se, inplace, *params):
         lib = _lib()
         st = _stream()
         rgb, depth = _chk(rgb, 'rgb'), _chk(depth, 'depth')
-        _same_shape(rgb, depth, 'rgb/depth fusion')
         N, Cc, H, W = rgb.shape
+        n_act = depth.shape[0]
+        if n_act > N or tuple(depth.shape[1:]) != tuple(rgb.shape[1:]) or n_act <= 0:
+            raise L.DynmmHipError(f'rgb/depth fusion: shape mismatch {tuple(rgb.shape)} vs {tuple(depth.shape)}')
         HW = H * W
         dev = rgb.device
         f32 = dict(device=dev, dtype=torch.float32)
@@ -652,15 +705,20 @@ class _SEFuseBlend(Function):
         if use_se:
             params = [_chk(p, 'se param') for p in params]
             parr = _ptr_array(params)
-            sr, sd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
-            L.check(lib.dynmm_gap2_fwd(_p(rgb), _p(depth), _p(sr), _p(sd), N * Cc, HW, st), 'gap2')
-            hr, hd = torch.empty((N, Cc // 16), **f32), torch.empty((N, Cc // 16), **f32)
-            gr, gd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
-        a, b = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            sr, sd = torch.empty((n_act, Cc), **f32), torch.empty((n_act, Cc), **f32)
+            L.check(lib.dynmm_gap2_fwd(_p(rgb), _p(depth), _p(sr), _p(sd), n_act * Cc, HW, st), 'gap2')
+            hr, hd = torch.empty((n_act, Cc // 16), **f32), torch.empty((n_act, Cc // 16), **f32)
+            gr, gd = torch.empty((n_act, Cc), **f32), torch.empty((n_act, Cc), **f32)
+        a, b = torch.empty((n_act, Cc), **f32), torch.empty((n_act, Cc), **f32)
         L.check(lib.dynmm_se_coeff_fwd(_p(sr), _p(sd), parr, wc_ptr, wc_stride, _p(a), _p(b),
-                                       _p(hr), _p(hd), _p(gr), _p(gd), N, Cc, int(use_se), st), 'se_coeff_fwd')
-        out = torch.empty_like(rgb)
-        L.check(lib.dynmm_axpby_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(out), N * Cc, HW, st), 'axpby_fwd')
+                                       _p(hr), _p(hd), _p(gr), _p(gd), n_act, Cc, int(use_se), st), 'se_coeff_fwd')
+        if inplace and n_act < N:
+            out = rgb                                   # prefix overwritten below, tail untouched
+            ctx.mark_dirty(rgb)
+        else:
+            out = torch.empty_like(rgb)
+            _copy_rows(rgb, out, n_act, N - n_act)
+        L.check(lib.dynmm_axpby_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(out), n_act * Cc, HW, st), 'axpby_fwd')
         ctx.use_se = use_se
         ctx.col = col
         ctx.n_params = len(params)
@@ -676,10 +734,11 @@ class _SEFuseBlend(Function):
         params = list(ctx.saved_tensors[11:])
         g = _chk(g, 'grad')
         N, Cc, H, W = rgb.shape
+        n_act = depth.shape[0]
         HW = H * W
         f32 = dict(device=g.device, dtype=torch.float32)
-        da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
-        L.check(lib.dynmm_axpby_bwd_reduce(_p(g), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, HW, st), 'axpby_bwd_reduce')
+        da, db = torch.empty((n_act, Cc), **f32), torch.empty((n_act, Cc), **f32)
+        L.check(lib.dynmm_axpby_bwd_reduce(_p(g), _p(rgb), _p(depth), _p(da), _p(db), n_act * Cc, HW, st), 'axpby_bwd_reduce')
         dparams = dparams_ret = [None] * ctx.n_params
         dsr = dsd = None
         parr = dparr = None
@@ -687,29 +746,33 @@ class _SEFuseBlend(Function):
             pairs = [_grad_dst(po) for po in ctx.param_objs]     # straight into the flat .grad views when possible
             dparams, dparams_ret = [d for d, _ in pairs], [r for _, r in pairs]
             parr, dparr = _ptr_array(params), _ptr_array(dparams)
-            dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            dsr, dsd = torch.empty((n_act, Cc), **f32), torch.empty((n_act, Cc), **f32)
         dwcum = None
         wc_ptr, wc_stride, dwc_ptr = None, 0, None
         if wcum is not None:
             wc_stride = wcum.shape[1]
             wc_ptr = wcum.data_ptr() + 4 * ctx.col
             if ctx.needs_input_grad[2]:
-                dwcum = torch.zeros_like(wcum)
+                dwcum = torch.zeros_like(wcum)           # samples past n_act: no gate gradient from this stage
                 dwc_ptr = dwcum.data_ptr() + 4 * ctx.col
+        ws = torch.empty(lib.dynmm_se_coeff_bwd_workspace_bytes(n_act, Cc) // 4, **f32) if ctx.use_se else None
         L.check(lib.dynmm_se_coeff_bwd(_p(da), _p(db), _p(sr), _p(sd), parr, wc_ptr, wc_stride,
                                        _p(hr), _p(hd), _p(gr), _p(gd), dparr, _p(dsr), _p(dsd),
-                                       dwc_ptr, wc_stride, N, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
+                                       dwc_ptr, wc_stride, _p(ws), n_act, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
         drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
         L.check(lib.dynmm_axpby_bwd_apply(_p(g), _p(a), _p(b), _p(dsr), _p(dsd), 1.0 / HW,
-                                          _p(drgb), _p(ddepth), N * Cc, HW, st), 'axpby_bwd_apply')
-        return (drgb, ddepth, dwcum, None, None, *dparams_ret)
+                                          _p(drgb), _p(ddepth), n_act * Cc, HW, st), 'axpby_bwd_apply')
+        _copy_rows(g, drgb, n_act, N - n_act)            # skipped samples: out = rgb
+        _grads_enqueued()
+        return (drgb, ddepth, dwcum, None, None, None, *dparams_ret)
 
 
-def se_fuse_blend(rgb, depth, se_params=None, wcum=None, col=0):
-    """se_params: None ('add' fusion) or the 8 tensors (W1r,b1r,W2r,b2r,W1d,b1d,W2d,b2d)."""
+def se_fuse_blend(rgb, depth, se_params=None, wcum=None, col=0, inplace=False):
+    """se_params: None ('add' fusion) or the 8 tensors (W1r,b1r,W2r,b2r,W1d,b1d,W2d,b2d).
+    depth may hold only a PREFIX of rgb's batch (compaction): the remaining samples pass rgb through."""
     use_se = se_params is not None
     params = tuple(se_params) if use_se else ()
-    return _SEFuseBlend.apply(rgb, depth, wcum, col, use_se, *params)
+    return _SEFuseBlend.apply(rgb, depth, wcum, col, use_se, bool(inplace) and not torch.is_grad_enabled(), *params)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -803,12 +866,14 @@ class _ReweighFuse(Function):
             if prev is not None and ctx.needs_input_grad[3]:
                 d_prev = torch.empty((N,), **f32)
         if need_wb or gate_bwd:
+            ws = torch.empty(lib.dynmm_reweigh_bwd_workspace_bytes(N, Cc) // 4, **f32) if gate_bwd else None
             L.check(lib.dynmm_reweigh_bwd(_p(d_wnext) if gate_bwd else None, _p(da), _p(db), _p(sr), _p(sd), parr,
                                           _p(prev), 1, _p(h), _p(gg), _p(aux), dparr, _p(dsr), _p(dsd),
-                                          _p(d_wblend), _p(d_prev), temp, N, Cc, st), 'reweigh_bwd')
+                                          _p(d_wblend), _p(d_prev), _p(ws), temp, N, Cc, st), 'reweigh_bwd')
         drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
         L.check(lib.dynmm_axpby_bwd_apply(_p(g), _p(a), _p(b), _p(dsr), _p(dsd), 1.0 / HW,
                                           _p(drgb), _p(ddepth), N * Cc, HW, st), 'axpby_bwd_apply')
+        _grads_enqueued()
         return (drgb, ddepth, d_wblend, d_prev, None, None, None, None, None, *dparams_ret)
 
 
@@ -830,7 +895,7 @@ def reweigh_fuse(rgb, depth, wblend=None, blend_mode=1, gate_params=None, temp=1
 # ------------------------------------------------------------------------------------------------
 class _GateHead(Function):
     @staticmethod
-    def forward(ctx, pooled, fc, flop_table, temp, hard):
+    def forward(ctx, pooled, fc, flop_table, temp, hard, force):
         lib = _lib()
         pooled, fc = _chk(pooled, 'pooled'), _chk(fc, 'fc')
         N = pooled.shape[0]
@@ -839,7 +904,8 @@ class _GateHead(Function):
         weight, wcum, soft = torch.empty((N, 5), **f32), torch.empty((N, 4), **f32), torch.empty((N, 5), **f32)
         loss = torch.empty((), **f32)
         L.check(lib.dynmm_gate_head_fwd(_p(pooled), _p(fc), _p(weight), _p(wcum), _p(soft), _p(loss),
-                                        _p(flop_table), N, J, float(temp), int(hard), 0, _stream()), 'gate_head_fwd')
+                                        _p(flop_table), None if force is None else force.data_ptr(), N, J,
+                                        float(temp), int(hard), 0, _stream()), 'gate_head_fwd')
         ctx.temp = float(temp)
         ctx.fc_param = fc
         ctx.save_for_backward(pooled, fc, soft, flop_table)
@@ -857,12 +923,16 @@ class _GateHead(Function):
         L.check(lib.dynmm_gate_head_bwd(_p(d_weight), _p(d_wcum), _p(d_loss), _p(pooled), _p(fc), _p(soft),
                                         _p(flop_table), _p(d_pooled), _p(d_fc), N, J, ctx.temp, _stream()),
                 'gate_head_bwd')
-        return d_pooled, d_fc_ret, None, None, None
+        _grads_enqueued()
+        return d_pooled, d_fc_ret, None, None, None, None
 
 
-def gate_head(pooled, fc_weight, flop_table, temp, hard):
-    """(weight[N,5], wcum[N,4], flop_loss) from the pooled gate features."""
-    return _GateHead.apply(pooled, fc_weight, flop_table, temp, hard)
+def gate_head(pooled, fc_weight, flop_table, temp, hard, force_branch=None):
+    """(weight[N,5], wcum[N,4], flop_loss) from the pooled gate features.  `force_branch` (device int32 [N],
+    hard gates only): fixed branch per sample instead of the arg-max (benchmark / test knob)."""
+    if force_branch is not None and (force_branch.dtype != torch.int32 or not force_branch.is_cuda):
+        raise L.DynmmHipError('force_branch must be a device int32 tensor')
+    return _GateHead.apply(pooled, fc_weight, flop_table, temp, hard, force_branch)
 
 
 def gate_from_weight(weight, flop_table):
@@ -872,16 +942,30 @@ def gate_from_weight(weight, flop_table):
     N = weight.shape[0]
     f32 = dict(device=weight.device, dtype=torch.float32)
     wcum, soft, loss = torch.empty((N, 4), **f32), torch.empty((N, 5), **f32), torch.empty((), **f32)
-    L.check(lib.dynmm_gate_head_fwd(None, None, _p(weight), _p(wcum), _p(soft), _p(loss), _p(flop_table),
+    L.check(lib.dynmm_gate_head_fwd(None, None, _p(weight), _p(wcum), _p(soft), _p(loss), _p(flop_table), None,
                                     N, 0, 1.0, 0, 1, _stream()), 'gate_head_fwd(mode 1)')
     return weight, wcum, loss
 
 
 # ------------------------------------------------------------------------------------------------
-# gate-decision compaction (inference only)
+# gate-decision compaction (K16)
 # ------------------------------------------------------------------------------------------------
+def gate_decide(weight):
+    """Compaction plan from one-hot gate weights [N,5], computed on the device:
+    (branch[N], order[N], inv[N], counts[4]) int32 — see dynmm_gate_decide."""
+    lib = _lib()
+    weight = _chk(weight.detach(), 'weight')
+    N = weight.shape[0]
+    i32 = dict(device=weight.device, dtype=torch.int32)
+    branch, order, inv, counts = (torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32),
+                                  torch.empty(4, **i32))
+    L.check(lib.dynmm_gate_decide(_p(weight), branch.data_ptr(), order.data_ptr(), inv.data_ptr(), counts.data_ptr(),
+                                  N, _stream()), 'gate_decide')
+    return branch, order, inv, counts
+
+
 def batch_gather(x, index):
-    """x[index] along the batch axis; `index` is a device int32 tensor."""
+    """x[index] along the batch axis; `index` is a device int32 tensor.  Not differentiable (see batch_permute)."""
     lib = _lib()
     x = _chk(x, 'x')
     n_out = index.numel()
@@ -889,6 +973,24 @@ def batch_gather(x, index):
     row = x[0].numel()
     L.check(lib.dynmm_batch_gather(_p(x), index.data_ptr(), _p(out), n_out, C.c_size_t(row), _stream()), 'batch_gather')
     return out
+
+
+class _BatchPermute(Function):
+    @staticmethod
+    def forward(ctx, x, index, inverse):
+        ctx.save_for_backward(index, inverse)
+        return batch_gather(x, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        index, inverse = ctx.saved_tensors
+        return batch_gather(_chk(g, 'grad'), inverse), None, None
+
+
+def batch_permute(x, index, inverse):
+    """x[index] for a PERMUTATION `index` of the batch (device int32) with inverse `inverse`; differentiable:
+    the gradient is gathered back with the inverse permutation."""
+    return _BatchPermute.apply(x, index, inverse)
 
 
 def batch_merge(base, sub, mapping):
@@ -900,6 +1002,16 @@ def batch_merge(base, sub, mapping):
     L.check(lib.dynmm_batch_merge(_p(base), _p(sub), mapping.data_ptr(), _p(out), base.shape[0], C.c_size_t(row),
                                   _stream()), 'batch_merge')
     return out
+
+
+def _copy_rows(src, dst, row0, n_rows):
+    """dst[row0:row0+n_rows] = src[row0:row0+n_rows] (whole samples), on the current stream."""
+    if n_rows <= 0:
+        return
+    row = src[0].numel()
+    off = row0 * row * 4
+    L.check(_lib().dynmm_batch_gather(src.data_ptr() + off, None, dst.data_ptr() + off, n_rows, C.c_size_t(row),
+                                      _stream()), 'copy_rows')
 
 
 # ------------------------------------------------------------------------------------------------

@@ -33,6 +33,24 @@ def one_cycle_lr(epoch, total_steps, max_lr, div_factor=25.0, pct_start=0.1, fin
     return cos(max_lr, min_lr, min(pct, 1.0))
 
 
+def one_cycle_momentum(epoch, total_steps, base_momentum=0.85, max_momentum=0.95, pct_start=0.1):
+    """Momentum (SGD) / beta1 (Adam) that the reference's OneCycleLR writes into the optimizer at the same
+    step: it is built with the default cycle_momentum=True (train.py:120-128), which OVERWRITES the optimizer's
+    momentum every scheduler step with the mirror image of the lr curve — max_momentum at the start, down to
+    base_momentum at peak lr, back up to max_momentum (so --momentum is effectively ignored by the reference)."""
+    up_end = float(pct_start * total_steps) - 1.0
+    down_end = float(total_steps) - 1.0
+
+    def cos(start, end, pct):
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    if epoch <= up_end or up_end <= 0 and epoch <= 0:
+        pct = epoch / up_end if up_end > 0 else 1.0
+        return cos(max_momentum, base_momentum, pct)
+    pct = (epoch - up_end) / (down_end - up_end)
+    return cos(base_momentum, max_momentum, min(pct, 1.0))
+
+
 def scaled_lr(lr, batch_size):
     """train.py:46-49: the CLI learning rate refers to batch 8 (use the GLOBAL batch under DP)."""
     return lr if batch_size == 8 else lr * batch_size / 8

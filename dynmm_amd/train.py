@@ -64,13 +64,16 @@ def train_main(argv=None):
 def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
     dp.broadcast_parameters(model)
     cw = train_loader.compute_class_weights(args.class_weighting) if args.class_weighting != 'None' else np.ones(40)
-    if args.freeze:
-        raise NotImplementedError('--freeze: see TrainStep note')
+    if args.freeze and args.dynamic:                      # train.py:139-141
+        print('Freeze everything but the soft gates')
+        model.freeze()
     step = engine.TrainStep(model, cw, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay,
-                            loss_ratio=args.loss_ratio, flop_budget=args.flop_budget, use_graph=args.hip_graph)
+                            loss_ratio=args.loss_ratio, flop_budget=args.flop_budget, use_graph=args.hip_graph,
+                            optimizer=args.optimizer)
+    print('Using {} as optimizer'.format(args.optimizer))
     temp = schedules.ExpDecayTemp(args.temp, args.end_temp, args.epoch_hard)
     model.baseline = args.baseline
-    best_miou, best_epoch, logs = 0.0, 0, []
+    best_miou, best_epoch, best_state, logs = 0.0, 0, None, []
     for epoch in range(args.epochs):
         assert args.epoch_ini <= args.epoch_hard
         model.ini_stage = epoch < args.epoch_ini
@@ -78,6 +81,8 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
         model.temp = temp.get_t(epoch)
         lr = schedules.one_cycle_lr(epoch, args.epochs, args.lr)
         step.opt.set_lr(lr)
+        # OneCycleLR(cycle_momentum=True) also rewrites the momentum (SGD) / beta1 (Adam) every epoch
+        step.opt.set_momentum(schedules.one_cycle_momentum(epoch, args.epochs))
         model.train()
         t0, tot, flop, nb = time.time(), [], [], 0
         for i, sample in enumerate(train_loader):
@@ -88,10 +93,15 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
             nb += 1
             if args.debug:
                 break
-        total = torch.stack(tot).mean().item()          # one device->host sync per EPOCH (reference: per step)
+        # NaN guard: every step's loss is inspected on the device by the optimizer kernel (a non-finite loss
+        # skips the update and latches the step index); the host reads the latch once per epoch instead of
+        # synchronising on the loss every step (train.py:328-335).
+        step.opt.check_finite()
+        total = torch.cat([t.reshape(1) for t in tot]).mean().item()
         if np.isnan(total):
             raise ValueError('Loss is None')
-        row = {'epoch': epoch, 'lr_0': lr, 'loss_train_total': total, 'loss_flop': torch.stack(flop).mean().item(),
+        row = {'epoch': epoch, 'lr_0': lr, 'loss_train_total': total,
+               'loss_flop': torch.stack([f.reshape(()) for f in flop]).mean().item(),
                'time_training': time.time() - t0, 'temp': model.temp}
         if epoch == 0 or epoch % args.eval_every == 0:
             batches = ((s['image'], s['depth'], s['label_orig']) for s in valid_loader)
@@ -99,6 +109,8 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
             row['mIoU_test'] = miou
             if miou > best_miou:
                 best_miou, best_epoch = miou, epoch
+                # train.py:235 deep-copies the model here; a CPU snapshot of its state_dict is what gets saved
+                best_state = {k: v.detach().to('cpu', copy=True) for k, v in model.state_dict().items()}
         if rank == 0:
             print(f"Epoch {epoch} | Train loss {row['loss_train_total']:.4f} | Flop loss {row['loss_flop']:.4f} "
                   f"Temperature {model.temp} | lr {lr}" + (f" | mIoU {row['mIoU_test']:.2f}" if 'mIoU_test' in row else ''))
@@ -106,7 +118,10 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
                 save_ckpt(ckpt_dir, model, step.opt, epoch)
         logs.append(row)
     if rank == 0:
-        save_ckpt(ckpt_dir, model, step.opt, best_epoch)
+        # train.py:250: the BEST model's weights under the best epoch's name
+        path = os.path.join(ckpt_dir, f'ckpt_epoch_{best_epoch}.pth')
+        state = best_state if best_state is not None else {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        torch.save({'epoch': best_epoch, 'state_dict': state, 'optimizer': step.opt.state_dict()}, path)
         with open(os.path.join(ckpt_dir, 'finished.txt'), 'w') as f:
             f.write(f'best miou: {best_miou}\nbest miou epoch: {best_epoch}\n')
     if world > 1:

@@ -14,8 +14,8 @@
  *     synchronising, so calls are capturable in a hipGraph;
  *   - return value: 0 on success, a negative DYNMM_E* code on bad arguments, or -(1000+hipError_t)
  *     if a launch failed.  Nothing throws across the boundary;
- *   - reduction outputs ("double* sums", dbias, dw of the depthwise conv, SE/gate parameter
- *     gradients) are zeroed by the callee (hipMemsetAsync on `stream`) before accumulation.
+ *   - reduction outputs ("double* sums", dbias, dw of the depthwise conv) are zeroed by the callee
+ *     (hipMemsetAsync on `stream`) before accumulation; SE / gate parameter gradients are plain stores.
  */
 #ifndef DYNMM_HIP_H
 #define DYNMM_HIP_H
@@ -106,8 +106,10 @@ int dynmm_conv2d_dgrad_bf16(const float* dy, const unsigned short* wd_split, int
                             const dynmm_conv_geom* g, void* stream);
 
 /* g_out = g * act'(y) ; dbias[c] = sum_{n,hw} g_out   (either output may be NULL).
- * ReLU/tanh backward + bias gradient of a conv+bias+act (autograd of resnet.py:125-126 etc.). */
-int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias,
+ * ReLU/tanh backward + bias gradient of a conv+bias+act (autograd of resnet.py:125-126 etc.).
+ * dbias is summed over sample splits through `workspace` (>= *_workspace_bytes) in a fixed order. */
+size_t dynmm_act_bwd_bias_workspace_bytes(int N, int C);
+int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbias, float* workspace,
                        int N, int C, int HW, int act, void* stream);
 
 /* ---- BatchNorm2d (src/models/resnet.py:59,110; model_utils.py:22; …globalgate.py:381,384) ---- */
@@ -163,8 +165,9 @@ int dynmm_nearest_into_bwd(const float* g_out, float* dy, int N, int C, int h, i
  * plus the decoder's `out += encoder_features` (model.py:354-355) when skip != NULL. */
 int dynmm_upsample2x_dw3x3_fwd(const float* x, const float* w, const float* b, const float* skip,
                                float* y, int N, int C, int H, int W, void* stream);
+size_t dynmm_upsample2x_dw3x3_bwd_workspace_bytes(int N, int C);
 int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const float* w,
-                               float* dx, float* dw, float* db,
+                               float* dx, float* dw, float* db, float* workspace,
                                int N, int C, int H, int W, void* stream);
 
 /* ---- SE fusion + gated blend (rgb_depth_fusion.py:22-26, model_utils.py:47-51, …globalgate.py:282-310) ---- */
@@ -180,11 +183,15 @@ int dynmm_se_coeff_fwd(const float* sr, const float* sd, const float* const* par
                        const float* wc, int wc_stride, float* a, float* b,
                        float* hr, float* hd, float* gr, float* gd,
                        int N, int C, int use_se, void* stream);
+/* backward: per-sample pass (pre-activation gradients of both MLPs into `workspace`,
+ * >= dynmm_se_coeff_bwd_workspace_bytes(N, C); pooled gradients dsr/dsd; dwc) followed by the parameter
+ * gradients summed over the samples in a fixed order — no float atomics, bit-reproducible. */
+size_t dynmm_se_coeff_bwd_workspace_bytes(int N, int C);
 int dynmm_se_coeff_bwd(const float* da, const float* db, const float* sr, const float* sd,
                        const float* const* params, const float* wc, int wc_stride,
                        const float* hr, const float* hd, const float* gr, const float* gd,
                        float* const* dparams, float* dsr, float* dsd, float* dwc, int dwc_stride,
-                       int N, int C, int use_se, void* stream);
+                       float* workspace, int N, int C, int use_se, void* stream);
 /* out = a[n,c]*xr + b[n,c]*xd */
 int dynmm_axpby_fwd(const float* xr, const float* xd, const float* a, const float* b, float* out,
                     int NC, int HW, void* stream);
@@ -215,19 +222,23 @@ int dynmm_reweigh_fwd(const float* sr, const float* sd, const float* const* para
                       const float* noise, unsigned long long seed, unsigned long long offset,
                       float temp, int hard, float* a, float* b, float* wnext, float* h, float* g,
                       float* aux, int N, int C, void* stream);
+size_t dynmm_reweigh_bwd_workspace_bytes(int N, int C);
 int dynmm_reweigh_bwd(const float* d_wnext, const float* da, const float* db, const float* sr,
                       const float* sd, const float* const* params, const float* prev, int prev_stride,
                       const float* h, const float* g, const float* aux, float* const* dparams,
-                      float* dsr, float* dsd, float* d_wblend, float* d_prev, float temp,
+                      float* dsr, float* dsd, float* d_wblend, float* d_prev, float* workspace, float temp,
                       int N, int C, void* stream);
 
 /* ---- global gate head (…globalgate.py:20-30, 263-272, 314-315, 391-394) ----
  * mode 0: logits = fc[5,J] . pooled[n,J];  weight = DiffSoftmax(logits, temp, hard)
  * mode 1: weight given (baseline / ini_stage one-hots), pooled/fc ignored
  * outputs: weight[N,5]; wcum[N,4] = {w0, w0+w1, w0+w1+w2, 1-w4}; soft[N,5] (saved);
- *          flop_loss = mean_k( mean_n(weight)[k] * flop_table[k] ). */
+ *          flop_loss = mean_k( mean_n(weight)[k] * flop_table[k] ).
+ * force_branch (optional, device int[N]; benchmark / test knob): with hard != 0 the straight-through one-hot is
+ * taken at force_branch[n] instead of the arg-max — a FIXED synthetic branch distribution with the gate
+ * network, its soft output and its gradient still evaluated (BASELINE configs[3]). */
 int dynmm_gate_head_fwd(const float* pooled, const float* fc, float* weight, float* wcum,
-                        float* soft, float* flop_loss, const float* flop_table,
+                        float* soft, float* flop_loss, const float* flop_table, const int* force_branch,
                         int N, int J, float temp, int hard, int mode, void* stream);
 int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, const float* d_loss,
                         const float* pooled, const float* fc, const float* soft,
@@ -253,16 +264,38 @@ int dynmm_eval_confusion(const float* logits, const unsigned char* label, long l
  * gather: dst[i] = src[idx[i]]  (i < n_out);  merge: out[n] = map[n] >= 0 ? sub[map[n]] : base[n].
  * Rows are whole samples of `row` floats; idx/map are device int32. */
 int dynmm_batch_gather(const float* src, const int* idx, float* dst, int n_out, size_t row, void* stream);
+/* (idx == NULL: plain copy of n_out rows.)
+ * Gate decision -> compaction plan, on the device: branch[n] = arg-max of the one-hot gate weights [N,5];
+ * order = samples sorted by branch, descending, stable; inv = inverse permutation;
+ * counts[j-1] = #{n : branch[n] >= j} (j = 1..4).  In the sorted batch the samples that run depth stage j are the
+ * contiguous prefix of length counts[j-1]: stages run on prefix views, and the only device->host traffic of a
+ * compacted forward is these 4 ints. */
+int dynmm_gate_decide(const float* weight, int* branch, int* order, int* inv, int* counts, int N, void* stream);
 int dynmm_batch_merge(const float* base, const float* sub, const int* map, float* out, int N, size_t row,
                       void* stream);
 
 /* ---- helpers ---- */
 /* out[i] = sum_s slabs[s][i] */
 int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nslabs, void* stream);
-/* fused SGD-Nesterov step over one flat parameter/grad/momentum buffer (train.py:557-563):
- * g += wd*p; buf = mom*buf + g; p -= lr*(g + mom*buf). lr is a device scalar (graph-friendly). */
-int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const float* lr,
-                       float momentum, float weight_decay, float grad_scale, void* stream);
+/* ---- fused flat optimizers (train.py:554-579), SURVEY §8f-1 ----
+ * p / g / state are the 16-byte aligned bases of flat fp32 buffers; one call updates the element range
+ * [lo, hi) (parameters that took no gradient in a step are skipped by the caller, as torch.optim does).
+ * hyper: DEVICE float array — SGD {lr, momentum}, Adam {lr, beta1, beta2, eps} — so values the driver changes
+ * between steps (OneCycleLR: lr and momentum/beta1, train.py:119-128) reach a captured hipGraph.
+ * step: DEVICE int step counter of the range's parameter group, incremented by dynmm_opt_tick before the call
+ * (Adam's bias correction; torch keeps one counter per parameter).
+ * loss / nan_flag (optional): if *loss is not finite the update is skipped and *nan_flag (int, zeroed by the
+ * caller) latches 1 + *step — the device-side form of train.py:334-335.
+ *   SGD : d = g*grad_scale + wd*p;  buf = mom*buf + d;  p -= lr*(d + mom*buf)            (nesterov)
+ *   Adam: d as above; m = b1*m + (1-b1)*d; v = b2*v + (1-b2)*d*d;
+ *         p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)                                        */
+int dynmm_opt_tick(int* step, void* stream);
+int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t lo, size_t hi, const float* hyper,
+                       float weight_decay, float grad_scale, const float* loss, int* nan_flag,
+                       const int* step, void* stream);
+int dynmm_adam(float* p, const float* g, float* m, float* v, size_t lo, size_t hi, const float* hyper,
+               const int* step, float weight_decay, float grad_scale, const float* loss, int* nan_flag,
+               void* stream);
 
 #ifdef __cplusplus
 }

@@ -302,9 +302,9 @@ def forward_skip(sd, rgb, depth, cfg: Config, exp_noise, training=False, test=Fa
 # --------------------------------------------------------------------------------------------
 def cross_entropy_2d(logits_scales, target_scales, class_weight):
     """CrossEntropyLoss2d.forward (src/utils.py:34-50).  targets: 0 = void, 1..C = classes."""
-    cw = torch.as_tensor(class_weight, dtype=torch.float32)
     losses = []
     for x, t in zip(logits_scales, target_scales):
+        cw = torch.as_tensor(class_weight).to(x.dtype)       # float32 as the reference; float64 for the fp64 truth runs
         per_px = F.cross_entropy(x, t.long() - 1, weight=cw, reduction='none', ignore_index=-1)
         counts = torch.bincount(t.flatten().long(), minlength=len(cw) + 1)
         losses.append(per_px.sum() / (counts[1:] * cw).sum())

@@ -258,6 +258,67 @@ def train_steps_fixture():
     np.savez_compressed(os.path.join(HERE, 'train_steps_P_se.npz'), **blob)
 
 
+def grad_sample(t, limit=128):
+    """Deterministic sub-sample of a gradient tensor (whole tensor when it has <= `limit` elements)."""
+    f = t.detach().reshape(-1)
+    step = max(1, -(-f.numel() // limit))
+    return f[::step]
+
+
+def train_n8_fixture():
+    """Train-mode parity pin at a better-conditioned batch: config P, SE-add, 160x192,
+    N = 8 (PyramidPooling's 1x1 branch normalises over 8 values instead of 2-4), soft gates tau = 1, the
+    reference's own weighted 4-scale CrossEntropyLoss2d (src/utils.py:18-50) and the total-loss rule of
+    train.py:313-321.  The reference is run twice — float32 and float64 (`model.double()`) — so that the
+    consumer can state its gradient error against the fp64 truth next to the reference's own fp32 error."""
+    h, w, n = 160, 192, 8
+    cw = np.linspace(0.5, 2.0, 40).astype(np.float32)
+    ratio = 0.5
+    blob = {'meta': np.array([h, w, n, 16]), 'cw': cw, 'ratio': np.float32(ratio)}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        m = build('P_se', h, w)
+        m.train()
+        m.temp, m.hard_gate = 1.0, False
+        m.flop = m.flop.to(dt)
+        m.depth_enc_flop = m.depth_enc_flop.to(dt)
+        m.total_flop = m.total_flop.to(dt)
+        m = m.to(dt)
+        rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+        labels = [synth.synth_labels(n, h // s_, w // s_, seed=300 + s_).float() for s_ in (1, 8, 16, 32)]
+        ce = ref_utils.CrossEntropyLoss2d(torch.device('cpu'), cw)
+        if dt == torch.float64:
+            ce.ce_loss = torch.nn.CrossEntropyLoss(torch.from_numpy(cw).double(), reduction='none', ignore_index=-1)
+        outs, lf = m(rgb.to(dt), depth.to(dt))
+        losses = ce(outs, labels)
+        total = sum(losses) + ratio * max(torch.zeros_like(lf), lf)
+        total.backward()
+        blob[f'{tag}/losses'] = np.array([l.item() for l in losses], np.float64)
+        blob[f'{tag}/loss_flop'] = np.float64(lf.item())
+        blob[f'{tag}/total'] = np.float64(total.item())
+        if dt == torch.float32:                 # outputs: fp32 run only (they agree with fp64 to ~1e-5), sub-sampled
+            o = outs[0].detach()
+            blob['out/strided'] = o[:, :, ::16, ::16].contiguous().numpy()
+            blob['out/csum'] = o.sum(dim=(2, 3)).numpy()
+            blob['out/cabs'] = o.abs().sum(dim=(2, 3)).numpy()
+            for i, (o, st) in enumerate(zip(outs[1:], (4, 2, 1))):
+                blob[f'out/side{i}'] = o.detach()[:, :, ::st, ::st].contiguous().numpy()
+        names, norms = [], []
+        for name, p in m.named_parameters():
+            names.append(name)
+            g = p.grad
+            norms.append(0.0 if g is None else g.double().norm().item())
+            if g is not None:
+                blob[f'{tag}/g:{name}'] = grad_sample(g).float().numpy()
+        blob['grad_names'] = np.array(names)
+        blob[f'{tag}/grad_norms'] = np.array(norms, np.float64)
+        sd = m.state_dict()
+        for name in ('encoder_rgb.bn1', 'encoder_depth.layer3.2.bn2', 'gate_layer.conv.4',
+                     'context_module.features.0.1.bn', 'decoder.decoder_module_3.conv3x3.bn'):
+            blob[f'{tag}/rm:{name}'] = sd[name + '.running_mean'].float().numpy().copy()
+            blob[f'{tag}/rv:{name}'] = sd[name + '.running_var'].float().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'train_n8_P_se_160x192.npz'), **blob)
+
+
 SKIP_MODES = {
     # name: (training, test, hard_gate, temp, block_rule)
     'eval_test': (False, True, False, 1.0, [2, 2, 2, 2]),
@@ -363,6 +424,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'train_steps':
         train_steps_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'train_n8':
+        train_n8_fixture()
+        sys.exit(0)
     contract_fixture()
     train_steps_fixture()
     ops_fixture()
@@ -374,4 +438,5 @@ if __name__ == '__main__':
     model_fixture('R18_se', 96, 128, 2, ['eval_hard', 'train_soft'])
     nyu8_fixture()
     skip_fixture()
+    train_n8_fixture()
     print('done')

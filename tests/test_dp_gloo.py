@@ -5,6 +5,7 @@ with and without backward overlap, and that parameter broadcast works."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -45,7 +46,11 @@ def _worker(rank, world, port, overlap, q):
         red.zero()
         (m(x[lo:hi]).sum() / 4.0).backward()     # mean over the GLOBAL batch, per-rank share
         red.finish()
-    q.put((rank, [p.grad.clone() for p in m.parameters()], [p.detach().clone() for p in m.parameters()]))
+    # numpy payloads: a torch tensor on an mp.Queue travels as a file descriptor the parent must fetch from a
+    # still-living child; numpy arrays are pickled by value, so the worker may exit right after put()
+    q.put((rank, [p.grad.numpy().copy() for p in m.parameters()], [p.detach().numpy().copy() for p in m.parameters()],
+           red.launched_in_backward, len(red.buckets)))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -65,12 +70,14 @@ def test_bucketed_allreduce_matches_single_process(overlap):
     torch.manual_seed(100)
     x = torch.randn(4, 3, 8, 8)
     (ref(x).sum() / 4.0).backward()
-    for rank, grads, params in res:
+    for rank, grads, params, in_bwd, nb in res:
         for g, p, pr in zip(grads, params, ref.parameters()):
-            assert torch.allclose(p, pr.detach())                       # broadcast restored rank 1
+            assert np.allclose(p, pr.detach().numpy())                  # broadcast restored rank 1
             # all_reduce(sum)/world of per-rank grads of (sum over shard)/4  ==  grad of global mean / world ... x world
-            assert torch.allclose(g * 2.0, pr.grad, atol=1e-6), rank
-    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))   # replicas agree bit-for-bit
+            assert np.allclose(g * 2.0, pr.grad.numpy(), atol=1e-6), rank
+        # with overlap every bucket's all-reduce is launched from a gradient hook DURING backward
+        assert in_bwd == (nb if overlap else 0), (in_bwd, nb)
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))   # replicas agree bit-for-bit
 
 
 def test_shard_batch_partitions():

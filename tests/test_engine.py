@@ -22,6 +22,43 @@ def test_one_cycle_matches_torch():
             assert abs(opt.param_groups[0]['lr'] - schedules.one_cycle_lr(e, epochs, max_lr)) < 1e-12
 
 
+def test_one_cycle_momentum_matches_torch():
+    """OneCycleLR's default cycle_momentum=True rewrites SGD's momentum / Adam's beta1 at every scheduler step
+    (train.py:120-128 uses the default): the driver must feed the same value to the fused optimizer."""
+    warnings.filterwarnings('ignore')
+    for epochs in (500, 30):
+        for make, key in ((lambda p: torch.optim.SGD(p, lr=0.01, momentum=0.9, nesterov=True), 'momentum'),
+                          (lambda p: torch.optim.Adam(p, lr=0.01, betas=(0.9, 0.999)), 'betas')):
+            opt = make([torch.nn.Parameter(torch.zeros(1))])
+            sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.01, total_steps=epochs, div_factor=25,
+                                                      pct_start=0.1, anneal_strategy='cos', final_div_factor=1e4)
+            for e in range(epochs):
+                sch.step(e)
+                mom = opt.param_groups[0][key]
+                mom = mom[0] if key == 'betas' else mom
+                assert abs(mom - schedules.one_cycle_momentum(e, epochs)) < 1e-12, (epochs, e)
+
+
+def test_flat_optimizer_touched_ranges():
+    """Host logic of the fused flat optimizers: only parameters that received a gradient are updated (torch.optim
+    skips `.grad is None`), as merged element ranges per parameter group."""
+    from dynmm_amd import engine
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 8, 3, 4)]
+    fp = engine.FlatParameters(ps)
+    assert fp.flat.numel() == 20 and fp.span[id(ps[3])] == (0, 4) and fp.span[id(ps[0])] == (15, 20)
+    for q in ps:                                         # parameters are views of the flat buffer
+        lo, hi = fp.span[id(q)]
+        assert q.data_ptr() == fp.flat.data_ptr() + 4 * lo and torch.equal(q.detach().flatten(), fp.flat[lo:hi])
+
+    class Dummy(engine._FlatOptimizer):
+        pass
+    opt = Dummy(fp, torch.zeros(20), {'gate': [ps[3]], 'rest': ps[:3]})
+    assert opt.plan(None) == [(0, [(0, 4)]), (1, [(4, 20)])]
+    assert opt.plan({id(ps[0]), id(ps[2])}) == [(1, [(4, 7), (15, 20)])]
+    assert opt.plan({id(ps[3]), id(ps[2]), id(ps[1])}) == [(0, [(0, 4)]), (1, [(4, 15)])]
+    assert opt.plan(set()) == []
+
+
 def test_temperature_schedule_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, 'ops.npz'))
     t = schedules.ExpDecayTemp(1.0, 0.001, 300)
@@ -109,3 +146,153 @@ def test_train_driver_smoke_per_stage_gates(tmp_path):
                              '--results_dir', str(tmp_path)])
     assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
     assert 'mIoU_test' in logs[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused flat optimizers, --freeze, hipGraph keying (GPU)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['SGD', 'Adam'])
+def test_fused_optimizers_match_torch_optim(kind):
+    """dynmm_sgd_nesterov / dynmm_adam vs torch.optim.SGD(nesterov) / torch.optim.Adam on the CPU over 5 steps
+    with OneCycle-style lr AND momentum/beta1 changes, odd-sized parameters (unaligned range edges) and a
+    parameter group that only starts receiving gradients at step 2 (the gate after ini_stage)."""
+    from dynmm_amd import engine
+    torch.manual_seed(3)
+    sizes = [(7,), (33, 5), (4, 3, 3, 3), (1,), (130,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s)) for s in sizes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    fp = engine.FlatParameters(hip_p)
+    flat_g = torch.zeros_like(fp.flat)
+    for q in hip_p:
+        lo, hi = fp.span[id(q)]
+        q.grad = flat_g[lo:hi].view_as(q)
+    groups = {'gate': [hip_p[4]], 'rest': hip_p[:4]}
+    if kind == 'SGD':
+        ref = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9, weight_decay=1e-2, nesterov=True)
+        opt = engine.SGDNesterov(fp, flat_g, 0.1, 0.9, 1e-2, groups)
+    else:
+        ref = torch.optim.Adam(ref_p, lr=0.1, betas=(0.9, 0.999), weight_decay=1e-2)
+        opt = engine.Adam(fp, flat_g, 0.1, weight_decay=1e-2, groups=groups)
+    loss = torch.ones(1, device='cuda')
+    for step in range(5):
+        lr, mom = 0.1 / (1 + step), 0.95 - 0.02 * step
+        for gr in ref.param_groups:
+            gr['lr'] = lr
+            if kind == 'SGD':
+                gr['momentum'] = mom
+            else:
+                gr['betas'] = (mom, 0.999)
+        opt.set_lr(lr)
+        opt.set_momentum(mom)
+        touched = set()
+        for i, (rp, hp) in enumerate(zip(ref_p, hip_p)):
+            if i == 4 and step < 2 or i == 1 and step == 3:      # no gradient: torch.optim skips the parameter
+                rp.grad = None
+                continue
+            g = torch.randn(sizes[i])
+            rp.grad = g.clone()
+            hp.grad.copy_(g)
+            touched.add(id(hp))
+        ref.step()
+        opt.step(touched, loss)
+        for rp, hp in zip(ref_p, hip_p):
+            assert torch.allclose(hp.detach().cpu(), rp.detach(), rtol=2e-6, atol=2e-7), (kind, step)
+    opt.check_finite()
+    # NaN guard: a non-finite loss skips the update and latches the step
+    before = fp.flat.clone()
+    opt.step(None, torch.full((1,), float('nan'), device='cuda'))
+    assert torch.equal(fp.flat, before)
+    with pytest.raises(ValueError, match='Loss is None'):
+        opt.check_finite()
+    opt.check_finite()           # latch cleared
+
+
+def _small_model(seed=0, h=96, w=128):
+    from dynmm_amd.nn.net import SkipGateESANet
+    m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+    synth.fill_state_dict(m.state_dict(), seed)
+    return m.cuda().train()
+
+
+def _batch(n=3, h=96, w=128):
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234, device='cuda')
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s, device='cuda') for s in (1, 8, 16, 32)]
+    return rgb, depth, labels
+
+
+@pytest.mark.gpu
+def test_freeze_trains_only_the_gate():
+    """--freeze (train.py:139-141 + …globalgate.py:225-228): everything but the gate keeps its values bit for
+    bit (no weight decay, no momentum), the gate parameters move by lr * (their oracle gradient)."""
+    from dynmm_amd import engine
+    from oracle import dynmm_oracle as O
+    m = _small_model()
+    m.temp, m.hard_gate = 1.0, False
+    m.freeze()
+    sd0 = {k: v.detach().clone().cpu() for k, v in m.state_dict().items()}
+    cw = np.linspace(0.5, 2.0, 40)
+    rgb, depth, labels = _batch()
+    step = engine.TrainStep(m, cw, lr=0.05, momentum=0.0, weight_decay=0.0, loss_ratio=0.5, flop_budget=0.0)
+    assert step.flatp.flat.numel() == sum(p.numel() for n, p in m.named_parameters() if 'gate' in n)
+    step(rgb, depth, labels)
+    torch.cuda.synchronize()
+    # oracle gradient of the same loss w.r.t. the gate parameters
+    sdo = {k: v.clone() for k, v in sd0.items()}
+    params = {k: v.requires_grad_(True) for k, v in sdo.items() if 'gate' in k and v.dtype.is_floating_point
+              and 'running_' not in k}
+    outs, lf = O.forward(sdo, rgb.cpu(), depth.cpu(), Hh.CFGS['P_se'], training=True, temp=1.0)
+    losses = O.cross_entropy_2d(outs, [l.cpu() for l in labels], torch.as_tensor(cw, dtype=torch.float32))
+    (sum(losses) + 0.5 * torch.clamp(lf, min=0.0)).backward()
+    new = m.state_dict()
+    for k, v in sd0.items():
+        if 'gate' in k and k in params:
+            want = v - 0.05 * params[k].grad
+            assert Hh.rel_err(new[k].cpu(), want) < 2e-3, k        # gate gradients: tiny tensors behind the whole net
+            assert not torch.equal(new[k].cpu(), v), k
+        elif 'gate' not in k and v.dtype.is_floating_point and 'running_' not in k:
+            assert torch.equal(new[k].cpu(), v), k                  # frozen: bit-identical
+
+
+@pytest.mark.gpu
+def test_hip_graph_follows_epoch_schedule():
+    """temp / hard_gate / ini_stage are frozen into a captured graph.  TrainStep keys its
+    captures on them (and runs ini_stage steps eagerly), so a graph run must track an eager run through the
+    epoch protocol of train.py:193-197; the returned losses must be fresh tensors each step."""
+    from dynmm_amd import engine
+    cw = np.linspace(0.5, 2.0, 40)
+    rgb, depth, labels = _batch(4)
+    runs = {}
+    for use_graph in (False, True):
+        m = _small_model()
+        step = engine.TrainStep(m, cw, lr=0.01, loss_ratio=0.1, use_graph=use_graph)
+        outs = []
+        for temp, hard, ini in ((1.0, False, True), (1.0, False, False), (0.5, False, False), (0.5, False, False),
+                                (0.25, True, False)):
+            m.temp, m.hard_gate, m.ini_stage = temp, hard, ini
+            m.ini_branches = [1, 4, 0, 2]
+            outs.append(step(rgb, depth, labels))
+        torch.cuda.synchronize()
+        runs[use_graph] = outs
+        if use_graph:
+            assert len(step._graphs) == 3                          # (1.0 soft), (0.5 soft), (0.25 hard); ini ran eagerly
+        step.opt.check_finite()
+    assert len({o['total'].data_ptr() for o in runs[True]}) == len(runs[True])       # no aliasing of `last`
+    for a, b in zip(runs[False], runs[True]):
+        assert torch.allclose(a['losses'], b['losses'], rtol=2e-3), (a['losses'], b['losses'])
+        assert torch.allclose(a['loss_flop'], b['loss_flop'], rtol=1e-3, atol=1e-5)
+    # the temperature change must be visible: step 2 (temp 0.5) differs from what temp 1.0 would have given
+    assert not torch.allclose(runs[True][1]['loss_flop'], runs[True][2]['loss_flop'], rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_train_driver_adam_and_freeze(tmp_path):
+    from dynmm_amd import train
+    common = ['--dynamic', '--global-gate', '--encoder', 'resnet34', '--encoder_block', 'NonBottleneck1D',
+              '--decoder_channels_mode', 'constant', '--no_imagenet_pretraining', '--dataset', 'synthetic',
+              '--height', '96', '--width', '128', '--batch_size', '4', '--synthetic_samples', '8', '--epochs', '2',
+              '--eval-every', '1', '--results_dir', str(tmp_path)]
+    logs = train.train_main(common + ['--optimizer', 'Adam', '--lr', '0.001'])
+    assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
+    logs = train.train_main(common + ['--freeze', '--hip_graph', '--loss-ratio', '0.1'])
+    assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)

@@ -275,3 +275,172 @@ def test_edge_shapes_and_errors():
     m.train()
     with pytest.raises(ValueError):
         m(rgb, depth)                                                          # PPM 1x1 branch: one value per channel
+
+
+@pytest.mark.parametrize('dual', [False, True])
+def test_all_parameter_gradients_are_run_to_run_reproducible(dual):
+    """No float atomics anywhere on the gradient path (conv slabs, SE / gate MLPs, depthwise upsample, bias
+    sums are all reduced in a fixed order): two runs of the same train step give bit-identical gradients for
+    EVERY parameter, single-stream and on the 3-stream schedule alike."""
+    from dynmm_amd import engine
+    h, w, n = 96, 128, 4
+    rgb, depth = synth.synth_inputs(n, h, w, seed=5, device='cuda')
+    grads = []
+    for _ in range(3):
+        m = hip_model('P_se', h, w, seed=1)
+        m.train()
+        m.temp, m.dual_stream = 0.7, dual
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+        with engine.direct_gradients(dual):
+            outs, lf = m(rgb, depth)
+            Hh.train_loss(outs, lf).backward()
+            from dynmm_amd import ops
+            ops.join_async()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for other in grads[1:]:
+        diff = [k for k in grads[0] if not torch.equal(grads[0][k], other[k])]
+        assert not diff, diff[:8]
+
+
+# ---------------------------------------------------------------------------------------------------
+# train-mode parity with the real loss: reference-generated N=8 fixture, and the benchmark resolution
+# ---------------------------------------------------------------------------------------------------
+def _hip_train_step(cfg, h, w, rgb, depth, labels, cw, ratio, seed=0, temp=1.0):
+    """One TrainStep body (forward, weighted 4-scale CE, total-loss rule, backward) on the HIP path; returns
+    (model, outs-free dict of losses, {name: grad})."""
+    from dynmm_amd import engine
+    m = hip_model(cfg, h, w, seed=seed)
+    m.train()
+    m.temp, m.hard_gate = temp, False
+    step = engine.TrainStep(m, cw, lr=0.0, loss_ratio=ratio, flop_budget=0.0)
+    captured = {}
+    real_forward = m.forward
+
+    def spy(*a, **k):
+        res = real_forward(*a, **k)
+        captured['outs'] = [o.detach() for o in res[0]]
+        return res
+    m.forward = spy
+    step._body(rgb, depth, [t.to(torch.uint8) for t in labels])
+    torch.cuda.synchronize()
+    m.forward = real_forward
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    return m, step.last, captured['outs'], grads
+
+
+def _sample(t, limit=128):
+    f = t.detach().reshape(-1)
+    return f[::max(1, -(-f.numel() // limit))]
+
+
+def test_train_step_matches_reference_n8_fixture(golden_dir):
+    """Reference-generated (tests/golden/make_goldens.py::train_n8_fixture): config P, 160x192, N = 8, soft
+    gates, the reference's weighted 4-scale CE + 0.5 * flop loss, run by the reference in fp32 AND fp64.
+    Outputs / losses / running statistics are held to the reference's fp32 values; every parameter gradient
+    (128-element samples) is held to the fp64 run within max(3 x the reference's own fp32 error, 1e-3), the
+    full sampled gradient vector additionally by cosine and against the fp32 reference."""
+    g = np.load(os.path.join(golden_dir, 'train_n8_P_se_160x192.npz'))
+    h, w, n, stride = [int(v) for v in g['meta']]
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234, device='cuda')
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s, device='cuda') for s in (1, 8, 16, 32)]
+    m, last, outs, grads = _hip_train_step('P_se', h, w, rgb, depth, labels, g['cw'], float(g['ratio']))
+    assert np.allclose(last['losses'].cpu().numpy(), g['f32/losses'], rtol=2e-5), (last['losses'], g['f32/losses'])
+    assert abs(last['loss_flop'].item() - float(g['f32/loss_flop'])) < 1e-5
+    assert abs(last['total'].item() - float(g['f32/total'])) < 2e-5 * float(g['f32/total'])
+    out = outs[0].cpu()
+    assert Hh.rel_err(out[:, :, ::stride, ::stride], g['out/strided']) < TRAIN_OUT_TOL
+    assert Hh.rel_err(out.sum(dim=(2, 3)), g['out/csum']) < 1e-3
+    for i, st in enumerate((4, 2, 1)):
+        assert Hh.rel_err(outs[1 + i].cpu()[:, :, ::st, ::st], g[f'out/side{i}']) < TRAIN_OUT_TOL, i
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith('f32/rm:'):
+            assert Hh.rel_err(sd[k.split('rm:')[1] + '.running_mean'].cpu(), g[k]) < 1e-4, k
+        if k.startswith('f32/rv:'):
+            assert Hh.rel_err(sd[k.split('rv:')[1] + '.running_var'].cpu(), g[k]) < 1e-4, k
+    names = [str(s) for s in g['grad_names']]
+    gmax = max(np.abs(g['f64/g:' + nm]).max() for nm in names)
+    e_hip, e_ref, e_h32, used, cat = [], [], [], [], {'hip': [], 'f32': [], 'f64': []}
+    for nm in names:
+        g64 = torch.from_numpy(g['f64/g:' + nm]).double()
+        if g64.abs().max().item() < 1e-5 * gmax:
+            continue                    # analytically-zero gradients (conv bias in front of a train-mode BN)
+        g32 = torch.from_numpy(g['f32/g:' + nm]).double()
+        gh = _sample(grads[nm]).cpu().double()
+        used.append(nm)
+        e_hip.append(_rl2(gh, g64))
+        e_ref.append(_rl2(g32, g64))
+        e_h32.append(_rl2(gh, g32))
+        for key, v in (('hip', gh), ('f32', g32), ('f64', g64)):
+            cat[key].append(v)
+    e_hip, e_ref, e_h32 = np.array(e_hip), np.array(e_ref), np.array(e_h32)
+    bad = e_hip > np.maximum(3 * e_ref, 1e-3)
+    assert not bad.any(), [(used[i], e_hip[i], e_ref[i]) for i in np.nonzero(bad)[0][:8]]
+    assert np.median(e_hip) <= 1.5 * np.median(e_ref) + 1e-5, (np.median(e_hip), np.median(e_ref))
+    A, B32, B64 = (torch.cat(cat[k]) for k in ('hip', 'f32', 'f64'))
+    cos64 = torch.nn.functional.cosine_similarity(A, B64, dim=0).item()
+    cos_ref = torch.nn.functional.cosine_similarity(B32, B64, dim=0).item()
+    print(f'n8 fixture: grad err vs fp64 median {np.median(e_hip):.2e} (reference fp32: {np.median(e_ref):.2e}), '
+          f'max {e_hip.max():.2e} ({e_ref.max():.2e}); vs fp32 reference median {np.median(e_h32):.2e}; '
+          f'cosine {cos64:.6f} (reference fp32: {cos_ref:.6f})')
+    assert 1 - cos64 <= 2 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
+    # against the reference's fp32 gradients directly: both sides carry ~1e-2 of fp32 conditioning noise
+    assert np.median(e_h32) < 2.5e-2 and e_h32.max() < 8e-2, (np.median(e_h32), e_h32.max())
+
+
+def test_train_step_parity_at_benchmark_resolution():
+    """BASELINE configs[2] at its own resolution: 480x640, config P, soft gates tau = 1, weighted 4-scale CE +
+    flop loss — batch 2 (the oracle's fp64 step takes ~20 s on the GPU box's host).  HIP TrainStep body vs the
+    CPU oracle in fp32 and fp64: outputs, the five loss terms, running statistics, and EVERY parameter
+    gradient (per-tensor relative L2 against fp64 within max(3 x the fp32 oracle's own error, 1e-3); full
+    gradient cosine)."""
+    from oracle import dynmm_oracle as O
+    h, w, n, ratio = 480, 640, 2, 0.5
+    cw = np.linspace(0.5, 2.0, 40).astype(np.float32)
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s) for s in (1, 8, 16, 32)]
+    ref = {}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        sd = Hh.filled_state_dict(Hh.CFGS['P_se'], seed=0)
+        sd = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+        outs, lf = O.forward(sd, rgb.to(dt), depth.to(dt), Hh.CFGS['P_se'], training=True, temp=1.0)
+        losses = O.cross_entropy_2d(outs, labels, torch.from_numpy(cw).to(dt))
+        total = sum(losses) + ratio * torch.clamp(lf, min=0.0)
+        total.backward()
+        ref[tag] = dict(outs=[o.detach() for o in outs], losses=torch.stack([l.detach() for l in losses]),
+                        lf=lf.detach(), total=total.detach(), grads={k: p.grad for k, p in params.items()}, sd=sd)
+    m, last, outs, grads = _hip_train_step('P_se', h, w, rgb.cuda(), depth.cuda(), [l.cuda() for l in labels], cw, ratio)
+    r32, r64 = ref['f32'], ref['f64']
+    for a, b32, b64 in zip(outs, r32['outs'], r64['outs']):
+        assert Hh.rel_err(a.cpu(), b32) < TRAIN_OUT_TOL and Hh.rel_err(a.cpu(), b64) < TRAIN_OUT_TOL
+    l_hip = last['losses'].cpu().double()
+    assert torch.allclose(l_hip, r64['losses'], rtol=1e-5), (l_hip, r64['losses'])
+    assert abs(last['loss_flop'].item() - r64['lf'].item()) < 1e-5 * max(1.0, abs(r64['lf'].item()))
+    assert abs(last['total'].item() - r64['total'].item()) < 1e-5 * r64['total'].item()
+    new_sd = m.state_dict()
+    for k, v in r32['sd'].items():
+        if 'running_' in k:
+            assert Hh.rel_err(new_sd[k].cpu(), v.detach()) < 1e-4, k
+    gmax = max(v.abs().max().item() for v in r64['grads'].values())
+    names, e_hip, e_ref = [], [], []
+    for name in grads:
+        if r64['grads'][name].abs().max().item() < 1e-5 * gmax:
+            continue
+        names.append(name)
+        e_hip.append(_rl2(grads[name].cpu(), r64['grads'][name]))
+        e_ref.append(_rl2(r32['grads'][name], r64['grads'][name]))
+    e_hip, e_ref = np.array(e_hip), np.array(e_ref)
+    bad = e_hip > np.maximum(3 * e_ref, 1e-3)
+    assert not bad.any(), [(names[i], e_hip[i], e_ref[i]) for i in np.nonzero(bad)[0][:8]]
+    flat = lambda src: torch.cat([src(nm).double().flatten() for nm in names])   # noqa: E731
+    A, B32, B64 = flat(lambda nm: grads[nm].cpu()), flat(lambda nm: r32['grads'][nm]), flat(lambda nm: r64['grads'][nm])
+    cos64 = torch.nn.functional.cosine_similarity(A, B64, dim=0).item()
+    cos_ref = torch.nn.functional.cosine_similarity(B32, B64, dim=0).item()
+    print(f'480x640 batch 2: logits rel err {Hh.rel_err(outs[0].cpu(), r64["outs"][0]):.2e}; grad err vs fp64 median '
+          f'{np.median(e_hip):.2e} (fp32 oracle {np.median(e_ref):.2e}), max {e_hip.max():.2e} ({e_ref.max():.2e}); '
+          f'cosine {cos64:.6f} (fp32 oracle {cos_ref:.6f}); |g| ratio {(A.norm() / B64.norm()).item():.5f}')
+    assert 1 - cos64 <= 2 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
+    assert _rl2(A, B64) <= 3 * _rl2(B32, B64) + 1e-5

@@ -115,3 +115,36 @@ def test_reference_known_answers():
     no_w = np.array([22.2534697, 25.1141161, 28.9498153, 34.6671145, 37.5417385])
     assert np.allclose(total - no_w, 0.1175, atol=1e-3)
     assert O.DEPTH_ENC_FLOP_R34[0] == 0.2506752 and O.DEPTH_ENC_FLOP_R34[4] == 15.538944
+
+
+@pytest.mark.parametrize('tag,dt,tol', [('f32', torch.float32, 5e-4), ('f64', torch.float64, 1e-6)])
+def test_oracle_train_step_n8_fixture(golden_dir, tag, dt, tol):
+    """The oracle's train step with the real loss (forward + cross_entropy_2d + total-loss rule + backward) vs the
+    reference's own run at 160x192, N = 8, in fp32 and in fp64 (tests/golden/make_goldens.py::train_n8_fixture):
+    pins the fp64 oracle that the GPU parity tests use as ground truth."""
+    g = np.load(os.path.join(golden_dir, 'train_n8_P_se_160x192.npz'))
+    h, w, n, stride = [int(v) for v in g['meta']]
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s) for s in (1, 8, 16, 32)]
+    sd = Hh.filled_state_dict(Hh.CFGS['P_se'])
+    sd = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+    outs, lf = O.forward(sd, rgb.to(dt), depth.to(dt), Hh.CFGS['P_se'], training=True, temp=1.0)
+    losses = O.cross_entropy_2d(outs, labels, g['cw'])
+    total = sum(losses) + float(g['ratio']) * torch.clamp(lf, min=0.0)
+    total.backward()
+    assert np.allclose([l.item() for l in losses], g[f'{tag}/losses'], rtol=1e-6 if dt == torch.float64 else 2e-6)
+    assert abs(lf.item() - float(g[f'{tag}/loss_flop'])) < 1e-6
+    if dt == torch.float32:
+        assert Hh.rel_err(outs[0].detach()[:, :, ::stride, ::stride], g['out/strided']) < TOL
+    names = [str(s) for s in g['grad_names']]
+    norms = np.array([params[nm].grad.double().norm().item() for nm in names])
+    ref = g[f'{tag}/grad_norms']
+    assert np.all(np.abs(norms - ref) <= tol * np.maximum(ref, 1e-3 * ref.max())), \
+        np.max(np.abs(norms - ref) / np.maximum(ref, 1e-3 * ref.max()))
+    for nm in names[::7]:
+        f = params[nm].grad.detach().reshape(-1)
+        samp = f[::max(1, -(-f.numel() // 128))]
+        ref_s = g[f'{tag}/g:{nm}']
+        if np.abs(ref_s).max() > 1e-6 * ref.max():
+            assert Hh.rel_err(samp.float(), ref_s) < max(tol, 1e-5) * 4, nm
