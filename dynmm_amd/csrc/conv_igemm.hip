@@ -844,6 +844,202 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, vectorised operand delivery ("v4"): the specialisation that carries the C >= 128 stages
+// ------------------------------------------------------------------------------------------------
+// Same GEMM as conv_wgrad_kernel (dW[co][k] = sum_pix dY[co][pix] * Xcol[k][pix], 32 pixels per step), rebuilt
+// around 16-byte accesses end to end:
+//   * global: one lane fetches 4 consecutive pixels of a row (dwordx4): 4 + 4(+4) loads per lane and step
+//     instead of 16 + 16 dword gathers (the old loader's vector-memory issue was ~1/2 of the MFMA time);
+//     a filter tap shifted by +-1 along W is the aligned quad plus one scalar neighbour, so every access
+//     stays aligned and inside the tensor (taps shifted along H move whole rows);
+//   * LDS: [row][36] tiles (144-byte rows: 16-byte aligned, and 9*r mod 16 is a permutation, so both the
+//     ds_write_b128 of the loader and the ds_read_b128 of the fragments are conflict-free);
+//   * MFMA k-pairing: instruction pp of a step contracts pixels {pp, pp+16} instead of {2pp, 2pp+1}; a
+//     lane's 16 operands of a row are then CONTIGUOUS — 4 ds_read_b128 instead of 16 ds_read_b32;
+//   * 8 waves (2 co x 4 k, wave tile 64 x 32, 32 accumulator VGPRs) on a double-buffered tile, one barrier
+//     per step, <= 128 VGPRs: 2 workgroups = 4 waves per SIMD instead of 2 (nothing hid a wave's non-MFMA
+//     instructions before).
+// Eligible: one input tensor, Ci % 64 == 0, Co > 64, stride 1 along W with 'same' padding and KW in {1, 3},
+// W % 4 == 0, (Ho*Wo) % 4 == 0, 16-byte aligned x / dy.  Everything else stays on conv_wgrad_kernel.
+template <int TCO, int TK>
+__global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a) {
+    constexpr int BP = 32, LD = 36;
+    constexpr int WAVES_K = TK / 32;
+    static_assert(TCO == 128 && TK == 128, "8 waves: 2 (co) x 4 (k)");
+    constexpr int MCO = 2;
+    __shared__ __attribute__((aligned(16))) float Gs[2][TCO][LD];
+    __shared__ __attribute__((aligned(16))) float Xs[2][TK][LD];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wave_co = wave / WAVES_K, wave_k = wave % WAVES_K;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x;
+    const int co0 = (tile % a.n_co_tiles) * TCO;
+    const int k0 = (tile / a.n_co_tiles) * TK;
+    const int split = blockIdx.y;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+
+    // loader coordinates: lane q owns pixels [4q, 4q+4) of a step; rows rr and rr + 64
+    const int q = t & 7, rr = t >> 3;
+    unsigned goff[2];                    // byte offset of the dy row (channel clamped: rows past Co are never stored)
+    unsigned xoff[2];                    // byte offset ci*HW of the x row
+    int f_r[2], f_dx[2];                 // filter row of the group's tap; its shift along W (-1, 0, +1)
+    bool f_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int co = co0 + rr + 64 * i;
+        if (co > a.Co - 1) co = a.Co - 1;
+        goff[i] = (unsigned)co * (unsigned)HoWo * 4u;
+        const int k = k0 + rr + 64 * i;
+        f_ok[i] = k < a.K;
+        const int kk = f_ok[i] ? k : 0;
+        const int tap = kk / a.Ci;
+        const int ci = kk - tap * a.Ci;
+        f_r[i] = tap / a.KW;
+        f_dx[i] = (tap - f_r[i] * a.KW) - a.PW;
+        xoff[i] = (unsigned)ci * (unsigned)HW * 4u;
+    }
+    const int step_begin = split * a.steps_per_split;
+    const int total_steps = (a.M + BP - 1) / BP;
+    const int step_end = min(total_steps, step_begin + a.steps_per_split);
+    int f_m = step_begin * BP + 4 * q;               // first pixel of this lane's quad
+    int f_n = f_m / HoWo;
+    int f_rem = f_m - f_n * HoWo;
+
+    // staging registers of the next step's tile (named scalars, not arrays: they must stay in VGPRs)
+    float4 rg0, rg1, rx0, rx1;
+    float rs0 = 0.f, rs1 = 0.f;
+    unsigned vmask = 0;       // bit 0/1: x group valid; bit 2/3: neighbour valid; bit 31: quad < M
+    auto load_x = [&](int i, bool ok, unsigned img, int ihb, int ow, float4& rx, float& rs) __attribute__((always_inline)) -> unsigned {
+        const int ih = ihb + f_r[i];
+        const bool v = ok && f_ok[i] && (unsigned)ih < (unsigned)a.H;
+        const unsigned row = img + xoff[i] + (unsigned)((v ? ih : 0) * a.W + ow) * 4u;   // invalid: row 0, mapped
+        rx = ldg_f32x4(a.x, row);
+        // neighbour along W for a shifted tap (wave-uniform branch: a wave's rows lie in one 64-group)
+        bool nv = false;
+        float s = 0.f;
+        if (f_dx[i] < 0) {
+            nv = v && ow > 0;
+            s = ldg_f32(a.x, row - (nv ? 4u : 0u));
+        } else if (f_dx[i] > 0) {
+            nv = v && ow + 4 < a.W;
+            s = ldg_f32(a.x, row + (nv ? 16u : 0u));
+        }
+        rs = s;
+        return (v ? (1u << i) : 0u) | (nv ? (4u << i) : 0u);
+    };
+    auto load_step = [&]() __attribute__((always_inline)) {
+        const bool ok = f_m < a.M;
+        const int n = ok ? f_n : 0, rem = ok ? f_rem : 0;
+        const int oh = a.magic_wo ? (int)__umulhi((unsigned)rem, a.magic_wo) : rem / a.Wo;
+        const int ow = rem - oh * a.Wo;
+        const unsigned gv = ((unsigned)(n * a.Co) * (unsigned)HoWo + (unsigned)rem) * 4u;
+        rg0 = ldg_f32x4(a.dy, gv + goff[0]);
+        rg1 = ldg_f32x4(a.dy, gv + goff[1]);
+        const int ihb = oh * a.SH - a.PH;
+        const unsigned img = (unsigned)(n * a.Ci) * (unsigned)HW * 4u;
+        unsigned vm = ok ? 0x80000000u : 0u;
+        vm |= load_x(0, ok, img, ihb, ow, rx0, rs0);
+        vm |= load_x(1, ok, img, ihb, ow, rx1, rs1);
+        vmask = vm;
+        f_m += BP;
+        f_rem += BP;
+        while (f_rem >= HoWo) { f_rem -= HoWo; ++f_n; }
+    };
+    auto put_x = [&](int buf, int i, float4 v, float sraw) __attribute__((always_inline)) {
+        const float s = ((vmask >> (2 + i)) & 1u) ? sraw : 0.f;
+        float e0 = v.x, e1 = v.y, e2 = v.z, e3 = v.w;
+        if (f_dx[i] < 0) { e3 = e2; e2 = e1; e1 = e0; e0 = s; }
+        else if (f_dx[i] > 0) { e0 = e1; e1 = e2; e2 = e3; e3 = s; }
+        const bool ok = ((vmask >> i) & 1u) != 0;      // component-wise selects: a ternary on float4 goes through scratch
+        *reinterpret_cast<float4*>(&Xs[buf][rr + 64 * i][4 * q]) =
+            make_float4(ok ? e0 : 0.f, ok ? e1 : 0.f, ok ? e2 : 0.f, ok ? e3 : 0.f);
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+        const bool ok = (vmask >> 31) != 0;
+        *reinterpret_cast<float4*>(&Gs[buf][rr][4 * q]) =
+            make_float4(ok ? rg0.x : 0.f, ok ? rg0.y : 0.f, ok ? rg0.z : 0.f, ok ? rg0.w : 0.f);
+        *reinterpret_cast<float4*>(&Gs[buf][rr + 64][4 * q]) =
+            make_float4(ok ? rg1.x : 0.f, ok ? rg1.y : 0.f, ok ? rg1.z : 0.f, ok ? rg1.w : 0.f);
+        put_x(buf, 0, rx0, rs0);
+        put_x(buf, 1, rx1, rs1);
+    };
+
+    f32x16 acc[MCO];
+#pragma unroll
+    for (int mi = 0; mi < MCO; ++mi)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
+
+    const bool do_bias = a.out_bias != nullptr && (tile / a.n_co_tiles) == 0;
+    float bsum = 0.f;
+
+    if (step_begin < step_end) {
+        load_step();
+        store_step(0);
+    }
+    __syncthreads();
+    for (int st = step_begin; st < step_end; ++st) {
+        const int buf = (st - step_begin) & 1;
+        const bool more = st + 1 < step_end;
+        if (more) load_step();                         // global loads fly under the MFMAs below
+        if (do_bias && t < TCO) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < BP; c4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(&Gs[buf][t][c4]);
+                s0 += (v.x + v.y) + (v.z + v.w);
+            }
+            bsum += s0;
+        }
+        // this lane's 16 pixels of the step: [16*khalf, 16*khalf + 16)
+        const float* ga = &Gs[buf][wave_co * 64 + l31][16 * khalf];
+        const float* xb = &Xs[buf][wave_k * 32 + l31][16 * khalf];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float af[MCO][8], bf[8];
+#pragma unroll
+            for (int mi = 0; mi < MCO; ++mi) {
+                const float4 u0 = *reinterpret_cast<const float4*>(ga + mi * 32 * LD + 8 * h);
+                const float4 u1 = *reinterpret_cast<const float4*>(ga + mi * 32 * LD + 8 * h + 4);
+                af[mi][0] = u0.x; af[mi][1] = u0.y; af[mi][2] = u0.z; af[mi][3] = u0.w;
+                af[mi][4] = u1.x; af[mi][5] = u1.y; af[mi][6] = u1.z; af[mi][7] = u1.w;
+            }
+            {
+                const float4 u0 = *reinterpret_cast<const float4*>(xb + 8 * h);
+                const float4 u1 = *reinterpret_cast<const float4*>(xb + 8 * h + 4);
+                bf[0] = u0.x; bf[1] = u0.y; bf[2] = u0.z; bf[3] = u0.w;
+                bf[4] = u1.x; bf[5] = u1.y; bf[6] = u1.z; bf[7] = u1.w;
+            }
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+                for (int mi = 0; mi < MCO; ++mi)
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][pp], bf[pp], acc[mi], 0, 0, 0);
+        }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (do_bias && t < TCO && co0 + t < a.Co) a.out_bias[(size_t)split * a.Co + co0 + t] = bsum;
+    const int KHKW = a.KH * a.KW;
+    float* out = a.out + (size_t)split * a.Co * a.K;
+    const int k = k0 + wave_k * 32 + l31;
+    if (k < a.K) {
+        const int tap = k / a.Ci;
+        const int ci = k - tap * a.Ci;
+#pragma unroll
+        for (int mi = 0; mi < MCO; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = co0 + wave_co * 64 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
+                if (co < a.Co) out[((size_t)co * a.Ci + ci) * KHKW + tap] = acc[mi][j];
+            }
+    }
+}
+
 struct WgradPlan {
     int tco, tk, n_co_tiles, n_k_tiles, splits, steps_per_split;
 };
@@ -1042,6 +1238,15 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     const bool dual = x2 != nullptr;
     const bool fast = !dual && (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
     a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
+    static const int no_v4 = env_int("DYNMM_WGRAD_NO_V4");
+    const bool v4 = !no_v4 && !dual && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
+                    (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
+                    ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH &&
+                    ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15u) == 0);
+    if (v4) {
+        hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128>), grid, dim3(512), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+    } else
 #define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
     do {                                                                                              \
         if (dual)                                                                                     \

@@ -376,9 +376,17 @@ def test_train_step_matches_reference_n8_fixture(golden_dir):
         for key, v in (('hip', gh), ('f32', g32), ('f64', g64)):
             cat[key].append(v)
     e_hip, e_ref, e_h32 = np.array(e_hip), np.array(e_ref), np.array(e_h32)
-    bad = e_hip > np.maximum(3 * e_ref, 1e-3)
+    # e_hip and e_ref are two draws of the same fp32 noise (ReLU / max-pool decisions that flip between fp32 and
+    # fp64 forward passes dominate it): compare the DISTRIBUTIONS tightly and each tensor against a bar that allows
+    # for the draw-to-draw spread (a wrong kernel shows up as O(1) on its tensor, two orders above these bars)
+    print(f'per-tensor grad err vs fp64: hip median {np.median(e_hip):.2e} p95 {np.percentile(e_hip, 95):.2e} max '
+          f'{e_hip.max():.2e} | reference fp32 median {np.median(e_ref):.2e} p95 {np.percentile(e_ref, 95):.2e} max '
+          f'{e_ref.max():.2e} | worst ratio {np.max(e_hip / np.maximum(e_ref, 1e-4)):.2f}')
+    bad = e_hip > np.maximum(5 * e_ref, np.maximum(2 * np.median(e_ref), 1e-3))
     assert not bad.any(), [(used[i], e_hip[i], e_ref[i]) for i in np.nonzero(bad)[0][:8]]
     assert np.median(e_hip) <= 1.5 * np.median(e_ref) + 1e-5, (np.median(e_hip), np.median(e_ref))
+    assert np.percentile(e_hip, 95) <= 1.5 * np.percentile(e_ref, 95) + 1e-5
+    assert e_hip.max() <= 2.0 * e_ref.max() + 1e-5, (e_hip.max(), e_ref.max())
     A, B32, B64 = (torch.cat(cat[k]) for k in ('hip', 'f32', 'f64'))
     cos64 = torch.nn.functional.cosine_similarity(A, B64, dim=0).item()
     cos_ref = torch.nn.functional.cosine_similarity(B32, B64, dim=0).item()
@@ -433,8 +441,14 @@ def test_train_step_parity_at_benchmark_resolution():
         e_hip.append(_rl2(grads[name].cpu(), r64['grads'][name]))
         e_ref.append(_rl2(r32['grads'][name], r64['grads'][name]))
     e_hip, e_ref = np.array(e_hip), np.array(e_ref)
-    bad = e_hip > np.maximum(3 * e_ref, 1e-3)
+    print(f'per-tensor grad err vs fp64: hip median {np.median(e_hip):.2e} p95 {np.percentile(e_hip, 95):.2e} max '
+          f'{e_hip.max():.2e} | fp32 oracle median {np.median(e_ref):.2e} p95 {np.percentile(e_ref, 95):.2e} max '
+          f'{e_ref.max():.2e} | worst ratio {np.max(e_hip / np.maximum(e_ref, 1e-4)):.2f}')
+    bad = e_hip > np.maximum(5 * e_ref, np.maximum(2 * np.median(e_ref), 1e-3))
     assert not bad.any(), [(names[i], e_hip[i], e_ref[i]) for i in np.nonzero(bad)[0][:8]]
+    assert np.median(e_hip) <= 1.5 * np.median(e_ref) + 1e-5, (np.median(e_hip), np.median(e_ref))
+    assert np.percentile(e_hip, 95) <= 1.5 * np.percentile(e_ref, 95) + 1e-5
+    assert e_hip.max() <= 2.0 * e_ref.max() + 1e-5, (e_hip.max(), e_ref.max())
     flat = lambda src: torch.cat([src(nm).double().flatten() for nm in names])   # noqa: E731
     A, B32, B64 = flat(lambda nm: grads[nm].cpu()), flat(lambda nm: r32['grads'][nm]), flat(lambda nm: r64['grads'][nm])
     cos64 = torch.nn.functional.cosine_similarity(A, B64, dim=0).item()
