@@ -39,6 +39,7 @@ struct IgemmArgs {
     int c_in_split, c_out_split;
     int act;
     int M, K, CoP;
+    int CiR;               // weight rows per filter tap: Ci, or Ci rounded up to 16 (zero rows) when 8 <= Ci, Ci % 16 != 0
     int n_co_tiles, n_pix_tiles;
     int subpix;            // DGRAD with stride > 1 and Ho % SH == Wo % SW == 0: output pixels are enumerated
                            // parity class by parity class (see pix_decode), so a tile is (mostly) class-pure
@@ -190,7 +191,8 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
 
     if constexpr (!GENERIC) {
         // ---------------- fast path: Ci % 16 == 0, one filter tap per K-step ----------------
-        const int cpt = a.Ci / BK;
+        const int cpt = a.CiR / BK;
+        const bool padded = a.CiR != a.Ci;       // last K-step of a tap is partly zero rows (e.g. dgrad of a 40-class conv)
         // taps that can reach this tile: all of them, unless the tile lies inside one parity class
         int live_ph = -1, live_pw = -1;
         if (DGRAD && a.subpix) {
@@ -223,10 +225,11 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
                 if (++ts == a.KW) { ts = 0; ++tr; }
                 if (tr >= a.KH) return;
                 if (tap_live(tr, ts)) break;
-                kbase += a.Ci;           // skipped tap: its Ci weight rows are never touched
+                kbase += a.CiR;          // skipped tap: its weight rows are never touched
             } while (true);
         };
         bool ld_ok = false;             // validity of the tile currently held in rb[]
+        unsigned ld_cmask = 0xffffffffu; // bit i: channel of rb[i] exists (only ever cleared when `padded`)
         auto load_tile = [&]() {
             // weights: rows kbase + a_row0 + i*A_ROWSTEP, 4 consecutive co per lane
             const float* wbase = a.wp + (size_t)kbase * a.CoP;
@@ -237,14 +240,27 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
             const bool first = ci0 < a.c_in_split;
             const float* xbase = first ? a.x + (size_t)ci0 * HW : a.x2 + (size_t)(ci0 - a.c_in_split) * HW;
             const unsigned voff = first ? voff1 : voff2;
+            if (!padded) {
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i)
-                rb[i] = ldg_f32(xbase + (size_t)(i * B_ROWSTEP) * HW, voff);
+                for (int i = 0; i < B_PER; ++i)
+                    rb[i] = ldg_f32(xbase + (size_t)(i * B_ROWSTEP) * HW, voff);
+            } else {
+                // channels past Ci: read channel ci0 (always present) instead and zero the value at the LDS store
+                const unsigned voff_c0 = voff - (unsigned)b_row0 * (unsigned)HW * 4u;
+                unsigned cm = 0;
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const bool cv = ci0 + b_row0 + i * B_ROWSTEP < a.Ci;
+                    rb[i] = cv ? ldg_f32(xbase + (size_t)(i * B_ROWSTEP) * HW, voff) : ldg_f32(xbase, voff_c0);
+                    cm |= cv ? (1u << i) : 0u;
+                }
+                ld_cmask = cm;
+            }
             ld_ok = tap_ok;
             // advance the K iterator
             ci0 += BK;
             kbase += BK;
-            if (ci0 >= a.Ci) {
+            if (ci0 >= a.CiR) {
                 ci0 = 0;
                 next_tap();
                 if (tr < a.KH) set_tap();
@@ -257,11 +273,12 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
                     *reinterpret_cast<float4*>(&As[buf][a_row0 + i * A_ROWSTEP][a_q * 4]) = ra[i];
             }
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = ld_ok ? rb[i] : 0.f;
+            for (int i = 0; i < B_PER; ++i)
+                Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = (ld_ok && ((ld_cmask >> i) & 1u)) ? rb[i] : 0.f;
         };
 
         if (!tap_live(0, 0)) {           // first live tap
-            kbase += a.Ci;
+            kbase += a.CiR;
             next_tap();
         }
         if (nk > 0) {
@@ -293,7 +310,8 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
 #pragma unroll
             for (int i = 0; i < AS_PER; ++i) {
                 const int k = kb + as_row0 + i * AS_ROWSTEP;
-                rs[i] = (a_ok && k < a.K) ? a.wp[(size_t)k * a.CoP + co_a] : 0.f;
+                // packed rows are (tap * CiR + ci); CiR == Ci whenever this path runs on un-rounded channel counts
+                rs[i] = (a_ok && k < a.K) ? a.wp[(size_t)((k / a.Ci) * a.CiR + (k % a.Ci)) * a.CoP + co_a] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
@@ -502,6 +520,9 @@ namespace dynmm {
 // Tuning knobs for experiments (read once; unset = built-in choice):
 //   DYNMM_IGEMM_TPIX=64|128      pixel tile of the Co>64 configuration
 //   DYNMM_IGEMM_TPIX_C64=128|256 pixel tile of the 32<Co<=64 configuration
+// rows per filter tap of a packed weight / K-steps of the fast path (see pack_weight_kernel)
+static inline int round_k(int c) { return (c >= 8 && c % 16 != 0) ? ((c + 15) & ~15) : c; }
+
 static int env_int(const char* name) {
     const char* v = getenv(name);
     return v ? atoi(v) : 0;
@@ -512,7 +533,8 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     static const int force_tpix = env_int("DYNMM_IGEMM_TPIX");
     static const int force_tpix64 = env_int("DYNMM_IGEMM_TPIX_C64");
     const bool dual_in = a.x2 != nullptr;
-    const bool generic = (a.Ci % 16 != 0) || (dual_in && (a.c_in_split % 16 != 0)) ||
+    a.CiR = round_k(a.Ci);
+    const bool generic = (a.CiR % 16 != 0) || (dual_in && (a.c_in_split % 16 != 0)) ||
                          ((reinterpret_cast<uintptr_t>(a.wp) & 15u) != 0);
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Ci;
@@ -576,6 +598,7 @@ struct WgradArgs {
     int n_co_tiles, n_k_tiles;
     int steps_per_split;   // 32-pixel steps handled by one workgroup
     unsigned magic_wo;     // floor(2^32 / Wo) + 1 when Ho*Wo*Wo < 2^32 (exact rem / Wo by mulhi), else 0
+    int k_major_out;       // v4 slabs: out[co][k] with k = tap*Ci + ci (128-byte store runs); permuted by the slab reduction
 };
 
 template <int TCO, int TK, int WCO, int WK, bool DUAL, bool FAST>
@@ -1030,13 +1053,58 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
     if (k < a.K) {
         const int tap = k / a.Ci;
         const int ci = k - tap * a.Ci;
+        // slabs: [co][k] (a half-wave stores 128 contiguous bytes; the reduction kernel applies the [co][ci][tap]
+        // permutation once); without a split the final OIHW layout is written directly
+        const size_t col = a.k_major_out ? (size_t)k : (size_t)ci * KHKW + tap;
+        const size_t rowlen = a.k_major_out ? (size_t)a.K : (size_t)a.Ci * KHKW;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int co = co0 + wave_co * 64 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
-                if (co < a.Co) out[((size_t)co * a.Ci + ci) * KHKW + tap] = acc[mi][j];
+                if (co < a.Co) out[(size_t)co * rowlen + col] = acc[mi][j];
             }
+    }
+}
+
+// out[(co*Ci + ci)*KHKW + tap] = sum_s slabs[s][co*K + tap*Ci + ci], fixed order (4 slab groups in flight per
+// column, combined through LDS like reduce_slabs_kernel); each lane owns 4 consecutive ci (Ci % 4 == 0).
+// Workgroups >= nb1 reduce the optional bias-gradient slabs (plain layout).
+__global__ void __launch_bounds__(256) reduce_slabs_perm_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                int n, int nslabs, int Ci, int KHKW, int K,
+                                                                const float* __restrict__ slabs2,
+                                                                float* __restrict__ out2, int n2, int nb1) {
+    __shared__ float part[4][64][4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int bx = blockIdx.x;
+    const bool second = bx >= nb1;
+    if (second) { bx -= nb1; slabs = slabs2; out = out2; n = n2; }
+    const int i = (bx * 64 + tx) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+#pragma unroll 4
+        for (int k = ty; k < nslabs; k += 4) {
+            float v[4];
+            vload<4>(slabs + (size_t)k * n + i, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[ty][tx][j] = acc[j];
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = ((part[0][tx][j] + part[1][tx][j]) + part[2][tx][j]) + part[3][tx][j];
+        if (second) {
+            vstore<4>(out + i, r);
+        } else {
+            const int co = i / K, kk = i - co * K;
+            const int tap = kk / Ci, ci = kk - tap * Ci;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[((size_t)co * Ci + ci + j) * KHKW + tap] = r[j];
+        }
     }
 }
 
@@ -1126,20 +1194,26 @@ void launch_reduce_slabs(const float* slabs, float* out, int n, int nslabs, hipS
     }
 }
 
-// wf[(tap*Ci+ci)*CoP + co], wd[(tap*Co+co)*CiP + ci]; padding columns are never consumed.
+// wf[(tap*CiR+ci)*CoP + co], wd[(tap*CoR+co)*CiP + ci]: CoP / CiP = row length rounded up to 4 floats, CiR / CoR =
+// rows per tap (round_k: rounded up to 16 for 8 <= C, C % 16 != 0, so those convs run the one-tap-per-K-step fast
+// path with a few zero rows instead of the element-wise generic loader).  Every padding element is written as 0.
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w,
                                                           float* __restrict__ wf,
                                                           float* __restrict__ wd,
-                                                          int Co, int Ci, int KHKW, int CoP, int CiP) {
+                                                          int Co, int Ci, int KHKW, int CoP, int CiP, int CiR, int CoR) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int total = Co * Ci * KHKW;
-    if (i >= total) return;
-    const int tap = i % KHKW;
-    const int ci = (i / KHKW) % Ci;
-    const int co = i / (KHKW * Ci);
-    const float v = w[i];
-    if (wf) wf[((size_t)tap * Ci + ci) * CoP + co] = v;
-    if (wd) wd[((size_t)tap * Co + co) * CiP + ci] = v;
+    const int nf = wf ? KHKW * CiR * CoP : 0;
+    const int nd = wd ? KHKW * CoR * CiP : 0;
+    if (i < nf) {
+        const int co = i % CoP, k = i / CoP;
+        const int ci = k % CiR, tap = k / CiR;
+        wf[i] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * KHKW + tap] : 0.f;
+    } else if (i - nf < nd) {
+        const int j = i - nf;
+        const int ci = j % CiP, k = j / CiP;
+        const int co = k % CoR, tap = k / CoR;
+        wd[j] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * KHKW + tap] : 0.f;
+    }
 }
 
 static bool geom_ok(const dynmm_conv_geom* g) {
@@ -1159,13 +1233,20 @@ static bool geom_ok(const dynmm_conv_geom* g) {
 
 using namespace dynmm;
 
+extern "C" size_t dynmm_packed_weight_floats(int Co, int Ci, int KH, int KW, int dgrad) {
+    if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
+    return dgrad ? (size_t)KH * KW * round_k(Co) * ((Ci + 3) & ~3) : (size_t)KH * KW * round_k(Ci) * ((Co + 3) & ~3);
+}
+
 extern "C" int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad, int Co, int Ci,
                                  int KH, int KW, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!w || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return DYNMM_EINVAL;
-    const int total = Co * Ci * KH * KW;
+    const int CoP = (Co + 3) & ~3, CiP = (Ci + 3) & ~3, CiR = round_k(Ci), CoR = round_k(Co);
+    const int total = (wp_fwd ? KH * KW * CiR * CoP : 0) + (wp_dgrad ? KH * KW * CoR * CiP : 0);
+    if (total == 0) return DYNMM_OK;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, wp_fwd, wp_dgrad, Co, Ci, KH * KW, (Co + 3) & ~3, (Ci + 3) & ~3);
+                       (hipStream_t)stream, w, wp_fwd, wp_dgrad, Co, Ci, KH * KW, CoP, CiP, CiR, CoR);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -1243,9 +1324,21 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
                     (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
                     ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH &&
                     ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15u) == 0);
+    const bool bias_ok4 = !dbias || ((g->Co % 4 == 0) && ((reinterpret_cast<uintptr_t>(bias_slabs) & 15u) == 0) &&
+                                     ((reinterpret_cast<uintptr_t>(dbias) & 15u) == 0));
+    const bool perm = v4 && p.splits > 1 && ((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) && bias_ok4;
+    a.k_major_out = perm ? 1 : 0;
     if (v4) {
         hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128>), grid, dim3(512), 0, st, a);
         DYNMM_LAUNCH_CHECK();
+        if (perm) {
+            const int n = g->Co * a.K, nb1 = ceil_div(n / 4, 64), nb2 = dbias ? ceil_div(g->Co / 4, 64) : 0;
+            hipLaunchKernelGGL(reduce_slabs_perm_kernel, dim3(nb1 + nb2), dim3(256), 0, st, (const float*)workspace, dw,
+                               n, p.splits, g->Ci, g->KH * g->KW, a.K, dbias ? bias_slabs : nullptr, dbias,
+                               dbias ? g->Co : 0, nb1);
+            DYNMM_LAUNCH_CHECK();
+            return DYNMM_OK;
+        }
     } else
 #define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
     do {                                                                                              \

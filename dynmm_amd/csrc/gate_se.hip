@@ -7,8 +7,8 @@
 
 namespace dynmm {
 
-constexpr int kMaxC = 1024;
-constexpr int kMaxHid = 64;
+constexpr int kMaxC = 2048;     // ResNet-50 stage 4: 2048 channels
+constexpr int kMaxHid = 128;
 
 struct SeParams { const float* p[8]; };   // W1r b1r W2r b2r W1d b1d W2d b2d
 

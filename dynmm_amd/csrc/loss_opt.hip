@@ -168,14 +168,13 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     if (loss_bad(loss, nan_flag, step)) return;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
     const double t = (double)step[0];
-    const float bc1 = (float)(1.0 - pow((double)b1, t));
-    const float rbc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
-    const float step_size = lr / bc1;
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
     auto upd = [&](float& pv, float gv, float& mv, float& vv) {
         const float d = gv * gscale + wd * pv;
         mv = b1 * mv + (1.f - b1) * d;
         vv = b2 * vv + (1.f - b2) * d * d;
-        pv -= step_size * (mv / (sqrtf(vv) * rbc2 + eps));
+        pv -= step_size * (mv / (sqrtf(vv) / bc2s + eps));       // torch: denom = sqrt(v)/sqrt(bc2) + eps
     };
     for_range4(r.lo, r.hi, [&](size_t i, int cnt) {
         if (cnt == 4) {

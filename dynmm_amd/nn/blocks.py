@@ -85,8 +85,32 @@ class BasicBlock(nn.Module):
         return conv_bn_act(y, self.conv2, self.bn2, 'relu', residual=idt, res_link=link)
 
 
-BLOCKS = {'NonBottleneck1D': NonBottleneck1D, 'BasicBlock': BasicBlock}
-LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3)}
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (carries the stride) -> 1x1 (x4 channels), each conv + BN, residual, ReLU — the ResNet-50
+    block (resnet.py:150-192); `--encoder resnet50` is the reference CLI's default (src/args.py:105)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.downsample = downsample
+
+    def forward(self, x):
+        fuse_bwd = torch.is_grad_enabled() and x.requires_grad
+        link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
+        y = conv_bn_act(x, self.conv1, self.bn1, 'relu', conv_link=link)
+        y = conv_bn_act(y, self.conv2, self.bn2, 'relu')
+        idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        return conv_bn_act(y, self.conv3, self.bn3, 'relu', residual=idt, res_link=link)
+
+
+BLOCKS = {'NonBottleneck1D': NonBottleneck1D, 'BasicBlock': BasicBlock, 'Bottleneck': Bottleneck}
+LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet50': (3, 4, 6, 3)}
 
 
 class ResNetEncoder(nn.Module):
@@ -96,24 +120,27 @@ class ResNetEncoder(nn.Module):
         super().__init__()
         if name not in LAYERS:
             raise NotImplementedError(f'Only {sorted(LAYERS)} encoders are implemented on the HIP path. Got {name}')
-        if block not in BLOCKS:
+        if block not in BLOCKS and name != 'resnet50':
             raise NotImplementedError(f'Block {block} is not implemented')
+        if name == 'resnet50':
+            block = 'Bottleneck'          # ResNet50() ignores encoder_block (…globalgate.py:93-96, resnet.py:450-452)
         blk = BLOCKS[block]
+        ex = blk.expansion
         self.conv1 = nn.Conv2d(input_channels, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
         for j, (planes, n) in enumerate(zip((64, 128, 256, 512), LAYERS[name]), start=1):
             stride = 1 if j == 1 else 2
             down = None
-            if stride != 1 or inplanes != planes:
-                down = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False),
-                                     nn.BatchNorm2d(planes))
-            stage = [blk(inplanes, planes, stride, down)] + [blk(planes, planes) for _ in range(n - 1)]
+            if stride != 1 or inplanes != planes * ex:
+                down = nn.Sequential(nn.Conv2d(inplanes, planes * ex, 1, stride=stride, bias=False),
+                                     nn.BatchNorm2d(planes * ex))
+            stage = [blk(inplanes, planes, stride, down)] + [blk(planes * ex, planes) for _ in range(n - 1)]
             setattr(self, f'layer{j}', nn.Sequential(*stage))
-            inplanes = planes
+            inplanes = planes * ex
         self.down_2_channels_out = 64
-        self.down_4_channels_out, self.down_8_channels_out = 64, 128
-        self.down_16_channels_out, self.down_32_channels_out = 256, 512
+        self.down_4_channels_out, self.down_8_channels_out = 64 * ex, 128 * ex
+        self.down_16_channels_out, self.down_32_channels_out = 256 * ex, 512 * ex
         for m in self.modules():           # resnet.py:264-270
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')

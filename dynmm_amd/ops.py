@@ -252,8 +252,10 @@ class _Conv2d(Function):
             if bf_d:
                 wpd = wsd
         if not bf_f or (need_dx and not bf_d):
-            wp = torch.empty(taps * g.Ci * _up4(g.Co), device=x.device, dtype=torch.float32) if not bf_f else None
-            wpd32 = torch.empty(taps * g.Co * _up4(g.Ci), device=x.device, dtype=torch.float32) if (need_dx and not bf_d) else None
+            wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=x.device,
+                             dtype=torch.float32) if not bf_f else None
+            wpd32 = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 1), device=x.device,
+                                dtype=torch.float32) if (need_dx and not bf_d) else None
             L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd32), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
             if wpd32 is not None:
                 wpd = wpd32
@@ -388,7 +390,7 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
             wsf = torch.empty(ns * g.KH * g.KW * g.Ci * g.Co, device=dev, dtype=torch.int16)
             L.check(lib.dynmm_pack_weight_bf16(_p(weight), _p(wsf), None, g.Co, g.Ci, g.KH, g.KW, ns, st), 'pack_weight_bf16')
         else:
-            wp = torch.empty(g.KH * g.KW * g.Ci * _up4(g.Co), device=dev, dtype=torch.float32)
+            wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=dev, dtype=torch.float32)
             L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
         scale = shift = None
         if bn is not None:

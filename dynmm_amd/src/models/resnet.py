@@ -1,5 +1,5 @@
-"""Counterpart of FusionDynMM/src/models/resnet.py (ResNet-18/34 trunks used by the hot path)."""
-from ...nn.blocks import BasicBlock, NonBottleneck1D, ResNetEncoder as ResNet  # noqa: F401
+"""Counterpart of FusionDynMM/src/models/resnet.py (ResNet-18/34/50 trunks used by the hot path)."""
+from ...nn.blocks import BasicBlock, Bottleneck, NonBottleneck1D, ResNetEncoder as ResNet  # noqa: F401
 
 
 def _make(name, block='BasicBlock', pretrained_on_imagenet=False, pretrained_dir=None,
@@ -18,4 +18,5 @@ def ResNet34(**kw):
 
 
 def ResNet50(**kw):
-    raise NotImplementedError('ResNet50/Bottleneck is outside the HIP hot path (north_star fixes ResNet-34)')
+    kw.pop('block', None)                 # resnet.py:450-452: always Bottleneck
+    return _make('resnet50', block='Bottleneck', **kw)

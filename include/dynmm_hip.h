@@ -51,11 +51,14 @@ typedef struct {
 } dynmm_conv_geom;
 
 /* Re-layout of a conv weight for the implicit-GEMM kernels (done per step; weights are small).
- *   wp_fwd  [(tap*Ci+ci)][CoP]  (tap = r*KW+s)   — operand of dynmm_conv2d_fwd
- *   wp_dgrad[(tap*Co+co)][CiP]                    — operand of dynmm_conv2d_dgrad
- * CoP / CiP = Co / Ci rounded up to a multiple of 4 (rows stay 16-byte aligned for dwordx4 loads;
- * the padding columns are never consumed).  Sizes: KH*KW*Ci*CoP and KH*KW*Co*CiP floats.
+ *   wp_fwd  [(tap*CiR+ci)][CoP]  (tap = r*KW+s)   — operand of dynmm_conv2d_fwd
+ *   wp_dgrad[(tap*CoR+co)][CiP]                    — operand of dynmm_conv2d_dgrad
+ * CoP / CiP = Co / Ci rounded up to a multiple of 4 (rows stay 16-byte aligned for dwordx4 loads); CiR / CoR =
+ * rows per filter tap: the channel count, rounded up to a multiple of 16 when it is >= 8 and not one already
+ * (zero rows: e.g. the input gradient of the 40-class convs then runs the one-tap-per-K-step fast path).
+ * All padding is written as zeros.  Buffer sizes in floats: dynmm_packed_weight_floats(..., dgrad = 0 / 1).
  * Either output may be NULL. */
+size_t dynmm_packed_weight_floats(int Co, int Ci, int KH, int KW, int dgrad);
 int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
                       int Co, int Ci, int KH, int KW, void* stream);
 

@@ -17,7 +17,7 @@ from typing import List, Optional
 import torch
 import torch.nn.functional as F
 
-RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3)}   # src/models/resnet.py:392,425
+RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet50': (3, 4, 6, 3)}   # src/models/resnet.py:392,425,452
 STAGE_PLANES = (64, 128, 256, 512)                                       # src/models/resnet.py:247-266
 # src/models/model_skip_mod_globalgate.py:219 (ResNet-34 table) and :222 (otherwise)
 DEPTH_ENC_FLOP_R34 = (0.2506752, 3.1113216, 6.9470208, 12.66432, 15.538944)
@@ -80,6 +80,17 @@ def basic_block(sd, p, x, training, stride=1):
     return F.relu(y + idt)
 
 
+def bottleneck(sd, p, x, training, stride=1):
+    """src/models/resnet.py:172-192: 1x1 -> 3x3 (stride) -> 1x1 (x4), each conv(no bias)+BN, residual, ReLU."""
+    y = F.relu(_bn(sd, p + '.bn1', _conv(sd, p + '.conv1', x), training))
+    y = F.relu(_bn(sd, p + '.bn2', _conv(sd, p + '.conv2', y, stride, 1), training))
+    y = _bn(sd, p + '.bn3', _conv(sd, p + '.conv3', y), training)
+    idt = x
+    if (p + '.downsample.0.weight') in sd:
+        idt = _bn(sd, p + '.downsample.1', _conv(sd, p + '.downsample.0', x, stride), training)
+    return F.relu(y + idt)
+
+
 def encoder_stem(sd, p, x, training):
     """ResNet.forward_first_conv (src/models/resnet.py:352-358)."""
     return F.relu(_bn(sd, p + '.bn1', _conv(sd, p + '.conv1', x, 2, 3), training))
@@ -87,7 +98,8 @@ def encoder_stem(sd, p, x, training):
 
 def encoder_stage(sd, p, x, training, cfg, j):
     """ResNet.forward_layer{j} (src/models/resnet.py:360-379); stride 2 in the first block of j>=2."""
-    blk = non_bottleneck_1d if cfg.encoder_block == 'NonBottleneck1D' else basic_block
+    blk = bottleneck if cfg.encoder == 'resnet50' else \
+        (non_bottleneck_1d if cfg.encoder_block == 'NonBottleneck1D' else basic_block)
     for i in range(RESNET_LAYERS[cfg.encoder][j - 1]):
         stride = 2 if (i == 0 and j > 1) else 1
         x = blk(sd, f'{p}.layer{j}.{i}', x, training, stride)

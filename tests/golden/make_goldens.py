@@ -53,6 +53,8 @@ CFGS = {
     'R18_se': dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='SE-add', encoder='resnet18',
                    nr_decoder_blocks=[1, 1, 1]),
 }
+# the reference CLI's default encoder (src/args.py:105): ResNet-50 / Bottleneck (encoder_block is ignored)
+CFGS['R50_se'] = dict(encoder_block='BasicBlock', fuse_depth_in_rgb_encoder='SE-add', encoder='resnet50')
 MODES = ['eval_baseline', 'eval_soft', 'eval_hard', 'eval_ini', 'train_soft', 'train_hard']
 STRIDE = 8
 
@@ -418,6 +420,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'r18':
         model_fixture('R18_se', 96, 128, 2, ['eval_hard', 'train_soft'])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'r50':
+        model_fixture('R50_se', 96, 128, 2, ['eval_hard', 'train_soft'])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'skip':
         skip_fixture()
         sys.exit(0)
@@ -436,6 +441,7 @@ if __name__ == '__main__':
     model_fixture('S_add', 96, 128, 2, ['eval_baseline'])
     model_fixture('P_se', 160, 192, 3, ['eval_hard', 'train_soft'])
     model_fixture('R18_se', 96, 128, 2, ['eval_hard', 'train_soft'])
+    model_fixture('R50_se', 96, 128, 2, ['eval_hard', 'train_soft'])
     nyu8_fixture()
     skip_fixture()
     train_n8_fixture()

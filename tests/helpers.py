@@ -10,6 +10,7 @@ CFGS = {
     'P_add': O.Config(encoder_block='NonBottleneck1D', fuse='add'),
     'S_se': O.Config(encoder_block='BasicBlock', fuse='SE-add'),
     'S_add': O.Config(encoder_block='BasicBlock', fuse='add'),
+    'R50_se': O.Config(encoder='resnet50', encoder_block='BasicBlock', fuse='SE-add'),
     'R18_se': O.Config(encoder='resnet18', encoder_block='BasicBlock', fuse='SE-add', nr_decoder_blocks=[1, 1, 1]),
 }
 

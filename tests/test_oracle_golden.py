@@ -14,7 +14,7 @@ TOL = 2e-5   # oracle and reference are the same fp32 ATen ops; only thread-coun
 
 MODEL_FIXTURES = [
     ('P_se', 96, 128), ('P_add', 96, 128), ('S_se', 96, 128), ('S_add', 96, 128), ('P_se', 160, 192),
-    ('R18_se', 96, 128),
+    ('R18_se', 96, 128), ('R50_se', 96, 128),
 ]
 
 
