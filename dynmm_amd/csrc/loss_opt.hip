@@ -93,6 +93,29 @@ __global__ void __launch_bounds__(256) ce2d_bwd_kernel(const float* __restrict__
     }
 }
 
+// train.py:313-321 in one tiny launch: the S per-scale losses loss_s = sum_s / wsum_s (from the fp64 accumulators
+// of ce2d_fwd), total = sum_s loss_s + ratio * max(0, flop_loss - budget), and the seeds of the backward pass:
+// gscale_s = d total / d (sum_s) = 1 / wsum_s for ce2d_bwd, d_flop = ratio * [flop_loss > budget].
+__global__ void loss_head_kernel(const double* __restrict__ acc, int S, const float* __restrict__ flop_loss,
+                                 float ratio, float budget, float* __restrict__ losses, float* __restrict__ total,
+                                 float* __restrict__ gscale, float* __restrict__ d_flop) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float tot = 0.f;
+    for (int s_ = 0; s_ < S; ++s_) {
+        const float l = (float)(acc[2 * s_] / acc[2 * s_ + 1]);
+        losses[s_] = l;
+        gscale[s_] = (float)(1.0 / acc[2 * s_ + 1]);
+        tot += l;                                  // left to right, like sum(losses) on the host
+    }
+    float df = 0.f;
+    if (flop_loss && ratio > 0.f) {
+        const float ex = flop_loss[0] - budget;
+        if (ex > 0.f) { tot += ratio * ex; df = ratio; }
+    }
+    total[0] = tot;
+    if (d_flop) d_flop[0] = df;
+}
+
 // Flat fused optimizer updates (train.py:554-579).  One kernel covers an element range [lo, hi) of the flat
 // parameter / gradient / state buffers (16-byte aligned bases): aligned groups of 4 go through dwordx4
 // accesses, the ragged edges of the range element by element.  Hyper-parameters that the training driver
@@ -234,13 +257,23 @@ __global__ void __launch_bounds__(256) eval_confusion_kernel(const float* __rest
 
 using namespace dynmm;
 
+extern "C" int dynmm_loss_head(const double* acc, int S, const float* flop_loss, float ratio, float budget,
+                               float* losses, float* total, float* gscale, float* d_flop, void* stream) {
+    (void)hipGetLastError();
+    if (!acc || S <= 0 || !losses || !total || !gscale) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, S, flop_loss, ratio, budget,
+                       losses, total, gscale, d_flop);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
 extern "C" int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
-                              double* loss_sum_wsum, int N, int C, int HW, void* stream) {
+                              double* loss_sum_wsum, int N, int C, int HW, int acc_is_zero, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !target || !cw || !loss_sum_wsum || N <= 0 || C <= 0 || C > kMaxClasses || HW <= 0)
         return DYNMM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    DYNMM_HIP_TRY(hipMemsetAsync(loss_sum_wsum, 0, 2 * sizeof(double), st));
+    if (!acc_is_zero) DYNMM_HIP_TRY(hipMemsetAsync(loss_sum_wsum, 0, 2 * sizeof(double), st));
     int bx = ceil_div(HW, 256);
     if (bx > 256) bx = 256;
     if (C <= 40)

@@ -558,11 +558,57 @@ __global__ void __launch_bounds__(256) batch_merge_kernel(const float* __restric
     }
 }
 
+// out = src[0] + src[1] (+ src[2] (+ src[3])), summed left to right: the gradient of a tensor that fans out to
+// several consumers (one pass over n inputs instead of autograd's n-1 pairwise accumulation passes).
+struct AddSrcs { const float* p[4]; };
+template <int V>
+__global__ void __launch_bounds__(256) add_n_kernel(AddSrcs S, int n, float* __restrict__ out, size_t numel) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < numel; i += (size_t)gridDim.x * 256 * V) {
+        float acc[V], v[V];
+        vload<V>(S.p[0] + i, acc);
+        vload<V>(S.p[1] + i, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += v[j];
+        if (n > 2) {
+            vload<V>(S.p[2] + i, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += v[j];
+        }
+        if (n > 3) {
+            vload<V>(S.p[3] + i, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += v[j];
+        }
+        vstore<V>(out + i, acc);
+    }
+}
+
 }  // namespace dynmm
 
 using namespace dynmm;
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int dynmm_add_n(const float* const* srcs, int n, float* out, size_t numel, void* stream) {
+    (void)hipGetLastError();
+    if (!srcs || !out || n < 2 || n > 4 || numel == 0) return DYNMM_EINVAL;
+    AddSrcs S{};
+    bool v4 = (numel % 4 == 0) && aligned16(out);
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i]) return DYNMM_EINVAL;
+        S.p[i] = srcs[i];
+        v4 = v4 && aligned16(srcs[i]);
+    }
+    size_t blocks = (numel / (v4 ? 4 : 1) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (v4)
+        hipLaunchKernelGGL(add_n_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, ST, S, n, out, numel);
+    else
+        hipLaunchKernelGGL(add_n_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ST, S, n, out, numel);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
 
 extern "C" int dynmm_batch_gather(const float* src, const int* idx, float* dst, int n_out, size_t row,
                                   void* stream) {

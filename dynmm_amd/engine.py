@@ -217,16 +217,13 @@ class TrainStep:
                 outs, lf = res                                   # SkipGateESANet: ((out, out8, out16, out32), flop loss)
             else:
                 outs, lf = res, torch.zeros((), device=rgb.device)   # SkipESANet: the four outputs only
-            losses = [ops.cross_entropy_2d(o, t, self.cw) for o, t in zip(outs, targets)]
-            seg = losses[0]
-            for l in losses[1:]:
-                seg = seg + l
-            total = seg + self.loss_ratio * torch.clamp(lf - self.flop_budget, min=0.0) if self.loss_ratio > 0 else seg
-            total.backward()
+            # weighted 4-scale CE, total-loss rule and the seeds of the backward pass on the device (no PyTorch
+            # arithmetic kernels between the forward and the backward of the model)
+            self.last = ops.multi_scale_loss_backward(outs, targets, self.cw, lf if self.loss_ratio > 0 else None,
+                                                      self.loss_ratio, self.flop_budget)
+            self.last['loss_flop'] = lf.detach()
             ops.join_async()
             self._touched = ops.touched_ids()
-        self.last = {'losses': torch.stack([l.detach() for l in losses]), 'loss_flop': lf.detach(),
-                     'total': total.detach().reshape(1)}
 
     def _finish(self):
         self.reducer.finish()

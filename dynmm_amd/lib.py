@@ -73,11 +73,13 @@ SIGNATURES = {
     'dynmm_gate_head_fwd': (c_i, [c_f] * 8 + [c_i, c_i, c_fl, c_i, c_i, c_f]),
     'dynmm_gate_decide': (c_i, [c_f] * 5 + [c_i, c_f]),
     'dynmm_gate_head_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_fl, c_f]),
-    'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_f]),
+    'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_loss_head': (c_i, [c_f, c_i, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'dynmm_ce2d_bwd': (c_i, [c_f] * 5 + [c_i, c_i, c_i, c_f]),
     'dynmm_eval_confusion': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
     'dynmm_batch_gather': (c_i, [c_f, c_f, c_f, c_i, c_sz, c_f]),
     'dynmm_batch_merge': (c_i, [c_f, c_f, c_f, c_f, c_i, c_sz, c_f]),
+    'dynmm_add_n': (c_i, [_PP, c_i, c_f, c_sz, c_f]),
     'dynmm_reduce_slabs': (c_i, [c_f, c_f, c_i, c_i, c_f]),
     'dynmm_opt_tick': (c_i, [c_f, c_f]),
     'dynmm_sgd_nesterov': (c_i, [c_f, c_f, c_f, c_sz, c_sz, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f]),

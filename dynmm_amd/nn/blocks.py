@@ -56,12 +56,15 @@ class NonBottleneck1D(nn.Module):
         # added in the dgrad epilogue of the first conv instead of a separate autograd add pass.
         fuse_bwd = torch.is_grad_enabled() and x.requires_grad
         link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
+        xd = x
+        if self.downsample is not None:
+            x, xd = ops.fan_out(x, 2)            # x feeds the first conv AND the down-sample conv: one fused gradient sum
         c = self.conv3x1_1
         y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link)
         y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd)
         c = self.conv3x1_2
         y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd)
-        idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
         return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link)
 
 
@@ -80,8 +83,11 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         fuse_bwd = torch.is_grad_enabled() and x.requires_grad
         link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
+        xd = x
+        if self.downsample is not None:
+            x, xd = ops.fan_out(x, 2)
         y = conv_bn_act(x, self.conv1, self.bn1, 'relu', conv_link=link)
-        idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
         return conv_bn_act(y, self.conv2, self.bn2, 'relu', residual=idt, res_link=link)
 
 
@@ -103,9 +109,12 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         fuse_bwd = torch.is_grad_enabled() and x.requires_grad
         link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
+        xd = x
+        if self.downsample is not None:
+            x, xd = ops.fan_out(x, 2)
         y = conv_bn_act(x, self.conv1, self.bn1, 'relu', conv_link=link)
         y = conv_bn_act(y, self.conv2, self.bn2, 'relu')
-        idt = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+        idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
         return conv_bn_act(y, self.conv3, self.bn3, 'relu', residual=idt, res_link=link)
 
 

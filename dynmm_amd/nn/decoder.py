@@ -38,7 +38,8 @@ class DecoderModule(nn.Module):
         side = None
         if self.training:
             s = self.side_output
-            side = ops.conv2d(y, s.weight, s.bias, 1, 0)
+            y, ys = ops.fan_out(y, 2)            # y feeds the side output AND the up-sampling
+            side = ops.conv2d(ys, s.weight, s.bias, 1, 0)
         return self.upsample(y, skip), side
 
 

@@ -212,9 +212,10 @@ class SkipGateESANet(nn.Module):
             ops.begin_step()
         r = er.forward_first_conv(rgb)
         d = ed.forward_first_conv(depth)
+        d, d_pool = ops.fan_out(d, 2)                               # depth stem output: stem fusion + its own max-pool
         fuse = ops.se_fuse_blend(r, d, self._se(0))                 # stem fusion is always on
         r = ops.max_pool_3x3_s2(fuse)
-        d = ops.max_pool_3x3_s2(d)
+        d = ops.max_pool_3x3_s2(d_pool)
 
         bs = r.shape[0]
         host_branch = None                                           # branch per sample when the host already knows it
@@ -234,7 +235,8 @@ class SkipGateESANet(nn.Module):
             if self.branch_override is not None and self.hard_gate:
                 host_branch = [int(v) for v in list(self.branch_override)[:bs]]
                 force = self._force_tensor(host_branch, rgb.device)
-            pooled = self.gate_layer.features(r, d)
+            (r, r_gate), (d, d_gate) = ops.fan_out(r, 2), ops.fan_out(d, 2)    # gate convs + first encoder stage
+            pooled = self.gate_layer.features(r_gate, d_gate)
             weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate, force)
         if self.save_weight_info:
             self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
@@ -279,17 +281,22 @@ class SkipGateESANet(nn.Module):
                     sk = getattr(self, f'skip_layer{j}')
                     skips.append(sk[0](fuse) if len(sk) else fuse)
         else:
+            wcs = ops.fan_out(wcum, 4)               # one cumulative-weight column per stage
             for j in (1, 2, 3, 4):
                 if self.dual_stream:
                     r, d = encoder_stage_pair(self, j, r if j == 1 else fuse, d)
                 else:
                     r = getattr(er, f'forward_layer{j}')(r if j == 1 else fuse)
                     d = getattr(ed, f'forward_layer{j}')(d)
-                # stage j<4: w*rgb + (1-w)*fused with w = sum_{k<j} weight[:,k];  stage 4: w = 1-weight[:,4]
-                fuse = ops.se_fuse_blend(r, d, self._se(j), wcum, j - 1)
+                d_f = d
                 if j < 4:
+                    d_f, d = ops.fan_out(d, 2)       # stage-j depth features: fusion + next depth stage
+                # stage j<4: w*rgb + (1-w)*fused with w = sum_{k<j} weight[:,k];  stage 4: w = 1-weight[:,4]
+                fuse = ops.se_fuse_blend(r, d_f, self._se(j), wcs[j - 1], j - 1)
+                if j < 4:
+                    fuse, f_skip = ops.fan_out(fuse, 2)   # fused map: next RGB stage + decoder skip connection
                     sk = getattr(self, f'skip_layer{j}')
-                    skips.append(sk[0](fuse) if len(sk) else fuse)
+                    skips.append(sk[0](f_skip) if len(sk) else f_skip)
         out = self.context_module(fuse)
         out = self.decoder([out, skips[2], skips[1], skips[0]], unpermute=unpermute)
 

@@ -351,6 +351,37 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_in
                          bool(defer_mask), link, _split_forward_allowed())
 
 
+class _FanOut(Function):
+    """n aliases of x whose gradients are summed by ONE kernel of ours (left to right, deterministic) instead of
+    autograd's n-1 pairwise accumulation passes."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_chk(g, 'grad') for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        while len(gs) > 1:
+            take, gs = gs[:4], gs[4:]
+            dst = out if not gs else torch.empty_like(out)
+            L.check(_lib().dynmm_add_n(_ptr_array(take), len(take), _p(dst), C.c_size_t(dst.numel()), _stream()), 'add_n')
+            gs = [dst] + gs
+        return out, None
+
+
+def fan_out(x, n):
+    """x for n consumers: returns n aliases (no copy).  Outside autograd it is the identity."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return _FanOut.apply(x, n)
+
+
 _MUTATION_GEN = [0]    # bumped by every HIP kernel of ours that rewrites parameters / buffers through raw pointers
 
 
@@ -1026,7 +1057,7 @@ class _CrossEntropy2d(Function):
         x, class_weight = _chk(x, 'logits'), _chk(class_weight, 'class_weight')
         N, Cc, H, W = x.shape
         acc = torch.empty(2, device=x.device, dtype=torch.float64)
-        L.check(lib.dynmm_ce2d_fwd(_p(x), _p(target_u8), _p(class_weight), _p(acc), N, Cc, H * W, _stream()), 'ce2d_fwd')
+        L.check(lib.dynmm_ce2d_fwd(_p(x), _p(target_u8), _p(class_weight), _p(acc), N, Cc, H * W, 0, _stream()), 'ce2d_fwd')
         ctx.save_for_backward(x, target_u8, class_weight, acc)
         return (acc[0] / acc[1]).float()
 
@@ -1048,6 +1079,50 @@ def cross_entropy_2d(logits, target, class_weight):
     if not t.is_contiguous():
         t = t.contiguous()
     return _CrossEntropy2d.apply(logits, t, class_weight)
+
+
+def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio=0.0, budget=0.0):
+    """train.py:313-323 for the HIP path, without a single PyTorch arithmetic kernel: the weighted CE of every
+    scale (fp64 accumulators), total = sum_s CE_s + ratio * max(0, flop_loss - budget), and the backward pass of
+    the whole step — the gradients of the logits come straight from dynmm_ce2d_bwd, seeded on the device, and are
+    handed to autograd as the incoming gradients of the model outputs.
+    Returns {'losses': [S], 'loss_flop': (), 'total': [1]} (detached device tensors)."""
+    lib = _lib()
+    st = _stream()
+    outs = [_chk(o, 'logits') for o in outs]
+    cw = _chk(class_weight, 'class_weight')
+    S = len(outs)
+    dev = outs[0].device
+    acc = torch.zeros(2 * S, device=dev, dtype=torch.float64)
+    tg = []
+    for s_, (o, t) in enumerate(zip(outs, targets)):
+        t = t if t.dtype == torch.uint8 else t.to(torch.uint8)
+        t = t if t.is_contiguous() else t.contiguous()
+        tg.append(t)
+        N, Cc, H, W = o.shape
+        L.check(lib.dynmm_ce2d_fwd(_p(o), _p(t), _p(cw), acc.data_ptr() + 16 * s_, N, Cc, H * W, 1, st), 'ce2d_fwd')
+    f32 = dict(device=dev, dtype=torch.float32)
+    losses, total, gscale = torch.empty(S, **f32), torch.empty(1, **f32), torch.empty(S, **f32)
+    use_flop = flop_loss is not None and flop_loss.requires_grad and ratio > 0
+    d_flop = torch.empty((), **f32) if use_flop else None
+    lf = flop_loss.detach() if flop_loss is not None else None
+    L.check(lib.dynmm_loss_head(acc.data_ptr(), S, _p(lf) if ratio > 0 else None, float(ratio), float(budget),
+                                _p(losses), _p(total), _p(gscale), _p(d_flop), st), 'loss_head')
+    roots, grads = [], []
+    for s_, (o, t) in enumerate(zip(outs, tg)):
+        if not o.requires_grad:
+            continue
+        N, Cc, H, W = o.shape
+        dx = torch.empty_like(o)
+        L.check(lib.dynmm_ce2d_bwd(_p(o), _p(t), _p(cw), gscale.data_ptr() + 4 * s_, _p(dx), N, Cc, H * W, st), 'ce2d_bwd')
+        roots.append(o)
+        grads.append(dx)
+    if use_flop:
+        roots.append(flop_loss)
+        grads.append(d_flop)
+    if roots:
+        torch.autograd.backward(roots, grads)
+    return {'losses': losses, 'loss_flop': lf if lf is not None else torch.zeros((), **f32), 'total': total}
 
 
 def eval_confusion(logits, label, cm):

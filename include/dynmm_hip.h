@@ -252,7 +252,12 @@ int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, const float*
  * loss_sum += sum_px w[t]*(-log softmax(x)[t]);  wsum += sum_px w[t]   (t = target-1, void skipped)
  * dx = (softmax - onehot) * w[t] * gscale[0]   (gscale = upstream_grad / wsum, device scalar). */
 int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
-                   double* loss_sum_wsum /*[2]*/, int N, int C, int HW, void* stream);
+                   double* loss_sum_wsum /*[2]*/, int N, int C, int HW, int acc_is_zero, void* stream);
+/* train.py:313-321 on the device: losses[s] = acc[2s]/acc[2s+1] for the S scales,
+ * total = sum_s losses[s] + ratio*max(0, flop_loss - budget), and the backward seeds gscale[s] = 1/acc[2s+1]
+ * (for dynmm_ce2d_bwd) and d_flop = ratio*[flop_loss > budget].  flop_loss / d_flop optional. */
+int dynmm_loss_head(const double* acc, int S, const float* flop_loss, float ratio, float budget,
+                    float* losses, float* total, float* gscale, float* d_flop, void* stream);
 int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
                    const float* gscale, float* dx, int N, int C, int HW, void* stream);
 
@@ -278,6 +283,10 @@ int dynmm_batch_merge(const float* base, const float* sub, const int* map, float
                       void* stream);
 
 /* ---- helpers ---- */
+/* out = srcs[0] + ... + srcs[n-1] (2 <= n <= 4, left to right): the gradient of an activation that fans out to
+ * several consumers (block input -> first conv + down-sample conv, stage output -> skip connection + next stage,
+ * ...) in one pass instead of autograd's pairwise accumulation. */
+int dynmm_add_n(const float* const* srcs, int n, float* out, size_t numel, void* stream);
 /* out[i] = sum_s slabs[s][i] */
 int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nslabs, void* stream);
 /* ---- fused flat optimizers (train.py:554-579), SURVEY §8f-1 ----
