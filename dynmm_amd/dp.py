@@ -48,6 +48,7 @@ class GradBucketReducer:
         self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda') else None
         self._hooks = []
         self._streams = [dict() for _ in self.buckets]      # per bucket: producer streams seen this step
+        self.active = True                                   # False: gradient hooks are ignored (tests: un-reduced pass)
         self.launched_in_backward = 0                        # buckets whose all-reduce started before finish()
         self.launch_log = []                                 # (bucket, 'backward' | 'finish') of the last step
         if self.overlap:
@@ -84,7 +85,7 @@ class GradBucketReducer:
 
     def _arrived(self, p):
         b = self._bucket_of.get(p)
-        if b is None or self._pending[b] <= 0:
+        if b is None or self._pending[b] <= 0 or not self.active:
             return
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -92,6 +93,12 @@ class GradBucketReducer:
             self._launch(b, 'backward')
 
     def _on_grad_ready(self, p):
+        # autograd runs a parameter's AccumulateGrad node — and this hook — even when the backward returned None for
+        # it, i.e. also under the in-place gradient protocol; there the kernels report completion themselves (with
+        # the streams they were launched on), so the hook must stay out of the way
+        from . import ops
+        if ops.DIRECT_GRAD:
+            return
         self._arrived(p)
 
     def _on_grad_written(self, p, streams):

@@ -25,7 +25,7 @@ def worker(rank, world, port, overlap):
     labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s + rank, device='cuda').to(torch.uint8) for s in (1, 8, 16, 32)]
     step = engine.TrainStep(m, np.linspace(0.5, 2.0, 40), lr=0.01, loss_ratio=0.1, bucket_mb=8.0, overlap=overlap)
     red = step.reducer
-    hook, ops.GRAD_READY_HOOK = ops.GRAD_READY_HOOK, None
+    red.active = False                                           # (1) un-reduced pass: hooks ignored
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     step._body(rgb, depth, labels)
     torch.cuda.synchronize()
@@ -34,7 +34,7 @@ def worker(rank, world, port, overlap):
     torch.cuda.synchronize()
     local2 = red.flat.clone()
     m.load_state_dict(sd)
-    ops.GRAD_READY_HOOK = hook
+    red.active = True
     step._body(rgb, depth, labels)
     log = list(red.launch_log)
     red.finish()

@@ -45,13 +45,13 @@ def _worker(rank, world, port, q):
     red = step.reducer
     assert red.overlap and len(red.buckets) >= 4
     # (1) un-reduced local gradient: same body with the hook detached
-    hook, ops.GRAD_READY_HOOK = ops.GRAD_READY_HOOK, None
+    red.active = False                                           # (1) un-reduced pass: hooks ignored
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     step._body(rgb, depth, labels)
     torch.cuda.synchronize()
     local = red.flat.clone()
     m.load_state_dict(sd)                                        # undo BN running-stat updates
-    ops.GRAD_READY_HOOK = hook
+    red.active = True
     # (2) the real step body: buckets fly during backward
     step._body(rgb, depth, labels)
     in_bwd, nb = red.launched_in_backward, len(red.buckets)
