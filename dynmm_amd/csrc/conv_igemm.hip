@@ -70,8 +70,14 @@ __device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: wall cloc
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
-template <int TCO, int TPIX, int WCO, int WPIX, bool DGRAD, bool GENERIC>
+// MODE 0: fast path (reduction channels % 16 == 0, one filter tap per K-step); MODE 1: the same with the channel
+// count rounded up to 16 by zero weight rows (8 <= C, C % 16 != 0: dgrad of the 40-class convs, the 8-channel gate
+// conv) — kept out of MODE 0 because even two extra VALU per staged element cost the hot kernels ~10 %;
+// MODE 2: generic element-wise loader (stems C = 1 / 3).
+template <int TCO, int TPIX, int WCO, int WPIX, bool DGRAD, int MODE>
 __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 : 6))) conv_igemm_kernel(const IgemmArgs a) {
+    constexpr bool GENERIC = MODE == 2;
+    constexpr bool padded = MODE == 1;
     constexpr int BK = 16;
     constexpr int MCO = WCO / 32, MPIX = WPIX / 32;
     constexpr int WAVES_PIX = TPIX / WPIX;
@@ -191,8 +197,7 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
 
     if constexpr (!GENERIC) {
         // ---------------- fast path: Ci % 16 == 0, one filter tap per K-step ----------------
-        const int cpt = a.CiR / BK;
-        const bool padded = a.CiR != a.Ci;       // last K-step of a tap is partly zero rows (e.g. dgrad of a 40-class conv)
+        const int cpt = a.CiR / BK;              // MODE 1: the last K-step of a tap is partly zero rows
         // taps that can reach this tile: all of them, unless the tile lies inside one parity class
         int live_ph = -1, live_pw = -1;
         if (DGRAD && a.subpix) {
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
             const bool first = ci0 < a.c_in_split;
             const float* xbase = first ? a.x + (size_t)ci0 * HW : a.x2 + (size_t)(ci0 - a.c_in_split) * HW;
             const unsigned voff = first ? voff1 : voff2;
-            if (!padded) {
+            if constexpr (!padded) {
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i)
                     rb[i] = ldg_f32(xbase + (size_t)(i * B_ROWSTEP) * HW, voff);
@@ -274,7 +279,7 @@ __global__ void __launch_bounds__(256, (TCO * TPIX > 8192 ? 2 : (TPIX > 128 ? 4 
             }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
-                Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = (ld_ok && ((ld_cmask >> i) & 1u)) ? rb[i] : 0.f;
+                Bs[buf][b_row0 + i * B_ROWSTEP][b_col] = (ld_ok && (!padded || ((ld_cmask >> i) & 1u))) ? rb[i] : 0.f;
         };
 
         if (!tap_live(0, 0)) {           // first live tap
@@ -547,10 +552,13 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
         a.n_pix_tiles = ceil_div(a.M, TPIX);                                                   \
         dim3 grid((unsigned)(a.n_co_tiles * a.n_pix_tiles));                                   \
         if (generic)                                                                           \
-            hipLaunchKernelGGL((conv_igemm_kernel<TCO, TPIX, WCO, WPIX, DGRAD, true>), grid,   \
+            hipLaunchKernelGGL((conv_igemm_kernel<TCO, TPIX, WCO, WPIX, DGRAD, 2>), grid,      \
+                               dim3(256), 0, st, a);                                           \
+        else if (a.CiR != a.Ci)                                                                \
+            hipLaunchKernelGGL((conv_igemm_kernel<TCO, TPIX, WCO, WPIX, DGRAD, 1>), grid,      \
                                dim3(256), 0, st, a);                                           \
         else                                                                                   \
-            hipLaunchKernelGGL((conv_igemm_kernel<TCO, TPIX, WCO, WPIX, DGRAD, false>), grid,  \
+            hipLaunchKernelGGL((conv_igemm_kernel<TCO, TPIX, WCO, WPIX, DGRAD, 0>), grid,      \
                                dim3(256), 0, st, a);                                           \
     } while (0)
     if (a.Co > 64) {

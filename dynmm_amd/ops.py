@@ -168,7 +168,13 @@ def _timed(kind, g, call):
         return call()
     co = g.Ci if kind == 'dgrad' else g.Co
     gemm_ci = g.Co if kind == 'dgrad' else g.Ci
-    generic = ',generic' if (kind != 'wgrad' and (gemm_ci % 16 != 0 or (g.c_split < g.Ci and g.c_split % 16 != 0))) else ''
+    rk = ((gemm_ci + 15) & ~15) if (gemm_ci >= 8 and gemm_ci % 16) else gemm_ci      # conv_igemm.hip: round_k
+    generic = ''
+    if kind != 'wgrad':
+        if rk % 16 != 0 or (g.c_split < g.Ci and g.c_split % 16 != 0):
+            generic = ',generic'
+        elif rk != gemm_ci:
+            generic = ',padded'
     m = g.N * (g.H * g.W if kind == 'dgrad' else g.Ho * g.Wo)
     name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co, m)}{generic}>'
     flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
