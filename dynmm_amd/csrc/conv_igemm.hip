@@ -893,14 +893,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 //     instructions before).
 // Eligible: one input tensor, Ci % 64 == 0, Co > 64, stride 1 along W with 'same' padding and KW in {1, 3},
 // W % 4 == 0, (Ho*Wo) % 4 == 0, 16-byte aligned x / dy.  Everything else stays on conv_wgrad_kernel.
-template <int TCO, int TK>
+template <int TCO, int TK, int NBUF>
 __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a) {
+    // NBUF = 2: double-buffered tiles, one barrier per step (72 KB of LDS per workgroup: fastest when the kernel has
+    // the GPU to itself).  NBUF = 1: 36 KB, two barriers per step — leaves LDS for the workgroups of the other
+    // streams' kernels (the training step runs the weight gradients beside the dgrad / BatchNorm chain).
     constexpr int BP = 32, LD = 36;
     constexpr int WAVES_K = TK / 32;
     static_assert(TCO == 128 && TK == 128, "8 waves: 2 (co) x 4 (k)");
     constexpr int MCO = 2;
-    __shared__ __attribute__((aligned(16))) float Gs[2][TCO][LD];
-    __shared__ __attribute__((aligned(16))) float Xs[2][TK][LD];
+    __shared__ __attribute__((aligned(16))) float Gs[NBUF][TCO][LD];
+    __shared__ __attribute__((aligned(16))) float Xs[NBUF][TK][LD];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -1013,7 +1016,7 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
     }
     __syncthreads();
     for (int st = step_begin; st < step_end; ++st) {
-        const int buf = (st - step_begin) & 1;
+        const int buf = NBUF == 2 ? ((st - step_begin) & 1) : 0;
         const bool more = st + 1 < step_end;
         if (more) load_step();                         // global loads fly under the MFMAs below
         if (do_bias && t < TCO) {
@@ -1050,7 +1053,8 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
                 for (int mi = 0; mi < MCO; ++mi)
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][pp], bf[pp], acc[mi], 0, 0, 0);
         }
-        if (more) store_step(buf ^ 1);
+        if (NBUF == 1) __syncthreads();                // every wave is done reading the tile
+        if (more) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -1337,7 +1341,11 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     const bool perm = v4 && p.splits > 1 && ((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) && bias_ok4;
     a.k_major_out = perm ? 1 : 0;
     if (v4) {
-        hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128>), grid, dim3(512), 0, st, a);
+        static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
+        if (v4_nbuf == 2)
+            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a);
         DYNMM_LAUNCH_CHECK();
         if (perm) {
             const int n = g->Co * a.K, nb1 = ceil_div(n / 4, 64), nb2 = dbias ? ceil_div(g->Co / 4, 64) : 0;

@@ -381,9 +381,12 @@ class _FanOut(Function):
         return out, None
 
 
+_NO_FANOUT = bool(int(_os.environ.get('DYNMM_NO_FANOUT', '0')))     # A/B knob: let autograd accumulate pairwise
+
+
 def fan_out(x, n):
     """x for n consumers: returns n aliases (no copy).  Outside autograd it is the identity."""
-    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+    if n <= 1 or _NO_FANOUT or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * n
     return _FanOut.apply(x, n)
 
