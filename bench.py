@@ -374,6 +374,42 @@ def measure_fwd(args, device, batch, branches, compact, steps, warmup, with_kern
     return out
 
 
+def measure_affect(device, steps, warmup=3, batch=128, T=50):
+    """BASELINE configs[4] (per GPU): ModalityDynMM CMU-MOSEI DynMMNetV2 — text-transformer expert + 3-modality
+    late-fusion transformer expert + transformer gate — one optimisation step (fwd, L1 + gate regulariser, bwd,
+    clip_grad_norm_, AdamW) at batch 128 on synthetic MOSEI-shaped features.  Parity of this path is UNPINNED
+    (MultiBench is not vendored by the reference): tests/test_affect.py checks it against a self-written oracle."""
+    from dynmm_amd.nn import affect as A
+    torch.manual_seed(0)
+    model = A.DynMMNetV2(1.0, False, freeze=False).to(device)
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(batch, T, f, generator=g).to(device) for f in (35, 74, 300)]
+    inputs = [xs, [torch.full((batch,), T, dtype=torch.long)] * 3]
+    y = torch.randn(batch, 1, generator=g).to(device)
+    step = A.AffectTrainStep(model, lr=1e-5, weight_decay=1e-4, lossw=0.1)
+    res = {}
+    for name, fn in (('train_step', lambda: step(inputs, y)), ('forward', None)):
+        if fn is None:
+            model.eval()
+
+            def fn():
+                with torch.no_grad():
+                    return model(inputs)
+        for _ in range(2):
+            fn()
+        el = timed(fn, steps, warmup, 1, device)
+        res[name] = {'value': round(batch * steps / el, 1), 'unit': 'samples/s', 'ms_per_step': round(1000 * el / steps, 3)}
+    mmac = 135.13226 + 320.03205                      # affect_dyn.py:126 (thop MACs per sample, experts 1 + 2)
+    res['forward']['model_tflops'] = round(res['forward']['value'] * 2 * mmac * 1e6 / 1e12, 2)
+    res['train_step']['model_tflops'] = round(res['train_step']['value'] * 6 * mmac * 1e6 / 1e12, 2)
+    res['workload'] = ('configs[4] per GPU: ModalityDynMM DynMMNetV2 on CMU-MOSEI-shaped synthetic features '
+                       f'(T={T}: visual 35, audio 74, text 300), batch {batch}; experts trainable (freeze=False); '
+                       'PARITY UNPINNED (MultiBench not vendored)')
+    del step, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -454,6 +490,10 @@ def main():
                            'taken subset, straight-through gate gradient from the taken stages only) — DESIGN.md')
         res['unit'] = 'images/s'
         extra['train_hard'] = res
+        try:
+            extra['affect_mosei'] = measure_affect(device, max(10, args.steps))
+        except Exception as e:                      # a secondary line must never take the headline line down
+            extra['affect_mosei'] = {'error': f'{type(e).__name__}: {e}'}
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

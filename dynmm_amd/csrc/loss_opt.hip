@@ -183,18 +183,25 @@ __global__ void __launch_bounds__(256) sgd_nesterov_kernel(float* __restrict__ p
 // torch.optim.Adam (L2 weight decay folded into the gradient, amsgrad off), train.py:564-570:
 //   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
 //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = step[0] (already incremented by dynmm_opt_tick)
+// decoupled != 0: torch.optim.AdamW (Supervised_Learning.py:91 via affect_dyn.py:216): p *= 1 - lr*wd first, the
+// gradient is used as is.  gscale_dev (optional): device scalar multiplied into the gradient (the clip coefficient
+// of dynmm_clip_grad_norm).
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, OptRange r,
                                                    const float* __restrict__ hyper, const int* __restrict__ step,
                                                    float wd, float gscale, const float* __restrict__ loss,
-                                                   int* nan_flag) {
+                                                   int* nan_flag, int decoupled, const float* __restrict__ gscale_dev) {
     if (loss_bad(loss, nan_flag, step)) return;
+    if (gscale_dev) gscale *= gscale_dev[0];
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
     const double t = (double)step[0];
     const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
     const float step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+    const float decay = decoupled ? 1.f - lr * wd : 1.f;
+    const float l2 = decoupled ? 0.f : wd;
     auto upd = [&](float& pv, float gv, float& mv, float& vv) {
-        const float d = gv * gscale + wd * pv;
+        pv *= decay;
+        const float d = gv * gscale + l2 * pv;
         mv = b1 * mv + (1.f - b1) * d;
         vv = b2 * vv + (1.f - b2) * d * d;
         pv -= step_size * (mv / (sqrtf(vv) / bc2s + eps));       // torch: denom = sqrt(v)/sqrt(bc2) + eps
@@ -330,12 +337,13 @@ extern "C" int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t l
 
 extern "C" int dynmm_adam(float* p, const float* g, float* m, float* v, size_t lo, size_t hi, const float* hyper,
                           const int* step, float weight_decay, float grad_scale, const float* loss, int* nan_flag,
-                          void* stream) {
+                          int decoupled, const float* grad_scale_dev, void* stream) {
     (void)hipGetLastError();
     if (!p || !g || !m || !v || !hyper || !step || hi <= lo) return DYNMM_EINVAL;
     if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return DYNMM_EUNSUPPORTED;
     hipLaunchKernelGGL(adam_kernel, dim3(opt_blocks(hi - lo)), dim3(256), 0, (hipStream_t)stream,
-                       p, g, m, v, OptRange{lo, hi}, hyper, step, weight_decay, grad_scale, loss, nan_flag);
+                       p, g, m, v, OptRange{lo, hi}, hyper, step, weight_decay, grad_scale, loss, nan_flag, decoupled,
+                       grad_scale_dev);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

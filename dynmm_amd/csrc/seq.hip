@@ -1,0 +1,421 @@
+// Modality-level DynMM (ModalityDynMM/affect/affect_dyn.py): the pieces of the sequence experts that are not
+// GEMMs.  Every Linear / Conv1d(k=1) of those experts is a 1x1 convolution over tokens and runs on the
+// implicit-GEMM MFMA kernels of conv_igemm.hip with activations laid out [B, D, T] (= NCHW with H = 1, W = T,
+// exactly the layout the reference produces with x.permute([0, 2, 1]) in front of its Conv1d).  This file adds
+//   * LayerNorm over the channel axis D of [B, D, T] (post-norm TransformerEncoderLayer), forward + backward,
+//   * multi-head self-attention for short sequences (T <= 64): one wave per (sample, head), Q K V and the
+//     T x T probabilities stay in LDS, forward + backward,
+//   * the mixture head: DiffSoftmax gate over K experts (affect_dyn.py:18-28), blend, L1 loss, gate regulariser
+//     and the backward seeds (affect_dyn.py:152-165, Supervised_Learning.py:135-136), one launch,
+//   * global gradient-norm clipping (Supervised_Learning.py:143) as a deterministic two-stage reduction.
+// All of it is latency-bound bookkeeping around ~0.3 GMAC/sample of feed-forward GEMMs.
+#include "common.h"
+
+namespace dynmm {
+
+constexpr int kSeqMaxT = 64;
+constexpr int kSeqMaxDh = 32;
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over D for every token (b, t) of x[B, D, T]; lanes walk consecutive t (coalesced), D is strided.
+// ---------------------------------------------------------------------------------------------------------------
+// `res` (optional): the layer normalises x + res (the residual connection of the encoder layer) without a
+// separate add pass.
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int B, int D,
+                                                     int T, float eps) {
+    const int tok = blockIdx.x * 256 + threadIdx.x;
+    if (tok >= B * T) return;
+    const int b = tok / T, t = tok - b * T;
+    const size_t base = (size_t)b * D * T + t;
+    float s = 0.f;
+    for (int c = 0; c < D; ++c) s += x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
+    const float mu = s / (float)D;
+    float v = 0.f;
+    for (int c = 0; c < D; ++c) {
+        const float d = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu;
+        v += d * d;
+    }
+    const float rs = rsqrtf(v / (float)D + eps);
+    if (mean) mean[tok] = mu;
+    if (rstd) rstd[tok] = rs;
+    for (int c = 0; c < D; ++c) {
+        const float sv = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
+        y[base + (size_t)c * T] = (sv - mu) * rs * gamma[c] + beta[c];
+    }
+}
+
+// dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))
+__global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                        const float* __restrict__ res,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ dx, int B,
+                                                        int D, int T) {
+    const int tok = blockIdx.x * 256 + threadIdx.x;
+    if (tok >= B * T) return;
+    const int b = tok / T, t = tok - b * T;
+    const size_t base = (size_t)b * D * T + t;
+    const float mu = mean[tok], rs = rstd[tok];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < D; ++c) {
+        const float gg = g[base + (size_t)c * T] * gamma[c];
+        const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
+        s1 += gg;
+        s2 += gg * xh;
+    }
+    s1 /= (float)D;
+    s2 /= (float)D;
+    for (int c = 0; c < D; ++c) {
+        const float gg = g[base + (size_t)c * T] * gamma[c];
+        const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
+        dx[base + (size_t)c * T] = rs * (gg - s1 - xh * s2);
+    }
+}
+
+// dgamma[c] = sum_tok g * xhat ; dbeta[c] = sum_tok g : one workgroup per channel, fixed summation order
+__global__ void __launch_bounds__(256) ln_bwd_param_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           const float* __restrict__ res,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int B, int D, int T) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float a = 0.f, bsum = 0.f;
+    for (int tok = threadIdx.x; tok < B * T; tok += 256) {
+        const int b = tok / T, t = tok - b * T;
+        const size_t i = ((size_t)b * D + c) * T + t;
+        const float gv = g[i];
+        a += gv * (x[i] + (res ? res[i] : 0.f) - mean[tok]) * rstd[tok];
+        bsum += gv;
+    }
+    const float ta = block_reduce_sum_256<float>(a, red);
+    const float tb = block_reduce_sum_256<float>(bsum, red);
+    if (threadIdx.x == 0) {
+        dgamma[c] = ta;
+        dbeta[c] = tb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-head self-attention, qkv [B, 3D, T] (q | k | v along channels, as nn.MultiheadAttention's in_proj), heads H,
+// dh = D / H.  One 64-lane wave per (b, h); lane i owns query i (forward) / query i and key i (backward).
+//   P = softmax_j( (q_i . k_j) / sqrt(dh) ),  out[c][i] = sum_j P[i][j] v[c][j]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                     float* __restrict__ probs, int D, int T, int H) {
+    __shared__ float qs[kSeqMaxDh][kSeqMaxT], ks[kSeqMaxDh][kSeqMaxT], vs[kSeqMaxDh][kSeqMaxT];
+    __shared__ float ps[kSeqMaxT][kSeqMaxT + 1];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int dh = D / H;
+    const int i = threadIdx.x;
+    const float* base = qkv + (size_t)b * 3 * D * T;
+    for (int c = 0; c < dh; ++c) {
+        if (i < T) {
+            qs[c][i] = base[(size_t)(h * dh + c) * T + i];
+            ks[c][i] = base[(size_t)(D + h * dh + c) * T + i];
+            vs[c][i] = base[(size_t)(2 * D + h * dh + c) * T + i];
+        }
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)dh);
+    if (i < T) {
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) {
+            float s = 0.f;
+            for (int c = 0; c < dh; ++c) s += qs[c][i] * scale * ks[c][j];     // torch scales q before q @ k^T
+            ps[i][j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float e = expf(ps[i][j] - mx);
+            ps[i][j] = e;
+            den += e;
+        }
+        const float inv = 1.f / den;
+        float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
+        for (int j = 0; j < T; ++j) {
+            const float p = ps[i][j] * inv;
+            ps[i][j] = p;
+            pg[j] = p;
+        }
+        float* ob = out + (size_t)b * D * T;
+        for (int c = 0; c < dh; ++c) {
+            float s = 0.f;
+            for (int j = 0; j < T; ++j) s += ps[i][j] * vs[c][j];
+            ob[(size_t)(h * dh + c) * T + i] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g, const float* __restrict__ qkv,
+                                                     const float* __restrict__ probs, float* __restrict__ dqkv, int D,
+                                                     int T, int H) {
+    __shared__ float qs[kSeqMaxDh][kSeqMaxT], ks[kSeqMaxDh][kSeqMaxT], vs[kSeqMaxDh][kSeqMaxT];
+    __shared__ float gs[kSeqMaxDh][kSeqMaxT];
+    __shared__ float ps[kSeqMaxT][kSeqMaxT + 1], ds[kSeqMaxT][kSeqMaxT + 1];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int dh = D / H;
+    const int i = threadIdx.x;
+    const float* base = qkv + (size_t)b * 3 * D * T;
+    const float* gb = g + (size_t)b * D * T;
+    for (int c = 0; c < dh; ++c) {
+        if (i < T) {
+            qs[c][i] = base[(size_t)(h * dh + c) * T + i];
+            ks[c][i] = base[(size_t)(D + h * dh + c) * T + i];
+            vs[c][i] = base[(size_t)(2 * D + h * dh + c) * T + i];
+            gs[c][i] = gb[(size_t)(h * dh + c) * T + i];
+        }
+    }
+    if (i < T) {
+        const float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
+        for (int j = 0; j < T; ++j) ps[i][j] = pg[j];
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)dh);
+    if (i < T) {
+        // dP[i][j] = sum_c g[c][i] v[c][j];  dS = P * (dP - sum_j P dP)
+        float dot = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float s = 0.f;
+            for (int c = 0; c < dh; ++c) s += gs[c][i] * vs[c][j];
+            ds[i][j] = s;
+            dot += ps[i][j] * s;
+        }
+        for (int j = 0; j < T; ++j) ds[i][j] = ps[i][j] * (ds[i][j] - dot);
+    }
+    __syncthreads();
+    if (i < T) {
+        float* db = dqkv + (size_t)b * 3 * D * T;
+        for (int c = 0; c < dh; ++c) {
+            float dq = 0.f, dk = 0.f, dv = 0.f;
+            for (int j = 0; j < T; ++j) {
+                dq += ds[i][j] * ks[c][j];          // query i
+                dk += ds[j][i] * qs[c][j];          // key i: sum over queries j
+                dv += ps[j][i] * gs[c][j];
+            }
+            db[(size_t)(h * dh + c) * T + i] = dq * scale;
+            db[(size_t)(D + h * dh + c) * T + i] = dk * scale;
+            db[(size_t)(2 * D + h * dh + c) * T + i] = dv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mixture head + loss + backward seeds (one workgroup; B <= a few thousand).
+//   w = DiffSoftmax(logits / temp, hard)                                   affect_dyn.py:18-28,153
+//   out[b] = sum_k w[b,k] * pred_k[b]          (infer_mode 0)              affect_dyn.py:164
+//   aux = mean_b w[b, K-1]                                                  affect_dyn.py:165
+//   loss1 = mean_b |out[b] - y[b]| ; total = loss1 + reg * aux              Supervised_Learning.py:135-136
+// Seeds of d total: d_pred_k[b] = w[b,k] * sgn/B ; d_logits through the soft path (straight-through).
+// ---------------------------------------------------------------------------------------------------------------
+struct MoePreds { const float* p[4]; };
+struct MoeGrads { float* p[4]; };
+
+__global__ void __launch_bounds__(256) moe_head_kernel(const float* __restrict__ logits, MoePreds P, int K,
+                                                       const float* __restrict__ target, float temp, int hard, float reg,
+                                                       float* __restrict__ out, float* __restrict__ weight,
+                                                       float* __restrict__ scalars /* loss1, aux, total */,
+                                                       MoeGrads dP, float* __restrict__ d_logits, int B) {
+    __shared__ float red[4];
+    float l1 = 0.f, aux = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float z[4], w[4];
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) { z[k] = logits[(size_t)b * K + k] / temp; mx = fmaxf(mx, z[k]); }
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) { z[k] = expf(z[k] - mx); den += z[k]; }
+        int arg = 0;
+        float best = -1.f;
+        for (int k = 0; k < K; ++k) {
+            z[k] /= den;
+            if (z[k] > best) { best = z[k]; arg = k; }
+        }
+        float o = 0.f;
+        for (int k = 0; k < K; ++k) {
+            w[k] = hard ? ((k == arg ? 1.f : 0.f) - z[k]) + z[k] : z[k];
+            weight[(size_t)b * K + k] = w[k];
+            o += w[k] * P.p[k][b];
+        }
+        out[b] = o;
+        aux += w[K - 1];
+        if (target) {
+            const float diff = o - target[b];
+            l1 += fabsf(diff);
+            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            const float go = sgn * invB;
+            float dw[4], dot = 0.f;
+            for (int k = 0; k < K; ++k) {
+                if (dP.p[k]) dP.p[k][b] = w[k] * go;
+                dw[k] = P.p[k][b] * go + (k == K - 1 ? reg * invB : 0.f);
+                dot += z[k] * dw[k];
+            }
+            if (d_logits)
+                for (int k = 0; k < K; ++k) d_logits[(size_t)b * K + k] = z[k] * (dw[k] - dot) / temp;
+        }
+    }
+    const float t1 = block_reduce_sum_256<float>(l1, red);
+    const float ta = block_reduce_sum_256<float>(aux, red);
+    if (threadIdx.x == 0) {
+        scalars[0] = t1 * invB;
+        scalars[1] = ta * invB;
+        scalars[2] = t1 * invB + reg * ta * invB;
+    }
+}
+
+// backward of the blend for arbitrary upstream gradients (model used under plain autograd):
+//   d_pred_k = w_k * d_out ; d_w_k = pred_k * d_out + [k == K-1] * d_aux / B ; d_logits through the soft path
+__global__ void __launch_bounds__(256) moe_blend_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ d_aux,
+                                                            const float* __restrict__ logits, MoePreds P, int K,
+                                                            const float* __restrict__ weight, float temp, MoeGrads dP,
+                                                            float* __restrict__ d_logits, int B) {
+    const float da = d_aux ? d_aux[0] / (float)B : 0.f;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        float z[4];
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) { z[k] = logits[(size_t)b * K + k] / temp; mx = fmaxf(mx, z[k]); }
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) { z[k] = expf(z[k] - mx); den += z[k]; }
+        const float go = d_out ? d_out[b] : 0.f;
+        float dw[4], dot = 0.f;
+        for (int k = 0; k < K; ++k) {
+            z[k] /= den;
+            if (dP.p[k]) dP.p[k][b] = weight[(size_t)b * K + k] * go;
+            dw[k] = P.p[k][b] * go + (k == K - 1 ? da : 0.f);
+            dot += z[k] * dw[k];
+        }
+        for (int k = 0; k < K; ++k) d_logits[(size_t)b * K + k] = z[k] * (dw[k] - dot) / temp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sum of squares of a flat buffer -> clip coefficient min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float* __restrict__ x, size_t n,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        s += v * v;
+    }
+    const double t = block_reduce_sum_256<double>(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ void clip_coef_kernel(const double* __restrict__ part, int nparts, float max_norm, float* __restrict__ out2) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += part[i];
+    const double norm = sqrt(s);
+    out2[0] = (float)norm;
+    const double c = (double)max_norm / (norm + 1e-6);
+    out2[1] = c < 1.0 ? (float)c : 1.f;
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int dynmm_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                   float* mean, float* rstd, int B, int D, int T, float eps, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !gamma || !beta || !y || B <= 0 || D <= 0 || T <= 0) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, ST, x, res, gamma, beta, y, mean, rstd,
+                       B, D, T, eps);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_layernorm_bwd(const float* g, const float* x, const float* res, const float* gamma,
+                                   const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, int B,
+                                   int D, int T, void* stream) {
+    (void)hipGetLastError();
+    if (!g || !x || !gamma || !mean || !rstd || B <= 0 || D <= 0 || T <= 0) return DYNMM_EINVAL;
+    if (dx) {
+        hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, ST, g, x, res, gamma, mean, rstd,
+                           dx, B, D, T);
+        DYNMM_LAUNCH_CHECK();
+    }
+    if (dgamma && dbeta) {
+        hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(D), dim3(256), 0, ST, g, x, res, mean, rstd, dgamma, dbeta, B, D, T);
+        DYNMM_LAUNCH_CHECK();
+    }
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads, void* stream) {
+    (void)hipGetLastError();
+    if (!qkv || !out || !probs || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
+    if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_mha_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T,
+                             int heads, void* stream) {
+    (void)hipGetLastError();
+    if (!g || !qkv || !probs || !dqkv || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
+    if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_moe_head(const float* logits, const float* const* preds, int K, const float* target, float temp,
+                              int hard, float reg, float* out, float* weight, float* scalars, float* const* d_preds,
+                              float* d_logits, int B, void* stream) {
+    (void)hipGetLastError();
+    if (!logits || !preds || K < 1 || K > 4 || !out || !weight || !scalars || B <= 0 || !(temp > 0.f)) return DYNMM_EINVAL;
+    MoePreds P{};
+    MoeGrads G{};
+    for (int k = 0; k < K; ++k) {
+        if (!preds[k]) return DYNMM_EINVAL;
+        P.p[k] = preds[k];
+        G.p[k] = d_preds ? d_preds[k] : nullptr;
+    }
+    hipLaunchKernelGGL(moe_head_kernel, dim3(1), dim3(256), 0, ST, logits, P, K, target, temp, hard, reg, out, weight,
+                       scalars, G, d_logits, B);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_moe_blend_bwd(const float* d_out, const float* d_aux, const float* logits, const float* const* preds,
+                                   int K, const float* weight, float temp, float* const* d_preds, float* d_logits, int B,
+                                   void* stream) {
+    (void)hipGetLastError();
+    if (!logits || !preds || !weight || !d_logits || K < 1 || K > 4 || B <= 0 || !(temp > 0.f)) return DYNMM_EINVAL;
+    MoePreds P{};
+    MoeGrads G{};
+    for (int k = 0; k < K; ++k) {
+        if (!preds[k]) return DYNMM_EINVAL;
+        P.p[k] = preds[k];
+        G.p[k] = d_preds ? d_preds[k] : nullptr;
+    }
+    hipLaunchKernelGGL(moe_blend_bwd_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, ST, d_out, d_aux, logits, P, K, weight,
+                       temp, G, d_logits, B);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" size_t dynmm_clip_grad_norm_workspace_bytes(void) { return 1024 * sizeof(double); }
+
+extern "C" int dynmm_clip_grad_norm(const float* flat_grad, size_t n, float max_norm, double* workspace,
+                                    float* norm_and_coef, void* stream) {
+    (void)hipGetLastError();
+    if (!flat_grad || n == 0 || !workspace || !norm_and_coef) return DYNMM_EINVAL;
+    size_t blocks = (n + 4095) / 4096;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, ST, flat_grad, n, workspace);
+    DYNMM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, ST, workspace, (int)blocks, max_norm, norm_and_coef);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}

@@ -139,8 +139,11 @@ class SGDNesterov(_FlatOptimizer):
 class Adam(_FlatOptimizer):
     """torch.optim.Adam(betas=(0.9, 0.999), eps=1e-8, weight_decay=L2) — train.py:564-570."""
 
-    def __init__(self, flatp, flat_grads, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, groups=None):
+    def __init__(self, flatp, flat_grads, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, groups=None,
+                 decoupled=False):
         super().__init__(flatp, flat_grads, groups)
+        self.decoupled = bool(decoupled)          # True: torch.optim.AdamW
+        self.grad_scale_dev = None                # optional device scalar (gradient-norm clip coefficient)
         self.m, self.v = torch.zeros_like(self.p), torch.zeros_like(self.p)
         self.weight_decay = float(weight_decay)
         self.set_lr(lr)
@@ -151,7 +154,8 @@ class Adam(_FlatOptimizer):
     def _launch(self, lib, lo, hi, sp, lp, st):
         L.check(lib.dynmm_adam(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), sp, self.weight_decay, 1.0,
-                               lp, self.nan_flag.data_ptr(), st), 'adam')
+                               lp, self.nan_flag.data_ptr(), int(self.decoupled),
+                               None if self.grad_scale_dev is None else self.grad_scale_dev.data_ptr(), st), 'adam')
 
     def state_dict(self):
         return {'kind': 'Adam', 'exp_avg': self.m, 'exp_avg_sq': self.v, 'hyper': self.hyper, 'steps': self.steps}

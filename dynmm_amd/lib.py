@@ -83,7 +83,15 @@ SIGNATURES = {
     'dynmm_reduce_slabs': (c_i, [c_f, c_f, c_i, c_i, c_f]),
     'dynmm_opt_tick': (c_i, [c_f, c_f]),
     'dynmm_sgd_nesterov': (c_i, [c_f, c_f, c_f, c_sz, c_sz, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f]),
-    'dynmm_adam': (c_i, [c_f, c_f, c_f, c_f, c_sz, c_sz, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f]),
+    'dynmm_adam': (c_i, [c_f, c_f, c_f, c_f, c_sz, c_sz, c_f, c_f, c_fl, c_fl, c_f, c_f, c_i, c_f, c_f]),
+    'dynmm_layernorm_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_i, c_fl, c_f]),
+    'dynmm_layernorm_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_i, c_f]),
+    'dynmm_moe_blend_bwd': (c_i, [c_f, c_f, c_f, _PP, c_i, c_f, c_fl, _PP, c_f, c_i, c_f]),
+    'dynmm_mha_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_mha_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_moe_head': (c_i, [c_f, _PP, c_i, c_f, c_fl, c_i, c_fl, c_f, c_f, c_f, _PP, c_f, c_i, c_f]),
+    'dynmm_clip_grad_norm_workspace_bytes': (c_sz, []),
+    'dynmm_clip_grad_norm': (c_i, [c_f, c_sz, c_fl, c_f, c_f, c_f]),
 }
 
 ABI_VERSION = 2

@@ -1,0 +1,215 @@
+"""Modality-level DynMM on CMU-MOSEI features (ModalityDynMM/affect/affect_dyn.py) on the HIP path.
+
+PARITY UNPINNED.  The reference builds its experts from MultiBench (`unimodals.common_models.Transformer / MLP`,
+`fusions.common_fusions.Concat`, `training_structures.Supervised_Learning.MMDL`), which is neither vendored in
+/root/reference nor pinned to a commit (ModalityDynMM README; affect_dyn.py:12-15).  The modules below restate
+MultiBench's published definitions:
+
+  Transformer(n_features, dim)   Conv1d(n_features, dim, 1, bias=False) over the feature axis, then
+                                 nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=dim, nhead=5), num_layers=5)
+                                 (post-norm, ReLU, dim_feedforward 2048), output = the LAST time step.  The padding
+                                 lengths that accompany the input are ignored (`x = x[0]`).
+  MLP(indim, hiddim, outdim)     fc -> ReLU -> fc2
+  Concat                         torch.cat(..., dim=1)
+  MMDL(encoders, fusion, head)   head(fusion([enc_i([x_i, len_i])]))          (Supervised_Learning.py:16-51 — vendored)
+
+and, from the reference's own file, DynMMNetV2 (affect_dyn.py:107-175: expert 1 = text Transformer + MLP head,
+expert 2 = 3-modality late-fusion MMDL, gate = Transformer(409, 10) + Linear(10, 2), DiffSoftmax, convex blend,
+regulariser mean(w[:, 1])) and DynMMNet (affect_dyn.py:31-104: three uni-modal experts, 3-way gate).
+
+Modules are parameter containers with torch's own state_dict keys (`conv.weight`, `transformer.layers.N.self_attn.
+in_proj_weight`, ...), so `expert.state_dict()` of a trained MultiBench module loads with load_state_dict.  Dropout
+(p = 0.1 inside nn.TransformerEncoderLayer while training) is NOT applied by the HIP path: outputs equal the
+reference's eval-mode arithmetic, in training as well.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops_seq as S
+
+FEATURES = {'visual': 35, 'audio': 74, 'text': 300}      # CMU-MOSEI (affect/count_flop.py:52)
+
+
+def encoder_layer(h, layer, heads):
+    """nn.TransformerEncoderLayer.forward (post-norm): h [B, D, T]."""
+    sa = layer.self_attn
+    qkv = S.linear_bdt(h, sa.in_proj_weight, sa.in_proj_bias)
+    a = S.mha_core(qkv, heads)
+    o = S.linear_bdt(a, sa.out_proj.weight, sa.out_proj.bias)
+    h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h)
+    f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu')
+    f = S.linear_bdt(f, layer.linear2.weight, layer.linear2.bias)
+    return S.layernorm_bdt(f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, residual=h1)
+
+
+class Transformer(nn.Module):
+    def __init__(self, n_features, dim, nhead=5, num_layers=5, dim_feedforward=2048):
+        super().__init__()
+        self.embed_dim, self.nhead = dim, nhead
+        self.conv = nn.Conv1d(n_features, dim, kernel_size=1, padding=0, bias=False)
+        layer = nn.TransformerEncoderLayer(d_model=dim, nhead=nhead, dim_feedforward=dim_feedforward)
+        self.transformer = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
+
+    def forward(self, x):
+        if isinstance(x, (list, tuple)):
+            x = x[0]                                            # [x, lengths]: the lengths are ignored
+        h = S.linear_bdt(x.permute(0, 2, 1).contiguous(), self.conv.weight)      # [B, dim, T]
+        for layer in self.transformer.layers:
+            h = encoder_layer(h, layer, self.nhead)
+        return h[:, :, -1].contiguous()                         # `self.transformer(x)[-1]`: the last time step
+
+
+class MLP(nn.Module):
+    def __init__(self, indim, hiddim, outdim):
+        super().__init__()
+        self.fc = nn.Linear(indim, hiddim)
+        self.fc2 = nn.Linear(hiddim, outdim)
+
+    def forward(self, x):
+        return S.linear_bdt(S.linear_bdt(x, self.fc.weight, self.fc.bias, act='relu'), self.fc2.weight, self.fc2.bias)
+
+
+class Concat(nn.Module):
+    def forward(self, modalities):
+        return torch.cat([m.flatten(1) for m in modalities], dim=1)
+
+
+class MMDL(nn.Module):
+    """Supervised_Learning.py:16-51 with has_padding=True and tensor-valued encoders."""
+
+    def __init__(self, encoders, fusion, head, has_padding=True):
+        super().__init__()
+        self.encoders = nn.ModuleList(encoders)
+        self.fuse, self.head, self.has_padding = fusion, head, has_padding
+
+    def forward(self, inputs):
+        if self.has_padding:
+            outs = [enc([inputs[0][i], inputs[1][i]]) for i, enc in enumerate(self.encoders)]
+        else:
+            outs = [enc(inputs[i]) for i, enc in enumerate(self.encoders)]
+        return self.head(self.fuse(outs))
+
+
+def late_fusion_transformer():
+    """affect_mm.py:61-66 (`--fusion 3`, saved as lf_tran.pt): the second expert of DynMMNetV2."""
+    return MMDL([Transformer(35, 60), Transformer(74, 120), Transformer(300, 120)], Concat(), MLP(300, 128, 1))
+
+
+class _GatedMixture(nn.Module):
+    def _init_gate(self, branch_num, temp, hard_gate):
+        self.branch_num = branch_num
+        self.gate = nn.Sequential(Transformer(409, 10), nn.Linear(10, branch_num))       # affect_dyn.py:41,120
+        self.temp, self.hard_gate = temp, hard_gate
+        self.weight_list = torch.Tensor()
+        self.store_weight = False
+        self.infer_mode = 0
+
+    @staticmethod
+    def freeze_branch(m):
+        for p in m.parameters():
+            p.requires_grad = False
+
+    def reset_weight(self):
+        self.weight_list = torch.Tensor()
+        self.store_weight = True
+
+    def cal_flop(self):
+        tmp = torch.mean(self.weight_list, dim=0)
+        total = (self.flop * tmp).sum()
+        print(f'Total Flops {total.item():.2f}M')
+        return total.item()
+
+    def gate_logits(self, inputs):
+        x = torch.cat(inputs[0], dim=2)                                                   # [B, T, 409]
+        return S.linear_bdt(self.gate[0]([x, inputs[1][0]]), self.gate[1].weight, self.gate[1].bias)
+
+    def _mix(self, logits, preds):
+        if self.infer_mode > 0:
+            return preds[self.infer_mode - 1], 0
+        if self.infer_mode == -1:                       # uniform weights (affect_dyn.py:161-162)
+            logits = torch.zeros_like(logits)
+        out, aux, weight = S.moe_blend(logits, preds, self.temp, self.hard_gate and self.infer_mode != -1)
+        if self.store_weight:
+            self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
+        return out, aux
+
+
+class DynMMNetV2(_GatedMixture):
+    """affect_dyn.py:107-175.  The reference loads pickled experts (`torch.load(model_name_list[i])`); here they are
+    constructed (random init) and filled with load_state_dict."""
+
+    def __init__(self, temp=1.0, hard_gate=False, freeze=False, model_name_list=None):
+        super().__init__()
+        self.text_encoder = Transformer(300, 120)            # affect_uni.py:68-73 (`--enc transformer`, text)
+        self.text_head = MLP(120, 64, 1)
+        self.branch2 = late_fusion_transformer()
+        if model_name_list:
+            raise NotImplementedError('pickled MultiBench modules cannot be loaded without MultiBench; export their '
+                                      'state_dict and use load_state_dict')
+        if freeze:
+            for m in (self.text_encoder, self.text_head, self.branch2):
+                self.freeze_branch(m)
+        self._init_gate(2, temp, hard_gate)
+        self.flop = torch.Tensor([135.13226, 320.03205])     # affect_dyn.py:126
+
+    def experts(self, inputs):
+        return [self.text_head(self.text_encoder([inputs[0][2], inputs[1][2]])), self.branch2(inputs)]
+
+    def forward(self, inputs):
+        return self._mix(self.gate_logits(inputs), self.experts(inputs))
+
+    def weight_stat(self):
+        tmp = torch.mean(self.weight_list, dim=0)
+        print(f'mean branch weight {tmp[0].item():.4f}, {tmp[1].item():.4f}')
+        self.store_weight = False
+        return tmp[1].item()
+
+
+class DynMMNet(_GatedMixture):
+    """affect_dyn.py:31-104 (`forward2`): three uni-modal experts (visual, audio, text), 3-way gate."""
+
+    def __init__(self, temp=1.0, hard_gate=False, freeze=True):
+        super().__init__()
+        self.encoders = nn.ModuleList([Transformer(FEATURES[m], 120) for m in ('visual', 'audio', 'text')])
+        self.heads = nn.ModuleList([MLP(120, 64, 1) for _ in range(3)])
+        if freeze:
+            self.freeze_branch(self.encoders)
+            self.freeze_branch(self.heads)
+        self._init_gate(3, temp, hard_gate)
+
+    def experts(self, inputs):
+        return [self.heads[i](self.encoders[i]([inputs[0][i], inputs[1][i]])) for i in range(3)]
+
+    def forward(self, inputs):
+        return self._mix(self.gate_logits(inputs), self.experts(inputs))
+
+
+class AffectTrainStep:
+    """One iteration of Supervised_Learning.train's loop (:104-144) for a DynMM mixture (`moe_model`,
+    additional_loss=True): forward, L1 objective + lossw * gate regulariser, backward, clip_grad_norm_(8), AdamW —
+    flat parameter / gradient / moment buffers, loss + backward seeds + clip coefficient computed on the device."""
+
+    def __init__(self, model, lr=1e-6, weight_decay=1e-4, lossw=0.0, clip_val=8.0):
+        from .. import engine
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.flatp = engine.FlatParameters(params)
+        self.flat_g = torch.zeros_like(self.flatp.flat)
+        for p in params:
+            lo, hi = self.flatp.span[id(p)]
+            p.grad = self.flat_g[lo:hi].view_as(p)
+        self.opt = engine.Adam(self.flatp, self.flat_g, lr, weight_decay=weight_decay, decoupled=True)   # AdamW
+        self.lossw, self.clip_val = float(lossw), float(clip_val)
+        self.last = None
+
+    def __call__(self, inputs, target):
+        m = self.model
+        self.flat_g.zero_()
+        logits = m.gate_logits(inputs)
+        preds = m.experts(inputs)
+        self.last = S.moe_loss_backward(logits, preds, target, m.temp, m.hard_gate, self.lossw)
+        nc = S.clip_grad_norm(self.flat_g, self.clip_val)
+        self.opt.grad_scale_dev = nc[1:2]
+        self.opt.step(None, self.last['total'])
+        self.last['grad_norm'] = nc[0:1]
+        return self.last

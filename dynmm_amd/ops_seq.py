@@ -1,0 +1,171 @@
+"""autograd shells for the modality-level DynMM path (ModalityDynMM/affect/affect_dyn.py, BASELINE configs[4]).
+
+Activations are [B, D, T] fp32 (the layout the reference feeds its Conv1d after `x.permute([0, 2, 1])`); every Linear
+/ Conv1d(k=1) is `linear_bdt` = the implicit-GEMM MFMA convolution of ops.conv2d with H = 1, W = T.  The kernels
+added for this path live in csrc/seq.hip.  As everywhere in dynmm_amd there is no CPU / eager fallback.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+from . import ops
+from .ops import _chk, _grad_dst, _grads_enqueued, _lib, _p, _ptr_array, _stream
+
+
+def linear_bdt(x, weight, bias=None, act=None):
+    """act(W x + b) over the channel axis of x [B, Ci, T] (or [B, Ci]): weight [Co, Ci] (nn.Linear,
+    in_proj_weight) or [Co, Ci, 1] (nn.Conv1d)."""
+    squeeze = x.dim() == 2
+    x4 = x.reshape(x.shape[0], x.shape[1], 1, -1) if not squeeze else x.reshape(x.shape[0], x.shape[1], 1, 1)
+    w4 = weight.reshape(weight.shape[0], weight.shape[1], 1, 1)
+    y = ops.conv2d(x4, w4, bias, 1, 0, act)
+    return y.reshape(y.shape[0], y.shape[1]) if squeeze else y.reshape(y.shape[0], y.shape[1], -1)
+
+
+class _LayerNormBDT(Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        lib = _lib()
+        x, res, gamma, beta = _chk(x, 'x'), _chk(res, 'res'), _chk(gamma, 'gamma'), _chk(beta, 'beta')
+        B, D, T = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(B * T, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        L.check(lib.dynmm_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), B, D, T,
+                                        float(eps), _stream()), 'layernorm_fwd')
+        ctx.save_for_backward(x, res, gamma, mean, rstd)
+        ctx.g_param, ctx.b_param = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        x, res, gamma, mean, rstd = ctx.saved_tensors
+        g = _chk(g, 'grad')
+        B, D, T = x.shape
+        need_dx = ctx.needs_input_grad[0] or (res is not None and ctx.needs_input_grad[1])
+        dx = torch.empty_like(x) if need_dx else None
+        dg = dg_ret = db = db_ret = None
+        if ctx.needs_input_grad[2]:
+            dg, dg_ret = _grad_dst(ctx.g_param)
+            db, db_ret = _grad_dst(ctx.b_param)
+        L.check(lib.dynmm_layernorm_bwd(_p(g), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db),
+                                        B, D, T, _stream()), 'layernorm_bwd')
+        _grads_enqueued()
+        return (dx if ctx.needs_input_grad[0] else None), (dx if (res is not None and ctx.needs_input_grad[1]) else None), \
+            dg_ret, db_ret, None
+
+
+def layernorm_bdt(x, gamma, beta, eps=1e-5, residual=None):
+    """LayerNorm over D of (x + residual), x [B, D, T]."""
+    return _LayerNormBDT.apply(x, residual, gamma, beta, eps)
+
+
+class _MHACore(Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        lib = _lib()
+        qkv = _chk(qkv, 'qkv')
+        B, D3, T = qkv.shape
+        D = D3 // 3
+        out = torch.empty((B, D, T), device=qkv.device, dtype=torch.float32)
+        probs = torch.empty((B * heads, T, T), device=qkv.device, dtype=torch.float32)
+        L.check(lib.dynmm_mha_fwd(_p(qkv), _p(out), _p(probs), B, D, T, heads, _stream()), 'mha_fwd')
+        ctx.save_for_backward(qkv, probs)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        qkv, probs = ctx.saved_tensors
+        g = _chk(g, 'grad')
+        B, D3, T = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        L.check(lib.dynmm_mha_bwd(_p(g), _p(qkv), _p(probs), _p(dqkv), B, D3 // 3, T, ctx.heads, _stream()), 'mha_bwd')
+        return dqkv, None
+
+
+def mha_core(qkv, heads):
+    """softmax(q k^T / sqrt(dh)) v per head for qkv [B, 3D, T] (q | k | v along channels) -> [B, D, T]."""
+    return _MHACore.apply(qkv, heads)
+
+
+class _MoEBlend(Function):
+    """out[B,1] = sum_k w_k pred_k, w = DiffSoftmax(logits/temp, hard); aux = mean w[:, K-1]  (affect_dyn.py:152-165)."""
+
+    @staticmethod
+    def forward(ctx, logits, temp, hard, *preds):
+        lib = _lib()
+        logits = _chk(logits, 'logits')
+        preds = [_chk(p.reshape(-1), 'pred') for p in preds]
+        B, K = logits.shape
+        f32 = dict(device=logits.device, dtype=torch.float32)
+        out, weight, scal = torch.empty(B, **f32), torch.empty((B, K), **f32), torch.empty(3, **f32)
+        L.check(lib.dynmm_moe_head(_p(logits), _ptr_array(preds), K, None, float(temp), int(bool(hard)), 0.0, _p(out),
+                                   _p(weight), _p(scal), None, None, B, _stream()), 'moe_head')
+        ctx.save_for_backward(logits, weight, *preds)
+        ctx.temp = float(temp)
+        ctx.mark_non_differentiable(weight)
+        return out.reshape(B, 1), scal[1], weight
+
+    @staticmethod
+    def backward(ctx, d_out, d_aux, _dw):
+        lib = _lib()
+        logits, weight = ctx.saved_tensors[:2]
+        preds = list(ctx.saved_tensors[2:])
+        B, K = logits.shape
+        f32 = dict(device=logits.device, dtype=torch.float32)
+        d_out = None if d_out is None else _chk(d_out.reshape(-1), 'd_out')
+        d_aux = None if d_aux is None else _chk(d_aux.reshape(1), 'd_aux')
+        dps = [torch.empty(B, **f32) for _ in preds]
+        dl = torch.empty((B, K), **f32)
+        L.check(lib.dynmm_moe_blend_bwd(_p(d_out), _p(d_aux), _p(logits), _ptr_array(preds), K, _p(weight), ctx.temp,
+                                        _ptr_array(dps), _p(dl), B, _stream()), 'moe_blend_bwd')
+        return (dl, None, None, *[d.reshape(B, 1) for d in dps])
+
+
+def moe_blend(logits, preds, temp=1.0, hard=False):
+    """(out [B,1], aux scalar, weight [B,K]) — the gated mixture of the experts' predictions."""
+    return _MoEBlend.apply(logits, temp, hard, *preds)
+
+
+def moe_loss_backward(logits, preds, target, temp, hard, reg):
+    """Supervised_Learning.py:120-141 for a DynMM mixture, on the device: blend, L1 loss, loss1 + reg * aux, and the
+    backward pass seeded straight from the kernel (no PyTorch arithmetic kernels).  Returns
+    {'out': [B,1], 'weight': [B,K], 'loss1', 'aux', 'total'}."""
+    lib = _lib()
+    logits = _chk(logits, 'logits')
+    flat = [_chk(p.reshape(-1), 'pred') for p in preds]
+    tgt = _chk(target.reshape(-1).float(), 'target')
+    B, K = logits.shape
+    f32 = dict(device=logits.device, dtype=torch.float32)
+    out, weight, scal = torch.empty(B, **f32), torch.empty((B, K), **f32), torch.empty(3, **f32)
+    dps = [torch.empty(B, **f32) if p.requires_grad else None for p in preds]
+    dl = torch.empty((B, K), **f32)
+    arr = (C.c_void_p * K)(*[(None if d is None else d.data_ptr()) for d in dps])
+    L.check(lib.dynmm_moe_head(_p(logits.detach()), _ptr_array(flat), K, _p(tgt), float(temp), int(bool(hard)), float(reg),
+                               _p(out), _p(weight), _p(scal), arr, _p(dl), B, _stream()), 'moe_head')
+    roots, grads = [], []
+    for p, d in zip(preds, dps):
+        if d is not None:
+            roots.append(p)
+            grads.append(d.reshape(p.shape))
+    if logits.requires_grad:
+        roots.append(logits)
+        grads.append(dl)
+    if roots:
+        torch.autograd.backward(roots, grads)
+    return {'out': out.reshape(B, 1), 'weight': weight, 'loss1': scal[0:1], 'aux': scal[1:2], 'total': scal[2:3]}
+
+
+def clip_grad_norm(flat_grad, max_norm):
+    """(norm, coef) device tensor [2]: coef = min(1, max_norm / (norm + 1e-6)), torch.nn.utils.clip_grad_norm_."""
+    lib = _lib()
+    ws = torch.empty(lib.dynmm_clip_grad_norm_workspace_bytes() // 8, device=flat_grad.device, dtype=torch.float64)
+    out = torch.empty(2, device=flat_grad.device, dtype=torch.float32)
+    L.check(lib.dynmm_clip_grad_norm(_p(flat_grad), C.c_size_t(flat_grad.numel()), float(max_norm), ws.data_ptr(), _p(out),
+                                     _stream()), 'clip_grad_norm')
+    return out

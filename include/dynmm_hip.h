@@ -307,7 +307,40 @@ int dynmm_sgd_nesterov(float* p, const float* g, float* buf, size_t lo, size_t h
                        const int* step, void* stream);
 int dynmm_adam(float* p, const float* g, float* m, float* v, size_t lo, size_t hi, const float* hyper,
                const int* step, float weight_decay, float grad_scale, const float* loss, int* nan_flag,
+               int decoupled /* != 0: AdamW, p *= 1 - lr*wd */, const float* grad_scale_dev /* optional */,
                void* stream);
+
+/* ================= modality-level DynMM (ModalityDynMM/affect/affect_dyn.py, BASELINE configs[4]) =================
+ * Activations are [B, D, T] (the layout the reference feeds its Conv1d after x.permute([0,2,1])); every Linear /
+ * Conv1d(k=1) is dynmm_conv2d_* with H = 1, W = T.  PARITY UNPINNED: the experts are MultiBench modules
+ * (unimodals.common_models.Transformer / MLP, fusions.common_fusions.Concat), which /root/reference does not
+ * contain and does not pin; these entry points follow torch.nn.TransformerEncoderLayer (post-norm, ReLU), which
+ * MultiBench's Transformer wraps. */
+/* LayerNorm over D per token (b,t) of s = x + res (res optional: the encoder layer's residual connection, fused):
+ * y = (s-mean)*rstd*gamma + beta; mean/rstd [B*T] saved for the backward; dx is also the gradient of res. */
+int dynmm_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int B, int D, int T, float eps, void* stream);
+int dynmm_layernorm_bwd(const float* g, const float* x, const float* res, const float* gamma, const float* mean,
+                        const float* rstd, float* dx, float* dgamma, float* dbeta, int B, int D, int T, void* stream);
+/* Self-attention core of nn.MultiheadAttention for T <= 64, D/heads <= 32: qkv [B,3D,T] -> out [B,D,T];
+ * probs [B*heads,T,T] saved for the backward (no dropout, no mask: the reference ignores the padding lengths). */
+int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads, void* stream);
+int dynmm_mha_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T, int heads,
+                  void* stream);
+/* Mixture head (affect_dyn.py:152-165) + loss (Supervised_Learning.py:135-136): w = DiffSoftmax(logits[B,K]/temp),
+ * out = sum_k w_k pred_k, aux = mean w[:,K-1], loss1 = mean |out - target|, scalars = {loss1, aux, loss1 + reg*aux};
+ * with target != NULL also the backward seeds d_preds[k][B] (optional per k) and d_logits[B,K]. K <= 4. */
+int dynmm_moe_head(const float* logits, const float* const* preds, int K, const float* target, float temp, int hard,
+                   float reg, float* out, float* weight, float* scalars, float* const* d_preds, float* d_logits, int B,
+                   void* stream);
+/* backward of the blend alone, for arbitrary upstream gradients d_out[B] / d_aux[1] (either may be NULL). */
+int dynmm_moe_blend_bwd(const float* d_out, const float* d_aux, const float* logits, const float* const* preds, int K,
+                        const float* weight, float temp, float* const* d_preds, float* d_logits, int B, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (Supervised_Learning.py:143) on a flat gradient buffer: norm_and_coef[0] = total
+ * L2 norm, [1] = min(1, max_norm / (norm + 1e-6)), to be passed to the optimizer as grad_scale_dev. */
+size_t dynmm_clip_grad_norm_workspace_bytes(void);
+int dynmm_clip_grad_norm(const float* flat_grad, size_t n, float max_norm, double* workspace, float* norm_and_coef,
+                         void* stream);
 
 #ifdef __cplusplus
 }
