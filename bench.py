@@ -386,7 +386,7 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     xs = [torch.randn(batch, T, f, generator=g).to(device) for f in (35, 74, 300)]
     inputs = [xs, [torch.full((batch,), T, dtype=torch.long)] * 3]
     y = torch.randn(batch, 1, generator=g).to(device)
-    step = A.AffectTrainStep(model, lr=1e-5, weight_decay=1e-4, lossw=0.1)
+    step = A.AffectTrainStep(model, lr=1e-5, weight_decay=1e-4, lossw=0.1, use_graph=True)
     res = {}
     for name, fn in (('train_step', lambda: step(inputs, y)), ('forward', None)):
         if fn is None:
@@ -402,6 +402,7 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     mmac = 135.13226 + 320.03205                      # affect_dyn.py:126 (thop MACs per sample, experts 1 + 2)
     res['forward']['model_tflops'] = round(res['forward']['value'] * 2 * mmac * 1e6 / 1e12, 2)
     res['train_step']['model_tflops'] = round(res['train_step']['value'] * 6 * mmac * 1e6 / 1e12, 2)
+    res['train_step']['launch'] = 'hipGraph replay'
     res['workload'] = ('configs[4] per GPU: ModalityDynMM DynMMNetV2 on CMU-MOSEI-shaped synthetic features '
                        f'(T={T}: visual 35, audio 74, text 300), batch {batch}; experts trainable (freeze=False); '
                        'PARITY UNPINNED (MultiBench not vendored)')

@@ -189,7 +189,7 @@ class AffectTrainStep:
     additional_loss=True): forward, L1 objective + lossw * gate regulariser, backward, clip_grad_norm_(8), AdamW —
     flat parameter / gradient / moment buffers, loss + backward seeds + clip coefficient computed on the device."""
 
-    def __init__(self, model, lr=1e-6, weight_decay=1e-4, lossw=0.0, clip_val=8.0):
+    def __init__(self, model, lr=1e-6, weight_decay=1e-4, lossw=0.0, clip_val=8.0, use_graph=False):
         from .. import engine
         self.model = model
         params = [p for p in model.parameters() if p.requires_grad]
@@ -201,8 +201,13 @@ class AffectTrainStep:
         self.opt = engine.Adam(self.flatp, self.flat_g, lr, weight_decay=weight_decay, decoupled=True)   # AdamW
         self.lossw, self.clip_val = float(lossw), float(clip_val)
         self.last = None
+        # The step is ~700 small launches (5-layer transformers on 50-token sequences): launch-bound when issued
+        # eagerly, so it can be replayed as ONE hipGraph (lr / step counter are device scalars; temp, hard_gate and
+        # the batch shape are frozen into a capture, which is re-made when they change).
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
 
-    def __call__(self, inputs, target):
+    def _body(self, inputs, target):
         m = self.model
         self.flat_g.zero_()
         logits = m.gate_logits(inputs)
@@ -212,4 +217,35 @@ class AffectTrainStep:
         self.opt.grad_scale_dev = nc[1:2]
         self.opt.step(None, self.last['total'])
         self.last['grad_norm'] = nc[0:1]
+
+    def __call__(self, inputs, target):
+        if not self.use_graph:
+            self._body(inputs, target)
+            return self.last
+        m = self.model
+        key = (tuple(tuple(x.shape) for x in inputs[0]), float(m.temp), bool(m.hard_gate))
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = [[x.clone() for x in inputs[0]], inputs[1]]
+            static_y = target.clone()
+            snap = [self.flatp.flat.clone()] + [t.clone() for t in self.opt.state_tensors()]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                    # warm-up outside capture (allocator, lazy init)
+                self._body(static_in, static_y)
+            torch.cuda.current_stream().wait_stream(side)
+            self.flatp.flat.copy_(snap[0])                   # undo the warm-up's parameter update
+            for t, c in zip(self.opt.state_tensors(), snap[1:]):
+                t.copy_(c)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._body(static_in, static_y)
+            entry = (graph, static_in, static_y, self.last)
+            self._graphs[key] = entry
+        graph, static_in, static_y, static_last = entry
+        for a, b in zip(static_in[0], inputs[0]):
+            a.copy_(b)
+        static_y.copy_(target)
+        graph.replay()
+        self.last = {k: v.clone() for k, v in static_last.items()}
         return self.last

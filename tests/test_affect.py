@@ -92,7 +92,7 @@ def test_affect_train_step_matches_torch_adamw():
     torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, two steps, frozen experts (the `--freeze` usage) and not."""
     from dynmm_amd.nn import affect as A
     from oracle import affect_oracle as O
-    for freeze in (True, False):
+    for freeze, use_graph in ((True, False), (False, False), (True, True)):
         ref = O.fill_(O.DynMMNetV2(1.0, False), seed=2)
         mine = A.DynMMNetV2(1.0, False, freeze=freeze)
         mine.load_state_dict(ref.state_dict())
@@ -102,7 +102,8 @@ def test_affect_train_step_matches_torch_adamw():
                 p.requires_grad = n.startswith('gate')
         params = [p for p in ref.parameters() if p.requires_grad]
         opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-2)
-        step = A.AffectTrainStep(mine, lr=1e-3, weight_decay=1e-2, lossw=0.2, clip_val=0.05 if freeze else 8.0)
+        step = A.AffectTrainStep(mine, lr=1e-3, weight_decay=1e-2, lossw=0.2, clip_val=0.05 if freeze else 8.0,
+                                 use_graph=use_graph)
         clip = 0.05 if freeze else 8.0
         for it in range(2):
             inputs, y = O.synth_batch(5, seed=10 + it)
