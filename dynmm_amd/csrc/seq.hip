@@ -20,28 +20,48 @@ constexpr int kSeqMaxDh = 32;
 // LayerNorm over D for every token (b, t) of x[B, D, T]; lanes walk consecutive t (coalesced), D is strided.
 // ---------------------------------------------------------------------------------------------------------------
 // `res` (optional): the layer normalises x + res (the residual connection of the encoder layer) without a
-// separate add pass.
+// separate add pass.  Workgroup = 16 tokens x 16 channel groups: lanes of a 16-lane row read consecutive t, the 16
+// groups split the channel loop (D = 10 ... 120: a thread touches <= 8 channels per pass) and meet in LDS.
+constexpr int kLnTok = 16, kLnGrp = 16;
+
+__device__ __forceinline__ float ln_group_sum(float v, float (*sh)[kLnTok], int tl, int grp) {
+    sh[grp][tl] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnGrp; ++k) s += sh[k][tl];       // fixed order: deterministic
+    __syncthreads();
+    return s;
+}
+
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int B, int D,
                                                      int T, float eps) {
-    const int tok = blockIdx.x * 256 + threadIdx.x;
-    if (tok >= B * T) return;
-    const int b = tok / T, t = tok - b * T;
+    __shared__ float sh[kLnGrp][kLnTok];
+    const int tl = threadIdx.x & (kLnTok - 1), grp = threadIdx.x / kLnTok;
+    const int tok = blockIdx.x * kLnTok + tl;
+    const bool ok = tok < B * T;
+    const int b = ok ? tok / T : 0, t = ok ? tok - b * T : 0;
     const size_t base = (size_t)b * D * T + t;
     float s = 0.f;
-    for (int c = 0; c < D; ++c) s += x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
-    const float mu = s / (float)D;
+    if (ok)
+        for (int c = grp; c < D; c += kLnGrp) s += x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
+    const float mu = ln_group_sum(s, sh, tl, grp) / (float)D;
     float v = 0.f;
-    for (int c = 0; c < D; ++c) {
-        const float d = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu;
-        v += d * d;
+    if (ok)
+        for (int c = grp; c < D; c += kLnGrp) {
+            const float d = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu;
+            v += d * d;
+        }
+    const float rs = rsqrtf(ln_group_sum(v, sh, tl, grp) / (float)D + eps);
+    if (!ok) return;
+    if (grp == 0) {
+        if (mean) mean[tok] = mu;
+        if (rstd) rstd[tok] = rs;
     }
-    const float rs = rsqrtf(v / (float)D + eps);
-    if (mean) mean[tok] = mu;
-    if (rstd) rstd[tok] = rs;
-    for (int c = 0; c < D; ++c) {
+    for (int c = grp; c < D; c += kLnGrp) {
         const float sv = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
         y[base + (size_t)c * T] = (sv - mu) * rs * gamma[c] + beta[c];
     }
@@ -53,21 +73,25 @@ __global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dx, int B,
                                                         int D, int T) {
-    const int tok = blockIdx.x * 256 + threadIdx.x;
-    if (tok >= B * T) return;
-    const int b = tok / T, t = tok - b * T;
+    __shared__ float sh[kLnGrp][kLnTok];
+    const int tl = threadIdx.x & (kLnTok - 1), grp = threadIdx.x / kLnTok;
+    const int tok = blockIdx.x * kLnTok + tl;
+    const bool ok = tok < B * T;
+    const int b = ok ? tok / T : 0, t = ok ? tok - b * T : 0;
     const size_t base = (size_t)b * D * T + t;
-    const float mu = mean[tok], rs = rstd[tok];
+    const float mu = ok ? mean[tok] : 0.f, rs = ok ? rstd[tok] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    for (int c = 0; c < D; ++c) {
-        const float gg = g[base + (size_t)c * T] * gamma[c];
-        const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
-        s1 += gg;
-        s2 += gg * xh;
-    }
-    s1 /= (float)D;
-    s2 /= (float)D;
-    for (int c = 0; c < D; ++c) {
+    if (ok)
+        for (int c = grp; c < D; c += kLnGrp) {
+            const float gg = g[base + (size_t)c * T] * gamma[c];
+            const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
+            s1 += gg;
+            s2 += gg * xh;
+        }
+    s1 = ln_group_sum(s1, sh, tl, grp) / (float)D;
+    s2 = ln_group_sum(s2, sh, tl, grp) / (float)D;
+    if (!ok) return;
+    for (int c = grp; c < D; c += kLnGrp) {
         const float gg = g[base + (size_t)c * T] * gamma[c];
         const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
         dx[base + (size_t)c * T] = rs * (gg - s1 - xh * s2);
@@ -103,104 +127,128 @@ __global__ void __launch_bounds__(256) ln_bwd_param_kernel(const float* __restri
 // dh = D / H.  One 64-lane wave per (b, h); lane i owns query i (forward) / query i and key i (backward).
 //   P = softmax_j( (q_i . k_j) / sqrt(dh) ),  out[c][i] = sum_j P[i][j] v[c][j]
 // ---------------------------------------------------------------------------------------------------------------
+// Lane i keeps its query (forward) / its query-side and key-side accumulators (backward) in REGISTERS (DH = compile-time
+// bound on the head dimension, dh <= DH), K / V / Q / dOut tiles sit in LDS and are read as wave-wide broadcasts
+// (every lane the same address) or conflict-free rows/columns of the [T][T+1] probability tiles: one LDS read per
+// FMA instead of two, and no dependent-latency chain per lane (the first version, with everything in LDS at ~2.5
+// waves per CU, was bound by LDS latency: 36 / 88 us forward / backward per launch for B = 128).
+template <int DH>
 __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                      float* __restrict__ probs, int D, int T, int H) {
-    __shared__ float qs[kSeqMaxDh][kSeqMaxT], ks[kSeqMaxDh][kSeqMaxT], vs[kSeqMaxDh][kSeqMaxT];
+    __shared__ float ks[DH][kSeqMaxT], vs[DH][kSeqMaxT];
     __shared__ float ps[kSeqMaxT][kSeqMaxT + 1];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int dh = D / H;
     const int i = threadIdx.x;
+    const bool act = i < T;
     const float* base = qkv + (size_t)b * 3 * D * T;
-    for (int c = 0; c < dh; ++c) {
-        if (i < T) {
-            qs[c][i] = base[(size_t)(h * dh + c) * T + i];
+    const float scale = rsqrtf((float)dh);
+    float q[DH], o[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        q[c] = 0.f;
+        o[c] = 0.f;
+        if (c < dh && act) {
+            q[c] = base[(size_t)(h * dh + c) * T + i] * scale;          // torch scales q before q @ k^T
             ks[c][i] = base[(size_t)(D + h * dh + c) * T + i];
             vs[c][i] = base[(size_t)(2 * D + h * dh + c) * T + i];
         }
     }
     __syncthreads();
-    const float scale = rsqrtf((float)dh);
-    if (i < T) {
-        float mx = -INFINITY;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f;
-            for (int c = 0; c < dh; ++c) s += qs[c][i] * scale * ks[c][j];     // torch scales q before q @ k^T
-            ps[i][j] = s;
-            mx = fmaxf(mx, s);
-        }
-        float den = 0.f;
-        for (int j = 0; j < T; ++j) {
-            const float e = expf(ps[i][j] - mx);
-            ps[i][j] = e;
-            den += e;
-        }
-        const float inv = 1.f / den;
-        float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
-        for (int j = 0; j < T; ++j) {
-            const float p = ps[i][j] * inv;
-            ps[i][j] = p;
-            pg[j] = p;
-        }
-        float* ob = out + (size_t)b * D * T;
-        for (int c = 0; c < dh; ++c) {
-            float s = 0.f;
-            for (int j = 0; j < T; ++j) s += ps[i][j] * vs[c][j];
-            ob[(size_t)(h * dh + c) * T + i] = s;
-        }
+    if (!act) return;
+    float mx = -INFINITY;
+    for (int j = 0; j < T; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c)
+            if (c < dh) s += q[c] * ks[c][j];
+        ps[i][j] = s;
+        mx = fmaxf(mx, s);
     }
+    float den = 0.f;
+    for (int j = 0; j < T; ++j) {
+        const float e = expf(ps[i][j] - mx);
+        ps[i][j] = e;
+        den += e;
+#pragma unroll
+        for (int c = 0; c < DH; ++c)
+            if (c < dh) o[c] += e * vs[c][j];
+    }
+    const float inv = 1.f / den;
+    float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
+    for (int j = 0; j < T; ++j) pg[j] = ps[i][j] * inv;
+    float* ob = out + (size_t)b * D * T;
+#pragma unroll
+    for (int c = 0; c < DH; ++c)
+        if (c < dh) ob[(size_t)(h * dh + c) * T + i] = o[c] * inv;
 }
 
+template <int DH>
 __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g, const float* __restrict__ qkv,
                                                      const float* __restrict__ probs, float* __restrict__ dqkv, int D,
                                                      int T, int H) {
-    __shared__ float qs[kSeqMaxDh][kSeqMaxT], ks[kSeqMaxDh][kSeqMaxT], vs[kSeqMaxDh][kSeqMaxT];
-    __shared__ float gs[kSeqMaxDh][kSeqMaxT];
+    __shared__ float qs[DH][kSeqMaxT], ks[DH][kSeqMaxT], vs[DH][kSeqMaxT], gs[DH][kSeqMaxT];
     __shared__ float ps[kSeqMaxT][kSeqMaxT + 1], ds[kSeqMaxT][kSeqMaxT + 1];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int dh = D / H;
     const int i = threadIdx.x;
+    const bool act = i < T;
     const float* base = qkv + (size_t)b * 3 * D * T;
     const float* gb = g + (size_t)b * D * T;
-    for (int c = 0; c < dh; ++c) {
-        if (i < T) {
+    float gq[DH];                                   // dOut column of query i
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        gq[c] = 0.f;
+        if (c < dh && act) {
             qs[c][i] = base[(size_t)(h * dh + c) * T + i];
             ks[c][i] = base[(size_t)(D + h * dh + c) * T + i];
             vs[c][i] = base[(size_t)(2 * D + h * dh + c) * T + i];
-            gs[c][i] = gb[(size_t)(h * dh + c) * T + i];
+            gq[c] = gb[(size_t)(h * dh + c) * T + i];
+            gs[c][i] = gq[c];
         }
     }
-    if (i < T) {
+    if (act) {
         const float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
         for (int j = 0; j < T; ++j) ps[i][j] = pg[j];
     }
     __syncthreads();
-    const float scale = rsqrtf((float)dh);
-    if (i < T) {
+    if (act) {
         // dP[i][j] = sum_c g[c][i] v[c][j];  dS = P * (dP - sum_j P dP)
         float dot = 0.f;
         for (int j = 0; j < T; ++j) {
-            float s = 0.f;
-            for (int c = 0; c < dh; ++c) s += gs[c][i] * vs[c][j];
-            ds[i][j] = s;
-            dot += ps[i][j] * s;
+            float sacc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c)
+                if (c < dh) sacc += gq[c] * vs[c][j];
+            ds[i][j] = sacc;
+            dot += ps[i][j] * sacc;
         }
         for (int j = 0; j < T; ++j) ds[i][j] = ps[i][j] * (ds[i][j] - dot);
     }
     __syncthreads();
-    if (i < T) {
-        float* db = dqkv + (size_t)b * 3 * D * T;
-        for (int c = 0; c < dh; ++c) {
-            float dq = 0.f, dk = 0.f, dv = 0.f;
-            for (int j = 0; j < T; ++j) {
-                dq += ds[i][j] * ks[c][j];          // query i
-                dk += ds[j][i] * qs[c][j];          // key i: sum over queries j
-                dv += ps[j][i] * gs[c][j];
+    if (!act) return;
+    const float scale = rsqrtf((float)dh);
+    float dq[DH], dk[DH], dv[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dq[c] = dk[c] = dv[c] = 0.f;
+    for (int j = 0; j < T; ++j) {
+        const float dsr = ds[i][j], dsc = ds[j][i], pc = ps[j][i];     // row (query i), columns (key i)
+#pragma unroll
+        for (int c = 0; c < DH; ++c)
+            if (c < dh) {
+                dq[c] += dsr * ks[c][j];
+                dk[c] += dsc * qs[c][j];
+                dv[c] += pc * gs[c][j];
             }
-            db[(size_t)(h * dh + c) * T + i] = dq * scale;
-            db[(size_t)(D + h * dh + c) * T + i] = dk * scale;
-            db[(size_t)(2 * D + h * dh + c) * T + i] = dv;
-        }
     }
+    float* db = dqkv + (size_t)b * 3 * D * T;
+#pragma unroll
+    for (int c = 0; c < DH; ++c)
+        if (c < dh) {
+            db[(size_t)(h * dh + c) * T + i] = dq[c] * scale;
+            db[(size_t)(D + h * dh + c) * T + i] = dk[c] * scale;
+            db[(size_t)(2 * D + h * dh + c) * T + i] = dv[c];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -326,7 +374,7 @@ extern "C" int dynmm_layernorm_fwd(const float* x, const float* res, const float
                                    float* mean, float* rstd, int B, int D, int T, float eps, void* stream) {
     (void)hipGetLastError();
     if (!x || !gamma || !beta || !y || B <= 0 || D <= 0 || T <= 0) return DYNMM_EINVAL;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, ST, x, res, gamma, beta, y, mean, rstd,
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, x, res, gamma, beta, y, mean, rstd,
                        B, D, T, eps);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
@@ -338,7 +386,7 @@ extern "C" int dynmm_layernorm_bwd(const float* g, const float* x, const float* 
     (void)hipGetLastError();
     if (!g || !x || !gamma || !mean || !rstd || B <= 0 || D <= 0 || T <= 0) return DYNMM_EINVAL;
     if (dx) {
-        hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, ST, g, x, res, gamma, mean, rstd,
+        hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, g, x, res, gamma, mean, rstd,
                            dx, B, D, T);
         DYNMM_LAUNCH_CHECK();
     }
@@ -353,7 +401,11 @@ extern "C" int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, 
     (void)hipGetLastError();
     if (!qkv || !out || !probs || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
     if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
+    const int dh = D / heads;
+    if (dh <= 8) hipLaunchKernelGGL(mha_fwd_kernel<8>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
+    else if (dh <= 16) hipLaunchKernelGGL(mha_fwd_kernel<16>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
+    else if (dh <= 24) hipLaunchKernelGGL(mha_fwd_kernel<24>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
+    else hipLaunchKernelGGL(mha_fwd_kernel<32>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -363,7 +415,11 @@ extern "C" int dynmm_mha_bwd(const float* g, const float* qkv, const float* prob
     (void)hipGetLastError();
     if (!g || !qkv || !probs || !dqkv || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
     if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
+    const int dh = D / heads;
+    if (dh <= 8) hipLaunchKernelGGL(mha_bwd_kernel<8>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
+    else if (dh <= 16) hipLaunchKernelGGL(mha_bwd_kernel<16>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
+    else if (dh <= 24) hipLaunchKernelGGL(mha_bwd_kernel<24>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
+    else hipLaunchKernelGGL(mha_bwd_kernel<32>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

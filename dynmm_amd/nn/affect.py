@@ -37,8 +37,9 @@ def encoder_layer(h, layer, heads):
     a = S.mha_core(qkv, heads)
     o = S.linear_bdt(a, sa.out_proj.weight, sa.out_proj.bias)
     h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h)
-    f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu')
-    f = S.linear_bdt(f, layer.linear2.weight, layer.linear2.bias)
+    # the ReLU backward of linear1 is applied in the input-gradient epilogue of linear2 (its only consumer)
+    f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu', defer_mask=True)
+    f = S.linear_bdt(f, layer.linear2.weight, layer.linear2.bias, mask_input=True)
     return S.layernorm_bdt(f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, residual=h1)
 
 
@@ -208,11 +209,14 @@ class AffectTrainStep:
         self._graphs = {}
 
     def _body(self, inputs, target):
+        from .. import engine, ops
         m = self.model
         self.flat_g.zero_()
-        logits = m.gate_logits(inputs)
-        preds = m.experts(inputs)
-        self.last = S.moe_loss_backward(logits, preds, target, m.temp, m.hard_gate, self.lossw)
+        with engine.direct_gradients(False):         # kernels write parameter gradients straight into flat_g
+            ops.touched_reset()
+            logits = m.gate_logits(inputs)
+            preds = m.experts(inputs)
+            self.last = S.moe_loss_backward(logits, preds, target, m.temp, m.hard_gate, self.lossw)
         nc = S.clip_grad_norm(self.flat_g, self.clip_val)
         self.opt.grad_scale_dev = nc[1:2]
         self.opt.step(None, self.last['total'])

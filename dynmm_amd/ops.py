@@ -235,7 +235,7 @@ class GradLink:
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, split_fwd):
+    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, split_fwd, w_owner=None):
         lib = _lib()
         st = _stream()
         x, x2, weight, bias = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight'), _chk(bias, 'bias')
@@ -281,7 +281,9 @@ class _Conv2d(Function):
         ctx.link = link
         ctx.save_for_backward(x, x2, wpd, y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
-        ctx.w_param, ctx.b_param = weight, bias
+        # w_owner: the nn.Parameter that `weight` is a reshaped view of (Linear / Conv1d weights used as 1x1 convs): its
+        # `.grad` has the same memory layout, so the in-place gradient protocol can write straight into it
+        ctx.w_param, ctx.b_param = (w_owner if w_owner is not None else weight), bias
         return y
 
     @staticmethod
@@ -342,11 +344,13 @@ class _Conv2d(Function):
                                                                           _p(dbias) if bias_in_wgrad else None, _p(ws), nbytes,
                                                                           C.byref(g), st)), 'conv2d_wgrad')
         _grads_enqueued(torch.cuda.current_stream(), ws_stream)
-        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None
+        if dw_ret is not None and tuple(dw_ret.shape) != ctx.wshape:
+            dw_ret = dw_ret.reshape(ctx.wshape)
+        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_input=False, defer_mask=False,
-           link=None):
+           link=None, w_owner=None):
     """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable.
 
     Backward-fusion hints (set by block code that knows the dataflow; results are unchanged):
@@ -354,7 +358,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_in
       mask_input : x is the output of a `defer_mask` op: the dgrad epilogue applies [x > 0];
       link       : GradLink whose residual-branch gradient is added in the dgrad epilogue."""
     return _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
-                         bool(defer_mask), link, _split_forward_allowed())
+                         bool(defer_mask), link, _split_forward_allowed(), w_owner)
 
 
 class _FanOut(Function):

@@ -14,14 +14,34 @@ from . import ops
 from .ops import _chk, _grad_dst, _grads_enqueued, _lib, _p, _ptr_array, _stream
 
 
-def linear_bdt(x, weight, bias=None, act=None):
+def linear_bdt(x, weight, bias=None, act=None, defer_mask=False, mask_input=False):
     """act(W x + b) over the channel axis of x [B, Ci, T] (or [B, Ci]): weight [Co, Ci] (nn.Linear,
-    in_proj_weight) or [Co, Ci, 1] (nn.Conv1d)."""
+    in_proj_weight) or [Co, Ci, 1] (nn.Conv1d).  defer_mask / mask_input: the ReLU backward of a `defer_mask` layer is
+    applied in the input-gradient epilogue of its single consumer (`mask_input`), as in the conv blocks."""
     squeeze = x.dim() == 2
     x4 = x.reshape(x.shape[0], x.shape[1], 1, -1) if not squeeze else x.reshape(x.shape[0], x.shape[1], 1, 1)
-    w4 = weight.reshape(weight.shape[0], weight.shape[1], 1, 1)
-    y = ops.conv2d(x4, w4, bias, 1, 0, act)
+    shape4 = (weight.shape[0], weight.shape[1], 1, 1)
+    train_w = weight.requires_grad and torch.is_grad_enabled()
+    # the parameter itself owns the gradient (same memory layout as its [Co, Ci, 1, 1] alias): the in-place gradient
+    # protocol writes straight into weight.grad, plain autograd gets it back through _Alias
+    w4 = _Alias.apply(weight, shape4) if train_w else weight.detach().view(shape4)
+    fuse = torch.is_grad_enabled() and x.requires_grad
+    y = ops.conv2d(x4, w4, bias, 1, 0, act, defer_mask=defer_mask and fuse, mask_input=mask_input and fuse,
+                   w_owner=weight if train_w else None)
     return y.reshape(y.shape[0], y.shape[1]) if squeeze else y.reshape(y.shape[0], y.shape[1], -1)
+
+
+class _Alias(Function):
+    """weight viewed as [Co, Ci, 1, 1]; the gradient comes back in the same memory layout."""
+
+    @staticmethod
+    def forward(ctx, w, shape):
+        ctx.shape = tuple(w.shape)
+        return w.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if g is None else g.reshape(ctx.shape)), None
 
 
 class _LayerNormBDT(Function):
