@@ -132,7 +132,9 @@ __global__ void __launch_bounds__(256) ln_bwd_param_kernel(const float* __restri
 // (every lane the same address) or conflict-free rows/columns of the [T][T+1] probability tiles: one LDS read per
 // FMA instead of two, and no dependent-latency chain per lane (the first version, with everything in LDS at ~2.5
 // waves per CU, was bound by LDS latency: 36 / 88 us forward / backward per launch for B = 128).
-template <int DH>
+// EXACT: dh == DH (no per-channel predicates inside the unrolled loops — with them every unrolled iteration is a
+// scalar branch and the kernel runs 3x slower); the non-exact instantiation serves any dh <= DH.
+template <int DH, bool EXACT>
 __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                      float* __restrict__ probs, int D, int T, int H) {
     __shared__ float ks[DH][kSeqMaxT], vs[DH][kSeqMaxT];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ q
     for (int c = 0; c < DH; ++c) {
         q[c] = 0.f;
         o[c] = 0.f;
-        if (c < dh && act) {
+        if ((EXACT || c < dh) && act) {
             q[c] = base[(size_t)(h * dh + c) * T + i] * scale;          // torch scales q before q @ k^T
             ks[c][i] = base[(size_t)(D + h * dh + c) * T + i];
             vs[c][i] = base[(size_t)(2 * D + h * dh + c) * T + i];
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ q
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < DH; ++c)
-            if (c < dh) s += q[c] * ks[c][j];
+            if (EXACT || c < dh) s += q[c] * ks[c][j];
         ps[i][j] = s;
         mx = fmaxf(mx, s);
     }
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ q
         den += e;
 #pragma unroll
         for (int c = 0; c < DH; ++c)
-            if (c < dh) o[c] += e * vs[c][j];
+            if (EXACT || c < dh) o[c] += e * vs[c][j];
     }
     const float inv = 1.f / den;
     float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
@@ -180,10 +182,10 @@ __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ q
     float* ob = out + (size_t)b * D * T;
 #pragma unroll
     for (int c = 0; c < DH; ++c)
-        if (c < dh) ob[(size_t)(h * dh + c) * T + i] = o[c] * inv;
+        if (EXACT || c < dh) ob[(size_t)(h * dh + c) * T + i] = o[c] * inv;
 }
 
-template <int DH>
+template <int DH, bool EXACT>
 __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g, const float* __restrict__ qkv,
                                                      const float* __restrict__ probs, float* __restrict__ dqkv, int D,
                                                      int T, int H) {
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g
 #pragma unroll
     for (int c = 0; c < DH; ++c) {
         gq[c] = 0.f;
-        if (c < dh && act) {
+        if ((EXACT || c < dh) && act) {
             qs[c][i] = base[(size_t)(h * dh + c) * T + i];
             ks[c][i] = base[(size_t)(D + h * dh + c) * T + i];
             vs[c][i] = base[(size_t)(2 * D + h * dh + c) * T + i];
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g
             float sacc = 0.f;
 #pragma unroll
             for (int c = 0; c < DH; ++c)
-                if (c < dh) sacc += gq[c] * vs[c][j];
+                if (EXACT || c < dh) sacc += gq[c] * vs[c][j];
             ds[i][j] = sacc;
             dot += ps[i][j] * sacc;
         }
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g
         const float dsr = ds[i][j], dsc = ds[j][i], pc = ps[j][i];     // row (query i), columns (key i)
 #pragma unroll
         for (int c = 0; c < DH; ++c)
-            if (c < dh) {
+            if (EXACT || c < dh) {
                 dq[c] += dsr * ks[c][j];
                 dk[c] += dsc * qs[c][j];
                 dv[c] += pc * gs[c][j];
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g
     float* db = dqkv + (size_t)b * 3 * D * T;
 #pragma unroll
     for (int c = 0; c < DH; ++c)
-        if (c < dh) {
+        if (EXACT || c < dh) {
             db[(size_t)(h * dh + c) * T + i] = dq[c] * scale;
             db[(size_t)(D + h * dh + c) * T + i] = dk[c] * scale;
             db[(size_t)(2 * D + h * dh + c) * T + i] = dv[c];
@@ -402,10 +404,12 @@ extern "C" int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, 
     if (!qkv || !out || !probs || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
     if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
     const int dh = D / heads;
-    if (dh <= 8) hipLaunchKernelGGL(mha_fwd_kernel<8>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
-    else if (dh <= 16) hipLaunchKernelGGL(mha_fwd_kernel<16>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
-    else if (dh <= 24) hipLaunchKernelGGL(mha_fwd_kernel<24>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
-    else hipLaunchKernelGGL(mha_fwd_kernel<32>, dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads);
+#define DYNMM_MHA_F(DH, EX) hipLaunchKernelGGL((mha_fwd_kernel<DH, EX>), dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads)
+    if (dh == 24) DYNMM_MHA_F(24, true);
+    else if (dh == 12) DYNMM_MHA_F(12, true);
+    else if (dh == 2) DYNMM_MHA_F(2, true);
+    else DYNMM_MHA_F(32, false);
+#undef DYNMM_MHA_F
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -416,10 +420,12 @@ extern "C" int dynmm_mha_bwd(const float* g, const float* qkv, const float* prob
     if (!g || !qkv || !probs || !dqkv || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
     if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
     const int dh = D / heads;
-    if (dh <= 8) hipLaunchKernelGGL(mha_bwd_kernel<8>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
-    else if (dh <= 16) hipLaunchKernelGGL(mha_bwd_kernel<16>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
-    else if (dh <= 24) hipLaunchKernelGGL(mha_bwd_kernel<24>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
-    else hipLaunchKernelGGL(mha_bwd_kernel<32>, dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads);
+#define DYNMM_MHA_B(DH, EX) hipLaunchKernelGGL((mha_bwd_kernel<DH, EX>), dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads)
+    if (dh == 24) DYNMM_MHA_B(24, true);
+    else if (dh == 12) DYNMM_MHA_B(12, true);
+    else if (dh == 2) DYNMM_MHA_B(2, true);
+    else DYNMM_MHA_B(32, false);
+#undef DYNMM_MHA_B
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -118,5 +118,6 @@ def test_affect_train_step_matches_torch_adamw():
             assert abs(res['grad_norm'].item() - norm_r.item()) < 2e-3 * max(norm_r.item(), 1e-3)
         sd_r, sd = ref.state_dict(), mine.state_dict()
         for k in sd_r:
-            assert _rel(sd[k], sd_r[k]) < 1e-3, (freeze, k)       # Adam: sign-like updates amplify rounding
+            # Adam's m / sqrt(v) is sign-like for near-zero gradients: compare against the size of the updates (2 steps of lr)
+            assert (sd[k].cpu() - sd_r[k]).abs().max().item() < 0.2 * 2 * 1e-3, (freeze, k)
         step.opt.check_finite()
