@@ -626,12 +626,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
     const int wave_co = wave / WAVES_K, wave_k = wave % WAVES_K;
     const int khalf = lane >> 5, l31 = lane & 31;
 
-    const int tile = blockIdx.x;
+    // XCD-aware order (1-D grid): consecutive logical ids stay on one XCD and walk the (co, k) tiles of ONE pixel
+    // split first, so the dy / x tiles of that split are fetched from HBM once per XCD and re-used out of its L2 by
+    // the other tiles (PMC, round 2: with blockIdx.x = tile the k-tiles of a split sat on different XCDs and every one
+    // of them re-fetched dy: 2 x FETCH_SIZE = 2.2 x the algorithmic bytes).
+    const int n_tiles = a.n_co_tiles * a.n_k_tiles;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lin % n_tiles;
     const int co0 = (tile % a.n_co_tiles) * TCO;
     const int k0 = (tile / a.n_co_tiles) * TK;
-    const int split = blockIdx.y;
+    const int split = lin / n_tiles;
 #ifdef DYNMM_TRACE
-    const size_t trace_row = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+    const size_t trace_row = (size_t)blockIdx.x * 6;
     if (g_trace && threadIdx.x == 0) { g_trace[trace_row] = wall_clock64(); g_trace[trace_row + 1] = g_trace[trace_row]; g_trace[trace_row + 4] = clock64(); }
 #endif
 
@@ -909,10 +915,12 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
     const int lane = t & 63, wave = t >> 6;
     const int wave_co = wave / WAVES_K, wave_k = wave % WAVES_K;
     const int khalf = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x;
+    const int n_tiles = a.n_co_tiles * a.n_k_tiles;          // XCD-aware order, see conv_wgrad_kernel
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lin % n_tiles;
     const int co0 = (tile % a.n_co_tiles) * TCO;
     const int k0 = (tile / a.n_co_tiles) * TK;
-    const int split = blockIdx.y;
+    const int split = lin / n_tiles;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
 
     // loader coordinates: lane q owns pixels [4q, 4q+4) of a step; rows rr and rr + 64
@@ -1327,7 +1335,9 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     a.K = g->KH * g->KW * g->Ci;
     a.n_co_tiles = p.n_co_tiles; a.n_k_tiles = p.n_k_tiles; a.steps_per_split = p.steps_per_split;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(p.n_co_tiles * p.n_k_tiles), (unsigned)p.splits);
+    static const int no_xcd = env_int("DYNMM_WGRAD_NO_XCD");
+    (void)no_xcd;
+    dim3 grid((unsigned)(p.n_co_tiles * p.n_k_tiles * p.splits));
     const bool dual = x2 != nullptr;
     const bool fast = !dual && (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
     a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
