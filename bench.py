@@ -35,9 +35,11 @@ from dynmm_amd.nn.net_skip import SkipESANet                # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 GFLOP_PER_IMG_FWD_BWD = {'P': 222.98, 'S': 300.8}   # BASELINE.md §2 (conv MACs x2, fwd+bwd)
 GFLOP_PER_IMG_FWD = {'P': 74.67, 'S': 100.62}
-TRAFFIC_NOTE = ('raw FETCH_SIZE+WRITE_SIZE per launch from profiles/pmc_dominant_kernel.json (separate --pmc passes); '
-                'the guide\'s x2 FETCH correction is calibrated for 16 B/lane streams only and this kernel gathers '
-                '4 B/lane, so the read side is uncalibrated: treat as a lower bound / for A-B ratios')
+TRAFFIC_NOTE = ('HBM bytes per launch from profiles/pmc_dominant_kernel.json (separate rocprofv3 --pmc passes for FETCH_SIZE '
+                'and WRITE_SIZE): fetch_factor x FETCH_SIZE + WRITE_SIZE, fetch_factor = 2 (the guide\'s gfx950 correction) '
+                'for kernels that stream 16 B/lane (conv_wgrad_v4), 1 = raw for the 4 B/lane gathers of the implicit-GEMM '
+                'kernels (uncalibrated width: lower bound).  For the split weight gradient the figure includes its slab '
+                'writes; the slab reduction kernel that follows is listed separately in the JSON.')
 
 
 def parse():
@@ -249,15 +251,20 @@ def kernel_timing(step_fn, model):
     agg, shapes = {}, {}
     for name, flops, e0, e1, shape in rec:
         ms = e0.elapsed_time(e1)
+        n_, ci, h, w, co, kh, kw, sh, sw = shape
+        # algorithmic bytes of the launch: every operand once (input + output/gradient tensor + weights), fp32
+        ho, wo = -(-h // sh), -(-w // sw)
+        abytes = 4.0 * (n_ * ci * h * w + n_ * co * ho * wo + co * ci * kh * kw)
         for d, key in ((agg, name), (shapes, (name, shape))):
-            a = d.setdefault(key, [0, 0.0, 0.0])
+            a = d.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += ms
             a[2] += flops
+            a[3] += abytes
     if os.environ.get('DYNMM_BENCH_SHAPES'):
         with open(os.environ['DYNMM_BENCH_SHAPES'], 'w') as f:
             f.write('kernel | N,Ci,H,W,Co,KH,KW,SH,SW | launches | total ms | avg us | TFLOP/s\n')
-            for (name, shape), (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            for (name, shape), (n, ms, fl, _) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 f.write(f'{name} | {shape} | {n} | {ms:.3f} | {1000 * ms / n:.1f} | {fl / (ms * 1e-3) / 1e12:.1f}\n')
     return agg
 
@@ -265,7 +272,7 @@ def kernel_timing(step_fn, model):
 def roofline_of(agg):
     if not agg:
         return None
-    name, (launches, ms, flops) = max(agg.items(), key=lambda kv: kv[1][1])
+    name, (launches, ms, flops, abytes) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
@@ -280,6 +287,7 @@ def roofline_of(agg):
             'kernel': name, 'launches_per_step': launches,
             'avg_launch_us': round(1000.0 * ms / launches, 2),
             'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
+            'algorithmic_bytes_per_launch': round(abytes / launches),
             'all_igemm_kernels': {k: {'launches': v[0], 'ms': round(v[1], 3),
                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                                   for k, v in sorted(agg.items())}}
