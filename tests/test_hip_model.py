@@ -458,3 +458,35 @@ def test_train_step_parity_at_benchmark_resolution():
           f'cosine {cos64:.6f} (fp32 oracle {cos_ref:.6f}); |g| ratio {(A.norm() / B64.norm()).item():.5f}')
     assert 1 - cos64 <= 2 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
     assert _rl2(A, B64) <= 3 * _rl2(B32, B64) + 1e-5
+
+
+def test_compacted_training_backward_matches_dense():
+    """K16 in training (`compact_train`, BASELINE configs[3]): with BatchNorm in eval mode (running statistics — the only
+    per-batch coupling of the depth path) the compacted forward AND backward must equal the dense ones up to fp32
+    rounding for every non-gate parameter: sorted-prefix stages, pass-through of the skipped samples, permutation and
+    un-permutation are all differentiable plumbing.  (Gate parameters differ by construction: a stage's straight-through
+    term comes only from the samples that run it — the documented approximation.)"""
+    h, w, n = 96, 128, 7
+    branches = [2, 4, 0, 1, 4, 3, 0]
+    rgb, depth = synth.synth_inputs(n, h, w, seed=11, device='cuda')
+    res = {}
+    for compact in (False, True):
+        m = hip_model('P_se', h, w, seed=4)
+        m.eval()                                   # BN: running statistics; gradients are still recorded below
+        m.hard_gate, m.temp = True, 0.7
+        m.branch_override = branches
+        m.compact_train = compact
+        out, lf = m(rgb, depth)
+        assert (m.last_stage_batch == [5, 4, 3, 2]) if compact else (m.last_stage_batch is None)
+        (out * Hh.grad_probe(tuple(out.shape), 'c').cuda()).mean().backward()
+        torch.cuda.synchronize()
+        res[compact] = (out.detach(), lf.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()
+                                                    if p.grad is not None})
+    (od, ld, gd), (oc, lc, gc) = res[False], res[True]
+    assert Hh.rel_err(oc.cpu(), od.cpu()) < 1e-5 and abs(lc.item() - ld.item()) < 1e-6
+    gmax = max(v.abs().max().item() for v in gd.values())
+    for k, g in gd.items():
+        if 'gate' in k or g.abs().max().item() < 1e-6 * gmax:
+            continue
+        assert _rl2(gc[k].cpu(), g.cpu()) < 2e-4, k
+    assert any('gate' in k and v.abs().max() > 0 for k, v in gc.items())      # the gate still trains
