@@ -336,6 +336,16 @@ def train_workload(args, device, rank, world, hard=False, branches='all4', compa
 
     def step():
         ts(rgb, depth, labels)
+
+    def body_only():
+        """forward + loss + backward of THIS rank only — no collective, no update: what the per-kernel timing pass runs
+        on rank 0 while the other ranks wait at the final barrier (a collective here would dead-lock the job)."""
+        ts.reducer.active = False
+        try:
+            ts._body(rgb, depth, [t if t.dtype == torch.uint8 else t.to(torch.uint8) for t in labels])
+        finally:
+            ts.reducer.active = True
+    step.body_only = body_only
     return step, ts, model
 
 
@@ -456,7 +466,7 @@ def main():
         if ts is not None:
             saved = (ts.multi_stream, getattr(model, 'dual_stream', False), ts.use_graph)
             ts.multi_stream, model.dual_stream, ts.use_graph = False, False, False
-            roofline = roofline_of(kernel_timing(step, model))
+            roofline = roofline_of(kernel_timing(step.body_only if world > 1 else step, model))
             ts.multi_stream, model.dual_stream, ts.use_graph = saved
         else:
             saved = getattr(model, 'dual_stream', False)

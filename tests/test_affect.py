@@ -119,6 +119,9 @@ def test_affect_train_step_matches_torch_adamw():
             assert abs(res['grad_norm'].item() - norm_r.item()) < 2e-3 * max(norm_r.item(), 1e-3)
         sd_r, sd = ref.state_dict(), mine.state_dict()
         for k in sd_r:
-            # Adam's m / sqrt(v) is sign-like for near-zero gradients: compare against the size of the updates (2 steps of lr)
-            assert (sd[k].cpu() - sd_r[k]).abs().max().item() < 0.2 * 2 * 1e-3, (freeze, k)
+            # Adam's first updates are lr * sign(g) whatever |g|: an element whose gradient is rounding noise can move the
+            # other way (2 update sizes apart).  Almost every element must agree to a fraction of an update, none may be
+            # further apart than the two updates allow.
+            d = (sd[k].cpu() - sd_r[k]).abs()
+            assert (d > 0.2 * 2 * 1e-3).float().mean().item() < 2e-3 and d.max().item() < 2.2 * 2 * 1e-3, (freeze, k)
         step.opt.check_finite()

@@ -305,3 +305,14 @@ def test_train_driver_adam_and_freeze(tmp_path):
     assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
     logs = train.train_main(common + ['--freeze', '--hip_graph', '--loss-ratio', '0.1'])
     assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
+
+
+@pytest.mark.gpu
+def test_train_driver_cli_default_encoder(tmp_path):
+    """The reference CLI's defaults (src/args.py:105,110-111,151): --encoder resnet50 (Bottleneck), decreasing decoder
+    channels [512, 256, 128], SE-add — the README commands as written (README.md:78-98 pass no --encoder)."""
+    from dynmm_amd import train
+    logs = train.train_main(['--dynamic', '--global-gate', '--no_imagenet_pretraining', '--dataset', 'synthetic',
+                             '--height', '96', '--width', '128', '--batch_size', '2', '--synthetic_samples', '4',
+                             '--epochs', '1', '--eval-every', '1', '--results_dir', str(tmp_path)])
+    assert len(logs) == 1 and np.isfinite(logs[0]['loss_train_total']) and 'mIoU_test' in logs[0]

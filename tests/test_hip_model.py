@@ -485,8 +485,14 @@ def test_compacted_training_backward_matches_dense():
     (od, ld, gd), (oc, lc, gc) = res[False], res[True]
     assert Hh.rel_err(oc.cpu(), od.cpu()) < 1e-5 and abs(lc.item() - ld.item()) < 1e-6
     gmax = max(v.abs().max().item() for v in gd.values())
+    # the gate's input is the pooled stem output, so the stems / stem fusion sit UPSTREAM of the approximated gate
+    # gradient; every other parameter (encoder stages, fusion, skips, context module, decoder) must agree
+    upstream = ('gate', 'encoder_rgb.conv1', 'encoder_rgb.bn1', 'encoder_depth.conv1', 'encoder_depth.bn1', 'se_layer0')
+    checked = 0
     for k, g in gd.items():
-        if 'gate' in k or g.abs().max().item() < 1e-6 * gmax:
+        if any(u in k for u in upstream) or g.abs().max().item() < 1e-6 * gmax:
             continue
         assert _rl2(gc[k].cpu(), g.cpu()) < 2e-4, k
+        checked += 1
+    assert checked > 400
     assert any('gate' in k and v.abs().max() > 0 for k, v in gc.items())      # the gate still trains
