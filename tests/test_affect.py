@@ -123,5 +123,10 @@ def test_affect_train_step_matches_torch_adamw():
             # other way (2 update sizes apart).  Almost every element must agree to a fraction of an update, none may be
             # further apart than the two updates allow.
             d = (sd[k].cpu() - sd_r[k]).abs()
+            if k.endswith('in_proj_bias'):
+                # the key bias of softmax attention has an analytically ZERO gradient (shift invariance): what Adam sees
+                # there is pure rounding noise on both sides
+                third = d.numel() // 3
+                d = torch.cat([d[:third], d[2 * third:]])
             assert (d > 0.2 * 2 * 1e-3).float().mean().item() < 2e-3 and d.max().item() < 2.2 * 2 * 1e-3, (freeze, k)
         step.opt.check_finite()
