@@ -11,6 +11,7 @@
 """
 import contextlib
 import ctypes as C
+import os
 
 import torch
 
@@ -184,7 +185,7 @@ class TrainStep:
 
     def __init__(self, model, class_weight, lr, momentum=0.9, weight_decay=1e-4, loss_ratio=0.0,
                  flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True, optimizer='SGD',
-                 overlap=True):
+                 overlap=True, fuse_tail=None):
         self.model = model
         self.cw = torch.as_tensor(class_weight, dtype=torch.float32, device=next(model.parameters()).device)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
@@ -203,6 +204,8 @@ class TrainStep:
             raise NotImplementedError(f'Currently only SGD and Adam as optimizers are supported. Got {optimizer}')
         # 3-stream schedule: RGB encoder | depth encoder | conv weight gradients (see nn/net.py, ops.py)
         self.multi_stream = bool(multi_stream)
+        # None: on unless DYNMM_NO_FUSED_TAIL is set (A/B switch for bench.py / tests)
+        self.fuse_tail = (os.environ.get('DYNMM_NO_FUSED_TAIL') is None) if fuse_tail is None else bool(fuse_tail)
         if hasattr(model, 'dual_stream'):
             model.dual_stream = self.multi_stream
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)
@@ -213,10 +216,17 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------------
     def _body(self, rgb, depth, targets):
+        dec = getattr(self.model, 'decoder', None) if self.fuse_tail else None
         with direct_gradients(self.multi_stream):
             ops.touched_reset()
             self.reducer.zero()
-            res = self.model(rgb, depth)
+            if dec is not None:
+                dec.defer_tail = True       # last up-sampling + full-resolution CE as one kernel pair (csrc/tail.hip)
+            try:
+                res = self.model(rgb, depth)
+            finally:
+                if dec is not None:
+                    dec.defer_tail = False
             if len(res) == 2 and isinstance(res[0], (tuple, list)):
                 outs, lf = res                                   # SkipGateESANet: ((out, out8, out16, out32), flop loss)
             else:

@@ -74,6 +74,9 @@ SIGNATURES = {
     'dynmm_gate_decide': (c_i, [c_f] * 5 + [c_i, c_f]),
     'dynmm_gate_head_bwd': (c_i, [c_f] * 9 + [c_i, c_i, c_fl, c_f]),
     'dynmm_ce2d_fwd': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_up2ce_fwd': (c_i, [c_f] * 7 + [c_i] * 5 + [c_f]),
+    'dynmm_up2ce_bwd_workspace_bytes': (c_sz, [c_i] * 4),
+    'dynmm_up2ce_bwd': (c_i, [c_f] * 11 + [c_i] * 4 + [c_f]),
     'dynmm_loss_head': (c_i, [c_f, c_i, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'dynmm_ce2d_bwd': (c_i, [c_f] * 5 + [c_i, c_i, c_i, c_f]),
     'dynmm_eval_confusion': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),

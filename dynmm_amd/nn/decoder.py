@@ -53,6 +53,9 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(cd[2], num_classes, 3, padding=1)
         self.upsample1 = Upsample(num_classes)
         self.upsample2 = Upsample(num_classes)
+        # engine.TrainStep sets this: in training the full-resolution logits feed the loss only, so the last
+        # up-sampling is fused with the cross entropy (ops.DeferredLogits, csrc/tail.hip) and never materialised
+        self.defer_tail = False
 
     def forward(self, enc_outs, unpermute=None):
         """unpermute = (index, inverse): the batch arrives in a permuted (branch-sorted, K16) order; the natural
@@ -66,7 +69,10 @@ class Decoder(nn.Module):
         out = ops.conv2d(out, c.weight, c.bias, 1, 1)
         if unpermute is not None:
             out = ops.batch_permute(out, *unpermute)
-        out = self.upsample2(self.upsample1(out))
+        if self.training and self.defer_tail and torch.is_grad_enabled():
+            out = ops.DeferredLogits(self.upsample1(out), self.upsample2.conv)
+        else:
+            out = self.upsample2(self.upsample1(out))
         if self.training:
             if unpermute is not None:
                 o8, o16, o32 = (ops.batch_permute(o, *unpermute) for o in (o8, o16, o32))

@@ -1094,6 +1094,41 @@ def cross_entropy_2d(logits, target, class_weight):
     return _CrossEntropy2d.apply(logits, t, class_weight)
 
 
+class DeferredLogits:
+    """Scale-0 output of a training step whose last up-sampling is left to the loss: `x` [N,C,H,W] is the input of
+    the decoder's final learned 2x up-sampling (model.py:404-410) and `conv` its depthwise 3x3.  Handed to
+    multi_scale_loss_backward, which runs the fused up-sampling + CE kernels (csrc/tail.hip) and never writes the
+    [N,C,2H,2W] logits; materialize() computes them with the ordinary kernel for callers that want to look."""
+
+    def __init__(self, x, conv):
+        self.x, self.conv = x, conv
+
+    @property
+    def shape(self):
+        N, Cc, H, W = self.x.shape
+        return torch.Size((N, Cc, 2 * H, 2 * W))
+
+    @property
+    def requires_grad(self):
+        return self.x.requires_grad or self.conv.weight.requires_grad
+
+    @property
+    def device(self):
+        return self.x.device
+
+    def materialize(self):
+        with torch.no_grad():
+            return upsample2x_dw3x3(self.x.detach(), self.conv.weight.detach(), self.conv.bias.detach())
+
+    detach = materialize          # what a caller inspecting the step's outputs asks for
+
+
+def _param_grad_commit(param, t, ret):
+    """plain-autograd fallback of the in-place gradient protocol for gradients produced outside a Function."""
+    if ret is not None and param.requires_grad:
+        param.grad = ret if param.grad is None else param.grad + ret
+
+
 def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio=0.0, budget=0.0):
     """train.py:313-323 for the HIP path, without a single PyTorch arithmetic kernel: the weighted CE of every
     scale (fp64 accumulators), total = sum_s CE_s + ratio * max(0, flop_loss - budget), and the backward pass of
@@ -1102,17 +1137,28 @@ def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio
     Returns {'losses': [S], 'loss_flop': (), 'total': [1]} (detached device tensors)."""
     lib = _lib()
     st = _stream()
-    outs = [_chk(o, 'logits') for o in outs]
+    outs = [o if isinstance(o, DeferredLogits) else _chk(o, 'logits') for o in outs]
     cw = _chk(class_weight, 'class_weight')
     S = len(outs)
     dev = outs[0].device
     acc = torch.zeros(2 * S, device=dev, dtype=torch.float64)
     tg = []
+    tail = None
     for s_, (o, t) in enumerate(zip(outs, targets)):
         t = t if t.dtype == torch.uint8 else t.to(torch.uint8)
         t = t if t.is_contiguous() else t.contiguous()
         tg.append(t)
         N, Cc, H, W = o.shape
+        if tuple(t.shape[-2:]) != (H, W) or t.numel() != N * H * W:
+            raise L.DynmmHipError(f'target {tuple(t.shape)} does not match logits {tuple(o.shape)}')
+        if isinstance(o, DeferredLogits):
+            xin = _chk(o.x.detach(), 'tail input')
+            wt, bs = _chk(o.conv.weight.detach(), 'w'), _chk(o.conv.bias.detach(), 'b')
+            lse = torch.empty((N, H, W), device=dev, dtype=torch.float32)
+            L.check(lib.dynmm_up2ce_fwd(_p(xin), _p(wt), _p(bs), t.data_ptr(), _p(cw), _p(lse), acc.data_ptr() + 16 * s_,
+                                        N, Cc, H // 2, W // 2, 1, st), 'up2ce_fwd')
+            tail = (s_, o, xin, wt, bs, lse)
+            continue
         L.check(lib.dynmm_ce2d_fwd(_p(o), _p(t), _p(cw), acc.data_ptr() + 16 * s_, N, Cc, H * W, 1, st), 'ce2d_fwd')
     f32 = dict(device=dev, dtype=torch.float32)
     losses, total, gscale = torch.empty(S, **f32), torch.empty(1, **f32), torch.empty(S, **f32)
@@ -1126,6 +1172,22 @@ def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio
         if not o.requires_grad:
             continue
         N, Cc, H, W = o.shape
+        if isinstance(o, DeferredLogits):
+            _, _, xin, wt, bs, lse = tail
+            dxin = torch.empty_like(xin)
+            dw, dw_ret = _grad_dst(o.conv.weight)
+            db, db_ret = _grad_dst(o.conv.bias)
+            nb = lib.dynmm_up2ce_bwd_workspace_bytes(N, Cc, H // 2, W // 2)
+            ws = torch.empty(max(nb // 4, 1), device=dev, dtype=torch.float32)
+            L.check(lib.dynmm_up2ce_bwd(_p(xin), _p(wt), _p(bs), t.data_ptr(), _p(cw), _p(lse), gscale.data_ptr() + 4 * s_,
+                                        _p(dxin), _p(dw), _p(db), _p(ws), N, Cc, H // 2, W // 2, st), 'up2ce_bwd')
+            _grads_enqueued()
+            _param_grad_commit(o.conv.weight, dw, dw_ret)
+            _param_grad_commit(o.conv.bias, db, db_ret)
+            if o.x.requires_grad:
+                roots.append(o.x)
+                grads.append(dxin)
+            continue
         dx = torch.empty_like(o)
         L.check(lib.dynmm_ce2d_bwd(_p(o), _p(t), _p(cw), gscale.data_ptr() + 4 * s_, _p(dx), N, Cc, H * W, st), 'ce2d_bwd')
         roots.append(o)

@@ -261,6 +261,18 @@ int dynmm_loss_head(const double* acc, int S, const float* flop_loss, float rati
 int dynmm_ce2d_bwd(const float* x, const unsigned char* target, const float* cw,
                    const float* gscale, float* dx, int N, int C, int HW, void* stream);
 
+/* ---- training tail: last learned 2x up-sampling (model.py:404-410) FUSED with the full-resolution weighted CE
+ * (src/utils.py:34-50).  x [N,C,H,W] is the input of the up-sampling (C <= 64), w [C,9] / b [C] its depthwise conv,
+ * target uint8 [N,2H,2W] (0 = void), cw [C].  The logits are never written: fwd adds this scale's (sum, wsum) to
+ * loss_sum_wsum and stores lse[N,2H,2W] (log-sum-exp per output pixel); bwd re-derives the logits and returns
+ * dx (gradient of x), dw [C,9], db [C] for d loss = gscale[0] * d(sum).  workspace >= *_workspace_bytes. */
+int dynmm_up2ce_fwd(const float* x, const float* w, const float* b, const unsigned char* target, const float* cw,
+                    float* lse, double* loss_sum_wsum, int N, int C, int H, int W, int acc_is_zero, void* stream);
+size_t dynmm_up2ce_bwd_workspace_bytes(int N, int C, int H, int W);
+int dynmm_up2ce_bwd(const float* x, const float* w, const float* b, const unsigned char* target, const float* cw,
+                    const float* lse, const float* gscale, float* dx, float* dw, float* db, float* workspace,
+                    int N, int C, int H, int W, void* stream);
+
 /* ---- eval post-processing + confusion matrix on device (eval.py:117-141, src/confusion_matrix.py:118-130;
  * SURVEY §8f-2): cm[(label-1)*C + argmax_c bilinear(logits)(label pixel)] += 1 for label > 0.
  * logits [N,C,H,W]; label uint8 [N,Ho,Wo] (0 = void); cm int64 [C*C], accumulated (caller zeroes). */

@@ -128,5 +128,7 @@ def test_affect_train_step_matches_torch_adamw():
                 # there is pure rounding noise on both sides
                 third = d.numel() // 3
                 d = torch.cat([d[:third], d[2 * third:]])
-            assert (d > 0.2 * 2 * 1e-3).float().mean().item() < 2e-3 and d.max().item() < 2.2 * 2 * 1e-3, (freeze, k)
+            # (small tensors: a single flipped element is allowed whatever the tensor's size)
+            n_far = int((d > 0.2 * 2 * 1e-3).sum().item())
+            assert n_far <= max(1, int(2e-3 * d.numel())) and d.max().item() < 2.2 * 2 * 1e-3, (freeze, k, n_far)
         step.opt.check_finite()

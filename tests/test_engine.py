@@ -316,3 +316,39 @@ def test_train_driver_cli_default_encoder(tmp_path):
                              '--height', '96', '--width', '128', '--batch_size', '2', '--synthetic_samples', '4',
                              '--epochs', '1', '--eval-every', '1', '--results_dir', str(tmp_path)])
     assert len(logs) == 1 and np.isfinite(logs[0]['loss_train_total']) and 'mIoU_test' in logs[0]
+
+
+@pytest.mark.gpu
+def test_fused_tail_step_equals_unfused_step():
+    """TrainStep with the last up-sampling fused into the loss (csrc/tail.hip) against the same step with the logits
+    materialised: same losses, same gradients (summation order only)."""
+    from dynmm_amd import engine
+    from tests.test_hip_model import hip_model
+    torch.manual_seed(0)
+    h, w, n = 96, 128, 3
+    rgb, depth = torch.randn(n, 3, h, w).cuda(), torch.randn(n, 1, h, w).cuda()
+    labels = [torch.randint(0, 41, (n, h // s, w // s), dtype=torch.uint8).cuda() for s in (1, 8, 16, 32)]
+    cw = np.linspace(0.5, 1.5, 40).astype(np.float32)
+    out = {}
+    for fused in (True, False):
+        m = hip_model('P_se', h, w, seed=3)
+        m.train()
+        m.temp, m.hard_gate = 1.0, False
+        step = engine.TrainStep(m, cw, lr=0.0, loss_ratio=1e-3, fuse_tail=fused)
+        step._body(rgb, depth, labels)
+        torch.cuda.synchronize()
+        assert m.decoder.defer_tail is False
+        out[fused] = (step.last['losses'].cpu(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    assert torch.allclose(out[True][0], out[False][0], rtol=2e-6, atol=2e-6)
+    # per tensor, relative to the tensor's own scale — but not below 1e-2 of the largest gradient of the model:
+    # conv biases in front of a batch norm have an analytically zero gradient (~1e-6 of rounding noise on both sides)
+    gmax = max(gb.abs().max().item() for gb in out[False][1].values())
+    worst = 0.0
+    for k, ga in out[True][1].items():
+        gb = out[False][1][k]
+        worst = max(worst, ((ga - gb).abs().max() / max(gb.abs().max().item(), 1e-2 * gmax)).item())
+    assert worst < 5e-4, worst
+    va = torch.cat([g.flatten() for g in out[True][1].values()]).double()
+    vb = torch.cat([g.flatten() for g in out[False][1].values()]).double()
+    assert abs(torch.nn.functional.cosine_similarity(va, vb, dim=0).item() - 1) < 1e-9
+    assert abs((va.norm() / vb.norm()).item() - 1) < 1e-5

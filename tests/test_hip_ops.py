@@ -435,3 +435,63 @@ def test_conv_gradients_are_run_to_run_reproducible(ops):
     for r in res[1:]:
         for a, bb in zip(res[0], r):
             assert torch.equal(a, bb)
+
+
+@pytest.mark.parametrize('shape', [(2, 40, 12, 16), (3, 40, 7, 9), (1, 5, 30, 70)])
+def test_fused_upsample_cross_entropy_tail(ops, shape):
+    """csrc/tail.hip: the decoder's last learned 2x up-sampling (model.py:404-410) fused with the weighted CE
+    (src/utils.py:34-50), logits never materialised — loss and the gradients of the up-sampling's input, weight and
+    bias against an fp64 torch restatement (nearest x2 -> depthwise 3x3 zero-pad -> CE), with void pixels, a second
+    (ordinary) scale so the per-scale seeds differ, and twice for bit-reproducibility."""
+    import torch.nn as nn
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(7 + H)
+    x = rnd(N, C, H, W, seed=1, scale=2.0)
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=C)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(C, 1, 3, 3, seed=2, scale=0.4))
+        conv.bias.copy_(rnd(C, seed=3, scale=0.3))
+    t0 = torch.randint(0, C + 1, (N, 2 * H, 2 * W), generator=g).to(torch.uint8)
+    t0[0, :3] = 0                                                  # a run of void pixels
+    x1 = rnd(N, C, 4, 5, seed=4)
+    t1 = torch.randint(0, C + 1, (N, 4, 5), generator=g).to(torch.uint8)
+    cw = torch.rand(C, generator=g) + 0.5
+
+    # fp64 restatement
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True)
+    x1d = x1.double().requires_grad_(True)
+    logits = F.conv2d(F.interpolate(xd, scale_factor=2, mode='nearest'), wd, bd, padding=1, groups=C)
+
+    def ce(lg, t):
+        tt = t.long() - 1
+        m = tt >= 0
+        l = F.cross_entropy(lg, tt.clamp_min(0), weight=cw.double(), reduction='none')
+        return (l * m).sum() / cw.double()[tt.clamp_min(0)][m].sum()
+    l0, l1 = ce(logits, t0), ce(x1d, t1)
+    (l0 + l1).backward()
+
+    conv = conv.cuda()
+    runs = []
+    for _ in range(2):
+        conv.zero_grad()
+        xg = x.cuda().requires_grad_(True)
+        x1g = x1.cuda().requires_grad_(True)
+        dl = ops.DeferredLogits(xg, conv)
+        assert tuple(dl.shape) == (N, C, 2 * H, 2 * W)
+        assert rel(dl.detach(), logits) < TOL
+        res = ops.multi_scale_loss_backward([dl, x1g], [t0.cuda(), t1.cuda()], cw.cuda())
+        runs.append((res['losses'].clone(), xg.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), x1g.grad.clone()))
+    losses, dx, dw, db, dx1 = runs[0]
+    assert abs(losses[0].item() - l0.item()) < 2e-5 * max(1.0, abs(l0.item()))
+    assert abs(losses[1].item() - l1.item()) < 2e-5 * max(1.0, abs(l1.item()))
+    assert abs(res['total'].item() - (l0 + l1).item()) < 4e-5 * max(1.0, (l0 + l1).item())
+    assert rel(dx, xd.grad) < GTOL
+    assert rel(dw, wd.grad) < GTOL
+    assert rel(db, bd.grad) < GTOL
+    assert rel(dx1, x1d.grad) < GTOL
+    # only the fp64 loss accumulators are atomic (their double sums round identically in any order up to 1 ulp of
+    # fp64, invisible in the fp32 seed): every gradient is bit-reproducible
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        assert torch.equal(a, b)
