@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_small.h"
 #include "vec.h"
 
 namespace dynmm {
@@ -1284,6 +1285,12 @@ extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp
     a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
     a.c_in_split = g->c_split; a.c_out_split = g->Co; a.act = act;
+    {
+        SmallConvArgs s{x, x2, wp_fwd, scale, shift, y, g->N, g->Ci, g->H, g->W, g->Co, g->Ho, g->Wo, g->KH, g->KW,
+                        g->SH, g->SW, g->PH, g->PW, g->c_split, round_k(g->Ci), (g->Co + 3) & ~3, act};
+        if (small_conv_fwd_eligible(s, residual)) return launch_small_conv_fwd(s, (hipStream_t)stream);
+        if (stem_conv_fwd_eligible(s, residual)) return launch_stem_conv_fwd(s, (hipStream_t)stream);
+    }
     return launch_igemm<false>(a, (hipStream_t)stream);
 }
 

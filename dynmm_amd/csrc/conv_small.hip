@@ -1,0 +1,336 @@
+// Direct (no MFMA) convolutions for the gate head's first conv (…globalgate.py:378-386: 128 -> 8 channels, 5x5,
+// stride 2, no padding, on the 120x160 stage-1 maps).  With 8 output channels an MFMA tile is 3/4 padding (the
+// implicit-GEMM kernel ran it at 11 TFLOP/s useful); on the vector ALUs — same fp32 FMA peak as the fp32 MFMA on
+// CDNA4 — nothing is padded: the filter taps are wave-uniform and live in SGPRs (s_load from the packed weight
+// buffer, one FMA operand straight from the scalar file), the input rows come from a wave-private LDS tile.
+//
+//   gate conv forward : a workgroup owns 4 x 80 output pixels of one image; its 4 waves split the INPUT channels
+//             (each wave runs Ci/4 of them, wave-synchronously: no barrier in the channel loop), a lane keeps
+//             8 channels x 5 pixels of accumulators; partial sums meet in LDS in a fixed order (bit-reproducible).
+//
+// The two stem convolutions (resnet.py:229: 3 / 1 -> 64 channels, 7x7, stride 2, pad 3, on the 480x640 inputs) get
+// an fp32-MFMA kernel of their own further down: K = Ci * 49 is too short and too ragged for the implicit-GEMM
+// loader (it ran at 42 TFLOP/s through the element-wise generic path).
+#include "common.h"
+#include "conv_small.h"
+#include <cstring>
+
+namespace dynmm {
+
+constexpr int kSP = 5;                // output pixels per lane (consecutive along W)
+constexpr int kSRows = 4;             // output rows per workgroup
+constexpr int kSColGroups = 16;       // lanes along W
+constexpr int kSCols = kSColGroups * kSP;      // 80 output columns per workgroup
+
+__device__ __forceinline__ float small_act(float v, int act) {
+    if (act == DYNMM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DYNMM_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+template <int KS, int S>
+__global__ void __launch_bounds__(256) conv_co8_fwd_kernel(const SmallConvArgs a) {
+    constexpr int IR = (kSRows - 1) * S + KS;          // input rows of a tile (11)
+    constexpr int IC = (kSCols - 1) * S + KS;          // input cols (163)
+    constexpr int TILE = IR * IC;
+    constexpr int NLD = (TILE + 63) / 64;              // staging loads per lane and channel
+    constexpr int XW = (kSP - 1) * S + KS;             // input columns one lane touches per row (13)
+    constexpr int RED = 4 * 8 * kSRows * kSCols;       // cross-wave reduction buffer (floats)
+    constexpr int LDSF = (4 * 2 * TILE > RED) ? 4 * 2 * TILE : RED;
+    __shared__ float lds[LDSF];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tw = (a.Wo + kSCols - 1) / kSCols, th = (a.Ho + kSRows - 1) / kSRows;
+    int b = blockIdx.x;
+    const int n = b / (th * tw);
+    b -= n * th * tw;
+    const int oh0 = (b / tw) * kSRows, ow0 = (b - (b / tw) * tw) * kSCols;
+    const int ih0 = oh0 * S, iw0 = ow0 * S;
+    const int r = lane >> 4, cg = lane & 15;           // the lane's output row / column group inside the tile
+
+    // staging geometry: element e = k*64 + lane of the flat [IR][IC] tile
+    int goff[NLD];
+    unsigned okmask = 0u;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = k * 64 + lane;
+        const int rr = e / IC, cc = e - rr * IC;
+        const bool ok = e < TILE && ih0 + rr < a.H && iw0 + cc < a.W;
+        goff[k] = ok ? (ih0 + rr) * a.W + iw0 + cc : 0;
+        okmask |= ok ? (1u << k) : 0u;
+    }
+    const int cpw = a.Ci / 4;                           // input channels per wave
+    const int c_begin = wave * cpw;
+    const int HW = a.H * a.W;
+    float* const tile0 = lds + wave * 2 * TILE;
+
+    auto plane = [&](int ci) -> const float* {
+        return ci < a.c_split ? a.x + ((size_t)n * a.c_split + ci) * HW
+                              : a.x2 + ((size_t)n * (a.Ci - a.c_split) + (ci - a.c_split)) * HW;
+    };
+    float st[NLD];
+    auto stage_load = [&](int ci) {
+        const float* p = plane(ci);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) st[k] = p[goff[k]];
+    };
+    auto stage_store = [&](float* t) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (k * 64 + lane < TILE) t[k * 64 + lane] = ((okmask >> k) & 1u) ? st[k] : 0.f;
+    };
+
+    float acc[8][kSP];
+#pragma unroll
+    for (int co = 0; co < 8; ++co)
+#pragma unroll
+        for (int p = 0; p < kSP; ++p) acc[co][p] = 0.f;
+
+    // wave-private tiles, wave-synchronous use: LDS executes one wave's operations in order, the fences only keep
+    // the compiler from moving a lane's reads across the (other lanes') writes
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    stage_load(c_begin);
+    stage_store(tile0);
+    wave_sync();
+    for (int i = 0; i < cpw; ++i) {
+        const int ci = c_begin + i;
+        const float* t = tile0 + (i & 1) * TILE;
+        if (i + 1 < cpw) stage_load(ci + 1);                       // in flight during this channel's arithmetic
+        const float* wci = a.wp + (size_t)ci * 8;                  // wp[(tap * CiR + ci) * 8 + co]
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+            const float* row = t + (S * r + kh) * IC + S * kSP * cg;
+            float xv[XW];
+#pragma unroll
+            for (int j = 0; j < XW; ++j) xv[j] = row[j];
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const float* wt = wci + (size_t)(kh * KS + kw) * a.CiR * 8;     // wave-uniform: 8 floats from SGPRs
+#pragma unroll
+                for (int co = 0; co < 8; ++co) {
+                    const float wv = wt[co];
+#pragma unroll
+                    for (int p = 0; p < kSP; ++p) acc[co][p] = fmaf(wv, xv[S * p + kw], acc[co][p]);
+                }
+            }
+        }
+        if (i + 1 < cpw) stage_store(tile0 + ((i + 1) & 1) * TILE);
+        wave_sync();
+    }
+    __syncthreads();                                                // staging tiles are dead: reuse as red[wave][co][r][col]
+#pragma unroll
+    for (int co = 0; co < 8; ++co)
+#pragma unroll
+        for (int p = 0; p < kSP; ++p)
+            lds[((wave * 8 + co) * kSRows + r) * kSCols + cg * kSP + p] = acc[co][p];
+    __syncthreads();
+    constexpr int PER = 8 * kSRows * kSCols;
+    for (int e = threadIdx.x; e < PER; e += 256) {
+        const int co = e / (kSRows * kSCols), rem = e - co * (kSRows * kSCols);
+        const int rr = rem / kSCols, cc = rem - rr * kSCols;
+        const int oh = oh0 + rr, ow = ow0 + cc;
+        if (co < a.Co && oh < a.Ho && ow < a.Wo) {
+            float v = ((lds[e] + lds[PER + e]) + lds[2 * PER + e]) + lds[3 * PER + e];
+            v = v * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
+            a.y[(((size_t)n * a.Co + co) * a.Ho + oh) * a.Wo + ow] = small_act(v, a.act);
+        }
+    }
+}
+
+// ---- stem: 1 or 3 input channels, 64 output channels, 7x7 stride 2 pad 3 — fp32 MFMA from an LDS patch ---------
+// GEMM view: out[co][pix] = sum_k W[co][k] * X[k][pix], k = (ci, kh, kw) with kw padded 7 -> 8 (a zero weight
+// column), so that the two k's of one v_mfma_f32_32x32x2_f32 step are always horizontal neighbours of the same
+// input row: lane (pixel l31, k-parity khalf) reads patch[base + khalf + compile-time offset] — stride-2 dwords over
+// the half-wave (even banks) and the other half on the odd banks: conflict-free without any im2col buffer.
+// A workgroup owns 64 channels x (4 rows x 64 cols) of one image: wave w = channel tile w & 1, output rows
+// 2 * (w >> 1) + {0, 1}, i.e. 1 channel tile x 4 pixel tiles of accumulators; its weight operand (84 / 28 values per
+// lane) lives in registers for the lifetime of the persistent workgroup.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CI>
+__global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(const SmallConvArgs a) {
+    constexpr int KS = 7, S = 2, PAD = 3, KW8 = 8;
+    constexpr int TRW = 4, TCW = 64;                   // output tile
+    constexpr int IR = (TRW - 1) * S + KS;             // 13 input rows
+    constexpr int ICP = (TCW - 1) * S + KW8 + 1;       // 135: 133 real columns + the padded tap's column (+1 spare)
+    constexpr int NSTEP = CI * KS * KW8 / 2;           // 84 / 28 MFMA steps (2 k's each)
+    constexpr int OP = TCW + 8;                        // output-chunk row pitch: rows cl and cl + 4 (the two half-waves) on disjoint banks
+    constexpr int OCH = 16 * OP;                       // floats of one output chunk (16 channels x 64 columns)
+    constexpr int PATCH = CI * IR * ICP > 4 * OCH ? CI * IR * ICP : 4 * OCH;
+    __shared__ __attribute__((aligned(16))) float patch[PATCH];
+
+    const int lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int mi = wave & 1, rp = wave >> 1;           // the wave's 32-channel tile and its pair of output rows
+    const int tw = (a.Wo + TCW - 1) / TCW, th = (a.Ho + TRW - 1) / TRW;
+    const int HW = a.H * a.W;
+    const int tiles = a.N * th * tw;
+
+    // persistent workgroups: the wave's weight operand (channel mi*32 + l31, k = 2*step + khalf) stays in registers
+    float areg[NSTEP];
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int ci = st / (KS * KW8 / 2), rem = st - ci * (KS * KW8 / 2);
+        const int kh = rem / (KW8 / 2), kp = rem - kh * (KW8 / 2);
+        const int kw = 2 * kp + khalf;
+        areg[st] = kw < KS ? a.wp[((size_t)(kh * KS + kw) * a.CiR + ci) * a.CoP + mi * 32 + l31] : 0.f;
+    }
+    const float* pb = patch + (S * 2 * rp) * ICP + S * l31 + khalf;     // row 0, pixel tile 0 of the wave
+    float* const ostage = patch + wave * OCH;                           // the wave's output chunk (patch is dead then)
+    const bool vec_out = (a.Wo & 3) == 0;
+
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        int b = tile;
+        const int n = b / (th * tw);
+        b -= n * th * tw;
+        const int oh0 = (b / tw) * TRW, ow0 = (b - (b / tw) * tw) * TCW;
+        const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        __syncthreads();                                                // previous tile's output staging is done
+        {
+            // all loads of the patch are issued before the first LDS write (clamped addresses + selects: a loop of
+            // load -> wait -> store iterations left the workgroup waiting 21 memory round trips per tile)
+            constexpr int NIT = (CI * IR * ICP + 255) / 256;
+            float sv[NIT];
+            const float* xn = a.x + (size_t)n * CI * HW;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = it * 256 + threadIdx.x;
+                const int ci = min(e / (IR * ICP), CI - 1), rem = e - ci * (IR * ICP);
+                const int rr = rem / ICP, cc = rem - rr * ICP;
+                const int ih = ih0 + rr, iw = iw0 + cc;
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                const float v = xn[(size_t)ci * HW + (size_t)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)];
+                sv[it] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = it * 256 + threadIdx.x;
+                if (e < CI * IR * ICP) patch[e] = sv[it];
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[2][2];                                               // [row of the pair][pixel tile]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kp = 0; kp < KW8 / 2; ++kp) {
+                    const int boff = (ci * IR + kh) * ICP + 2 * kp;
+                    const float av = areg[(ci * KS + kh) * (KW8 / 2) + kp];
+                    const float b00 = pb[boff], b01 = pb[boff + S * 32];
+                    const float b10 = pb[boff + S * ICP], b11 = pb[boff + S * ICP + S * 32];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b00, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b01, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b10, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b11, acc[1][1], 0, 0, 0);
+                }
+        __syncthreads();                                                // every wave is done reading the patch
+
+        // Epilogue through LDS: the accumulator layout gives 128-byte runs per half-wave (dword stores, ~2 TB/s
+        // measured on this 629 MB output); transposed, a lane stores 16 bytes and a wave 4 x 256 contiguous bytes.
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                // chunk = channels mi*32 + 16q + [0,16) of output row rr: accumulator elements j in [8q, 8q+8),
+                // channel-in-chunk = (j & 3) + 8 * ((j >> 2) & 1) + 4 * khalf
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = 8 * q + jj;
+                    const int cl = (jj & 3) + 8 * (jj >> 2) + 4 * khalf;
+                    const int c = mi * 32 + 16 * q + cl;
+                    const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f;
+                    ostage[cl * OP + l31] = small_act(fmaf(acc[rr][0][j], sc, sh), a.act);
+                    ostage[cl * OP + 32 + l31] = small_act(fmaf(acc[rr][1][j], sc, sh), a.act);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int oh = oh0 + 2 * rp + rr;
+                if (oh < a.Ho) {
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int cl = ps * 4 + (lane >> 4), col = (lane & 15) * 4;
+                        const int c = mi * 32 + 16 * q + cl;
+                        const float4 v = *reinterpret_cast<const float4*>(ostage + cl * OP + col);
+                        float* yr = a.y + (((size_t)n * a.Co + c) * a.Ho + oh) * a.Wo + ow0 + col;
+                        if (vec_out && ow0 + col + 3 < a.Wo) *reinterpret_cast<float4*>(yr) = v;
+                        else {
+                            if (ow0 + col < a.Wo) yr[0] = v.x;
+                            if (ow0 + col + 1 < a.Wo) yr[1] = v.y;
+                            if (ow0 + col + 2 < a.Wo) yr[2] = v.z;
+                            if (ow0 + col + 3 < a.Wo) yr[3] = v.w;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+}
+
+// DYNMM_NO_SMALL_CO = 1 | gate | stem : A/B switch back to the implicit-GEMM kernels
+static bool small_off(const char* which) {
+    const char* v = getenv("DYNMM_NO_SMALL_CO");
+    return v && (strcmp(v, which) == 0 || strcmp(v, "1") == 0);
+}
+
+bool stem_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
+    static const bool off = small_off("stem");
+    if (off || residual || a.x2) return false;
+    if (a.KH != 7 || a.KW != 7 || a.SH != 2 || a.SW != 2 || a.PH != 3 || a.PW != 3) return false;
+    return (a.Ci == 1 || a.Ci == 3) && a.Co == 64;
+}
+
+int launch_stem_conv_fwd(const SmallConvArgs& a_in, hipStream_t st) {
+    const long tiles = (long)a_in.N * ceil_div(a_in.Ho, 4) * ceil_div(a_in.Wo, 64);
+    if (tiles > 0x7fffffffL) return DYNMM_EUNSUPPORTED;
+    const SmallConvArgs& a = a_in;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int resident = a.Ci == 1 ? 3 : 2;             // workgroups per CU = waves per SIMD (register-bound)
+    const long cap = (long)cus * resident;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    if (a.Ci == 3)
+        hipLaunchKernelGGL((conv_stem_fwd_kernel<3>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_stem_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, a);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+bool small_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
+    static const bool off = small_off("gate");
+    if (off || residual) return false;
+    if (a.Co < 5 || a.Co > 8) return false;                       // packed rows of exactly 8 floats
+    if (a.KH != 5 || a.KW != 5 || a.SH != 2 || a.SW != 2 || a.PH != 0 || a.PW != 0) return false;
+    if (a.Ci % 4 != 0 || a.Ci < 16) return false;
+    if (a.c_split < a.Ci && a.c_split % (a.Ci / 4) != 0) return false;      // a wave's channels come from one tensor
+    return true;
+}
+
+int launch_small_conv_fwd(const SmallConvArgs& a, hipStream_t st) {
+    const long tiles = (long)a.N * ceil_div(a.Ho, kSRows) * ceil_div(a.Wo, kSCols);
+    if (tiles > 0x7fffffffL) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv_co8_fwd_kernel<5, 2>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+}  // namespace dynmm

@@ -54,6 +54,8 @@ CONV_CASES = [
     (2, 64, 15, 21, 128, (3, 1), (2, 1), (1, 0), True, None),        # odd H: strided dgrad without sub-pixel classes
     (2, 64, 6, 10, 128, (1, 3), (1, 2), (0, 1), False, None),        # parity classes of 30 pixels: tiles straddle classes
     (3, 128, 8, 8, 64, (3, 3), (2, 2), (1, 1), False, None),         # 4 parity classes, 3x3: 1/2/2/4 live taps
+    (2, 32, 21, 37, 8, (5, 5), (2, 2), (0, 0), True, None),          # gate-conv class: direct (no-MFMA) kernel
+    (1, 128, 30, 171, 6, (5, 5), (2, 2), (0, 0), True, 'relu'),      # ... 84 output columns = 2 column tiles, Co = 6
 ]
 
 
