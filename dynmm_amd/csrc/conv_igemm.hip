@@ -1237,6 +1237,42 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     }
 }
 
+// All conv weights of a model in ONE launch (engine.TrainStep: 186 pack launches per step otherwise).  desc[d] =
+// {src, dst_fwd, dst_dgrad (or -1): float offsets from the two base pointers; Co, Ci, KHKW; first workgroup}.
+struct PackDesc {
+    long long src, dstf, dstd;
+    int Co, Ci, KHKW, blk0;
+};
+
+__global__ void __launch_bounds__(256) pack_weight_multi_kernel(const float* __restrict__ src_base,
+                                                                float* __restrict__ dst_base,
+                                                                const PackDesc* __restrict__ desc, int ndesc) {
+    int lo = 0, hi = ndesc - 1;                    // last descriptor whose first workgroup is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackDesc d = desc[lo];
+    const int CoP = (d.Co + 3) & ~3, CiP = (d.Ci + 3) & ~3;
+    const int CiR = (d.Ci >= 8 && d.Ci % 16 != 0) ? ((d.Ci + 15) & ~15) : d.Ci;
+    const int CoR = (d.Co >= 8 && d.Co % 16 != 0) ? ((d.Co + 15) & ~15) : d.Co;
+    const float* __restrict__ w = src_base + d.src;
+    const int i = ((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+    const int nf = d.KHKW * CiR * CoP;
+    const int nd = d.dstd >= 0 ? d.KHKW * CoR * CiP : 0;
+    if (i < nf) {
+        const int co = i % CoP, k = i / CoP;
+        const int ci = k % CiR, tap = k / CiR;
+        dst_base[d.dstf + i] = (co < d.Co && ci < d.Ci) ? w[((size_t)co * d.Ci + ci) * d.KHKW + tap] : 0.f;
+    } else if (i - nf < nd) {
+        const int j = i - nf;
+        const int ci = j % CiP, k = j / CiP;
+        const int co = k % CoR, tap = k / CoR;
+        dst_base[d.dstd + j] = (co < d.Co && ci < d.Ci) ? w[((size_t)co * d.Ci + ci) * d.KHKW + tap] : 0.f;
+    }
+}
+
 static bool geom_ok(const dynmm_conv_geom* g) {
     if (!g) return false;
     if (g->N <= 0 || g->Ci <= 0 || g->Co <= 0 || g->H <= 0 || g->W <= 0) return false;
@@ -1268,6 +1304,17 @@ extern "C" int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
     if (total == 0) return DYNMM_OK;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, w, wp_fwd, wp_dgrad, Co, Ci, KH * KW, CoP, CiP, CiR, CoR);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_pack_weight_multi(const float* src_base, float* dst_base, const void* desc, int ndesc,
+                                       int total_blocks, void* stream) {
+    (void)hipGetLastError();
+    if (!src_base || !dst_base || !desc || ndesc <= 0 || total_blocks <= 0) return DYNMM_EINVAL;
+    static_assert(sizeof(PackDesc) == 40, "descriptor layout is part of the ABI (5 x int64 words)");
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, src_base,
+                       dst_base, (const PackDesc*)desc, ndesc);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -206,6 +206,7 @@ class TrainStep:
         self.multi_stream = bool(multi_stream)
         # None: on unless DYNMM_NO_FUSED_TAIL is set (A/B switch for bench.py / tests)
         self.fuse_tail = (os.environ.get('DYNMM_NO_FUSED_TAIL') is None) if fuse_tail is None else bool(fuse_tail)
+        self.prepack = ops.PackedWeights() if os.environ.get('DYNMM_NO_PREPACK') is None else None
         if hasattr(model, 'dual_stream'):
             model.dual_stream = self.multi_stream
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)
@@ -217,7 +218,7 @@ class TrainStep:
     # ------------------------------------------------------------------------------------------------
     def _body(self, rgb, depth, targets):
         dec = getattr(self.model, 'decoder', None) if self.fuse_tail else None
-        with direct_gradients(self.multi_stream):
+        with direct_gradients(self.multi_stream), self._prepacked():
             ops.touched_reset()
             self.reducer.zero()
             if dec is not None:
@@ -238,6 +239,20 @@ class TrainStep:
             self.last['loss_flop'] = lf.detach()
             ops.join_async()
             self._touched = ops.touched_ids()
+
+    @contextlib.contextmanager
+    def _prepacked(self):
+        """all conv weights of the step packed by one launch (ops.PackedWeights); per-conv packs on the first step"""
+        prev = ops.PREPACK
+        ops.PREPACK = self.prepack
+        if self.prepack is not None:
+            self.prepack.pack()
+        try:
+            yield
+        finally:
+            if self.prepack is not None:
+                self.prepack.invalidate()
+            ops.PREPACK = prev
 
     def _finish(self):
         self.reducer.finish()
@@ -294,6 +309,8 @@ class TrainStep:
             for t, c in zip(self.opt.state_tensors(), opt_state):
                 t.copy_(c)
         restore()
+        if self.prepack is not None and self.prepack.reg and self.prepack.dirty:
+            self.prepack._layout()           # the warm-up registered the weights: lay the arena out before capturing
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._body(*static)

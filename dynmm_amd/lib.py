@@ -35,6 +35,7 @@ SIGNATURES = {
     'dynmm_build_info': (C.c_char_p, []),
     'dynmm_packed_weight_floats': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'dynmm_pack_weight': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_pack_weight_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     'dynmm_conv2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),

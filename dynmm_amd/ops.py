@@ -233,6 +233,84 @@ class GradLink:
         self.dres = None
 
 
+class PackedWeights:
+    """The implicit-GEMM operand layouts (dynmm_pack_weight) of every conv weight a training step uses, produced by
+    ONE launch per step instead of one per convolution (186 for config P).  engine.TrainStep installs an instance
+    as ops.PREPACK: the first step runs the ordinary per-conv packs and registers (weight, shape, needs the
+    input-gradient layout); from then on pack() fills a static arena at the start of the step body and the
+    convolutions look their operands up.  Entries are valid between pack() and invalidate() only (the optimizer
+    rewrites the weights after the body)."""
+
+    def __init__(self):
+        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_dgrad]
+        self.slots = {}          # id(weight) -> (wp, wpd or None)
+        self.arena = self.desc = None
+        self.blocks = 0
+        self.valid = False
+        self.dirty = False       # registrations since the arena was laid out
+
+    def register(self, weight, g, need_dgrad):
+        if not isinstance(weight, torch.nn.Parameter):
+            return
+        e = self.reg.get(id(weight))
+        if e is None:
+            self.reg[id(weight)] = [weight, g.Co, g.Ci, g.KH, g.KW, bool(need_dgrad)]
+            self.dirty = True
+        elif need_dgrad and not e[5]:
+            e[5] = True
+            self.dirty = True
+
+    def lookup(self, weight, need_dgrad):
+        if not self.valid:
+            return None
+        s = self.slots.get(id(weight))
+        if s is None or (need_dgrad and s[1] is None):
+            return None
+        return s
+
+    def _layout(self):
+        lib = _lib()
+        ents = list(self.reg.values())
+        dev = ents[0][0].device
+        base = min(e[0].data_ptr() for e in ents)
+        off, blk, rows = 0, 0, []
+        spans = {}
+        for w, Co, Ci, KH, KW, nd in ents:
+            nf = lib.dynmm_packed_weight_floats(Co, Ci, KH, KW, 0)
+            ndg = lib.dynmm_packed_weight_floats(Co, Ci, KH, KW, 1) if nd else 0
+            dstf = off
+            off += (nf + 3) & ~3                 # rows stay 16-byte aligned (the kernels' dwordx4 path)
+            dstd = off if nd else -1
+            off += (ndg + 3) & ~3
+            rows.append([(w.data_ptr() - base) // 4, dstf, dstd, Co | (Ci << 32), (KH * KW) | (blk << 32)])
+            spans[id(w)] = (dstf, nf, dstd, ndg)
+            blk += -(-(nf + ndg) // 256)
+        self.arena = torch.empty(off, device=dev, dtype=torch.float32)
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.base, self.blocks = base, blk
+        self.slots = {k: (self.arena[a:a + n], self.arena[d:d + m] if d >= 0 else None) for k, (a, n, d, m) in spans.items()}
+        self.dirty = False
+
+    def pack(self):
+        """one launch: every registered weight -> its forward (and input-gradient) operand layout"""
+        self.valid = False
+        if not self.reg:
+            return
+        if self.dirty or self.arena is None:
+            if torch.cuda.is_current_stream_capturing():
+                return                           # layout changes allocate: not inside a capture
+            self._layout()
+        L.check(_lib().dynmm_pack_weight_multi(C.c_void_p(self.base), _p(self.arena), self.desc.data_ptr(), len(self.reg),
+                                               self.blocks, _stream()), 'pack_weight_multi')
+        self.valid = True
+
+    def invalidate(self):
+        self.valid = False
+
+
+PREPACK = None
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, split_fwd, w_owner=None):
@@ -257,7 +335,12 @@ class _Conv2d(Function):
                     'pack_weight_bf16')
             if bf_d:
                 wpd = wsd
-        if not bf_f or (need_dx and not bf_d):
+        pre = PREPACK.lookup(weight, need_dx) if (PREPACK is not None and not bf_f and not bf_d) else None
+        if pre is not None:
+            wp, wpd32 = pre                      # packed by the step's single multi-tensor launch
+            if need_dx:
+                wpd = wpd32
+        elif not bf_f or (need_dx and not bf_d):
             wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=x.device,
                              dtype=torch.float32) if not bf_f else None
             wpd32 = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 1), device=x.device,
@@ -265,6 +348,8 @@ class _Conv2d(Function):
             L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd32), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
             if wpd32 is not None:
                 wpd = wpd32
+            if PREPACK is not None and not bf_f and not bf_d:
+                PREPACK.register(weight, g, need_dx)
         if bf_f:
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_bf16(_p(x), _p(wsf), ns, None, _p(bias), None, _p(y),
                                                                        C.byref(g), act, st)), 'conv2d_fwd_bf16')

@@ -62,6 +62,14 @@ size_t dynmm_packed_weight_floats(int Co, int Ci, int KH, int KW, int dgrad);
 int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
                       int Co, int Ci, int KH, int KW, void* stream);
 
+/* dynmm_pack_weight for many weights in one launch.  desc (device memory) = ndesc records of 5 int64 words:
+ *   { src, dst_fwd, dst_dgrad (-1: none) : float offsets from src_base / dst_base ;
+ *     Co | Ci << 32 ;  KH*KW | first_workgroup << 32 }
+ * record d owns the workgroups [first_workgroup_d, first_workgroup_{d+1}) of 256 elements each, enough for its
+ * dynmm_packed_weight_floats(.., 0) + (.., 1) output elements; total_blocks = their sum. */
+int dynmm_pack_weight_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
+                            void* stream);
+
 /* y = act( conv(x|x2, w) * scale[co] + shift[co] + residual )      (scale/shift/residual optional)
  * Replaces nn.Conv2d (+ folded eval BatchNorm2d + ReLU + residual add) of
  *   ResNet stem src/models/resnet.py:352-358, BasicBlock :66-84, NonBottleneck1D :124-147,

@@ -352,3 +352,39 @@ def test_fused_tail_step_equals_unfused_step():
     vb = torch.cat([g.flatten() for g in out[False][1].values()]).double()
     assert abs(torch.nn.functional.cosine_similarity(va, vb, dim=0).item() - 1) < 1e-9
     assert abs((va.norm() / vb.norm()).item() - 1) < 1e-5
+
+
+@pytest.mark.gpu
+def test_prepacked_weights_step_is_bit_identical(monkeypatch):
+    """ops.PackedWeights: from the second step on every conv weight is packed by ONE multi-tensor launch at the start
+    of the step; losses, gradients and updated parameters must be bit-identical to per-convolution packing, the arena
+    must follow the optimizer's updates, and a step that meets an unregistered weight falls back for it."""
+    from dynmm_amd import engine, ops
+    from tests.test_hip_model import hip_model
+    torch.manual_seed(1)
+    h, w, n = 96, 128, 2
+    rgb, depth = torch.randn(n, 3, h, w).cuda(), torch.randn(n, 1, h, w).cuda()
+    labels = [torch.randint(0, 41, (n, h // s, w // s), dtype=torch.uint8).cuda() for s in (1, 8, 16, 32)]
+    cw = np.linspace(0.5, 1.5, 40).astype(np.float32)
+    res = {}
+    for pre in (True, False):
+        if not pre:
+            monkeypatch.setenv('DYNMM_NO_PREPACK', '1')
+        m = hip_model('P_se', h, w, seed=4)
+        m.train()
+        m.temp, m.hard_gate = 1.0, False
+        step = engine.TrainStep(m, cw, lr=0.05, loss_ratio=1e-3)
+        assert (step.prepack is not None) == pre
+        losses = [step(rgb, depth, labels)['total'].item() for _ in range(3)]
+        torch.cuda.synchronize()
+        if pre:
+            assert len(step.prepack.reg) > 150 and step.prepack.arena is not None and not step.prepack.valid
+            assert ops.PREPACK is None
+        res[pre] = (losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()},
+                    {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    assert res[True][0] == res[False][0]
+    assert res[True][0][0] != res[True][0][2]          # the weights (and so the packed operands) did change
+    for k, v in res[True][1].items():
+        assert torch.equal(v, res[False][1][k]), k
+    for k, v in res[True][2].items():
+        assert torch.equal(v, res[False][2][k]), k

@@ -466,7 +466,8 @@ def test_train_step_parity_at_benchmark_resolution():
     print(f'480x640 batch 2: logits rel err {Hh.rel_err(outs[0].cpu(), r64["outs"][0]):.2e}; grad err vs fp64 median '
           f'{np.median(e_hip):.2e} (fp32 oracle {np.median(e_ref):.2e}), max {e_hip.max():.2e} ({e_ref.max():.2e}); '
           f'cosine {cos64:.6f} (fp32 oracle {cos_ref:.6f}); |g| ratio {(A.norm() / B64.norm()).item():.5f}')
-    assert 1 - cos64 <= 2 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
+    # 1 - cosine is quadratic in the relative error: the 2x error bars above are 4x here
+    assert 1 - cos64 <= 4 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
     assert _rl2(A, B64) <= 3 * _rl2(B32, B64) + 1e-5
 
 
