@@ -163,6 +163,9 @@ def _tile(co, m=1 << 30):
     return '64x128' if co > 32 else '32x256'
 
 
+_SMALL_DIRECT = _os.environ.get('DYNMM_NO_SMALL_CO') is None
+
+
 def _timed(kind, g, call):
     if PROFILE is None:
         return call()
@@ -177,6 +180,12 @@ def _timed(kind, g, call):
             generic = ',padded'
     m = g.N * (g.H * g.W if kind == 'dgrad' else g.Ho * g.Wo)
     name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co, m)}{generic}>'
+    if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)
+        k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
+        if k5 and 5 <= g.Co <= 8 and g.Ci % 4 == 0 and g.Ci >= 16 and (g.c_split == g.Ci or g.c_split % (g.Ci // 4) == 0):
+            name = 'conv_co8_fwd<direct,valu>'
+        elif k7 and g.Ci in (1, 3) and g.Co == 64 and g.c_split == g.Ci:
+            name = f'conv_stem_fwd<ci{g.Ci},mfma>'
     flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
