@@ -113,6 +113,101 @@ __global__ void __launch_bounds__(256) maxpool_bwd4_kernel(const float* __restri
     }
 }
 
+// Even H, W % 8 == 0 (the stems' 240x320 maps): wide versions.  Round 1's kernels issued 9 scalar loads per pooled
+// pixel (forward: 2.4 TB/s) / 12 scalar + byte gathers per 16-byte store (backward: 1.9 TB/s).
+// Forward: a thread owns 4 pooled pixels of one row = input columns 8t-1 .. 8t+7: one scalar + two 16-byte loads per
+// input row, one 16-byte store + one 4-byte index store.  Same tie rule, tap by tap in row-major window order.
+__global__ void __launch_bounds__(256) maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           signed char* __restrict__ idx, int H, int W, int Ho,
+                                                           int Wo) {
+    const size_t plane = blockIdx.x;
+    const float* xp = x + plane * (size_t)H * W;
+    const int Wq = Wo / 4, nq = Ho * Wq;
+    const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
+    for (int q = beg + threadIdx.x; q < end; q += 256) {
+        const int oh = q / Wq, t = q - oh * Wq;
+        float best[4];
+        int bi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = -1; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = 2 * oh - 1 + r;                     // < H always (H even); -1 for the first pooled row
+            if (ih < 0) continue;
+            const float* row = xp + (size_t)ih * W + 8 * t;
+            const float4 a = *reinterpret_cast<const float4*>(row);
+            const float4 b = *reinterpret_cast<const float4*>(row + 4);
+            const float left = t > 0 ? row[-1] : 0.f;
+            const float v[9] = {left, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    if (j == 0 && sx == 0 && t == 0) continue;          // input column -1
+                    const float val = v[2 * j + sx];
+                    if (bi[j] < 0 || val > best[j] || val != val) { best[j] = val; bi[j] = r * 3 + sx; }
+                }
+        }
+        const size_t o = plane * (size_t)Ho * Wo + (size_t)oh * Wo + 4 * t;
+        *reinterpret_cast<float4*>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+        if (idx) {
+            const unsigned pk = (unsigned)(bi[0] & 0xff) | ((unsigned)(bi[1] & 0xff) << 8) |
+                                ((unsigned)(bi[2] & 0xff) << 16) | ((unsigned)(bi[3] & 0xff) << 24);
+            *reinterpret_cast<unsigned*>(idx + o) = pk;
+        }
+    }
+}
+
+// Backward: a thread owns input rows 2a, 2a+1 x columns 8t .. 8t+7 = four 2x2 blocks; the block at pooled position
+// (a, m) collects from the windows (a, m), (a, m+1), (a+1, m), (a+1, m+1) by their arg-max code:
+//   (2a, 2m): code 4 of w(a,m)            (2a,   2m+1): 5 of w(a,m), 3 of w(a,m+1)
+//   (2a+1, 2m): 7 of w(a,m), 1 of w(a+1,m)    (2a+1, 2m+1): 8 of w(a,m), 6 of w(a,m+1), 2 of w(a+1,m), 0 of w(a+1,m+1)
+// i.e. 2 pooled rows x 5 pooled columns of (gradient, code), fetched as one 16-byte + one scalar load each.
+__global__ void __launch_bounds__(256) maxpool_bwd8_kernel(const float* __restrict__ g,
+                                                           const signed char* __restrict__ idx,
+                                                           float* __restrict__ dx, int H, int W, int Ho, int Wo) {
+    const size_t plane = blockIdx.x;
+    const float* gp = g + plane * (size_t)Ho * Wo;
+    const signed char* ip = idx + plane * (size_t)Ho * Wo;
+    float* dp = dx + plane * (size_t)H * W;
+    const int Wq = Wo / 4, nq = Ho * Wq;
+    const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
+    for (int q = beg + threadIdx.x; q < end; q += 256) {
+        const int a = q / Wq, t = q - a * Wq;
+        float gv[2][5];
+        int cd[2][5];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const bool rok = a + rr < Ho;
+            const size_t o = (size_t)(rok ? a + rr : a) * Wo + 4 * t;
+            const float4 g4 = *reinterpret_cast<const float4*>(gp + o);
+            const unsigned c4 = *reinterpret_cast<const unsigned*>(ip + o);
+            const bool cok = 4 * t + 4 < Wo;
+            const float g5 = cok ? gp[o + 4] : 0.f;
+            const int c5 = cok ? (int)ip[o + 4] : -1;
+            gv[rr][0] = g4.x; gv[rr][1] = g4.y; gv[rr][2] = g4.z; gv[rr][3] = g4.w; gv[rr][4] = g5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cd[rr][j] = rok ? (int)(signed char)((c4 >> (8 * j)) & 0xffu) : -1;
+            cd[rr][4] = rok ? c5 : -1;
+        }
+        float top[8], bot[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float g00 = gv[0][m], g01 = gv[0][m + 1], g10 = gv[1][m], g11 = gv[1][m + 1];
+            const int c00 = cd[0][m], c01 = cd[0][m + 1], c10 = cd[1][m], c11 = cd[1][m + 1];
+            top[2 * m] = c00 == 4 ? g00 : 0.f;
+            top[2 * m + 1] = (c00 == 5 ? g00 : 0.f) + (c01 == 3 ? g01 : 0.f);
+            bot[2 * m] = (c00 == 7 ? g00 : 0.f) + (c10 == 1 ? g10 : 0.f);
+            bot[2 * m + 1] = ((c00 == 8 ? g00 : 0.f) + (c01 == 6 ? g01 : 0.f)) + ((c10 == 2 ? g10 : 0.f) + (c11 == 0 ? g11 : 0.f));
+        }
+        float* r0 = dp + (size_t)(2 * a) * W + 8 * t;
+        *reinterpret_cast<float4*>(r0) = make_float4(top[0], top[1], top[2], top[3]);
+        *reinterpret_cast<float4*>(r0 + 4) = make_float4(top[4], top[5], top[6], top[7]);
+        *reinterpret_cast<float4*>(r0 + W) = make_float4(bot[0], bot[1], bot[2], bot[3]);
+        *reinterpret_cast<float4*>(r0 + W + 4) = make_float4(bot[4], bot[5], bot[6], bot[7]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // adaptive average pool (windows [floor(o*I/O), ceil((o+1)*I/O)) ) — tiny maps only (PPM).
 // ------------------------------------------------------------------------------------------------
@@ -646,7 +741,12 @@ extern "C" int dynmm_maxpool3x3s2_fwd(const float* x, float* y, signed char* idx
     if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return DYNMM_EINVAL;
     dim3 grid(N * C, plane_chunks(Ho * Wo, kChunk));
-    hipLaunchKernelGGL(maxpool_fwd_kernel, grid, dim3(256), 0, ST, x, y, idx, H, W, Ho, Wo);
+    const bool wide = H % 2 == 0 && W % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0 &&
+                      (reinterpret_cast<uintptr_t>(idx) & 3u) == 0;
+    if (wide)
+        hipLaunchKernelGGL(maxpool_fwd4_kernel, grid, dim3(256), 0, ST, x, y, idx, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel, grid, dim3(256), 0, ST, x, y, idx, H, W, Ho, Wo);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -656,7 +756,12 @@ extern "C" int dynmm_maxpool3x3s2_bwd(const float* g, const signed char* idx, fl
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !idx || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DYNMM_EINVAL;
     dim3 grid(N * C, plane_chunks(H * W, kChunk));
-    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15u) == 0)
+    if (H % 2 == 0 && W % 8 == 0 && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(idx) & 3u) == 0) {
+        // one thread per 2 x 8 input pixels = per 4 pooled pixels: the forward's chunking
+        hipLaunchKernelGGL(maxpool_bwd8_kernel, dim3(N * C, plane_chunks(Ho * Wo, kChunk)), dim3(256), 0, ST, g, idx, dx,
+                           H, W, Ho, Wo);
+    } else if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15u) == 0)
         hipLaunchKernelGGL(maxpool_bwd4_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);
     else
         hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, ST, g, idx, dx, H, W, Ho, Wo);

@@ -170,8 +170,9 @@ def test_batch_norm_act(ops, shape, act, training):
     assert int(bng.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
-def test_maxpool_with_ties(ops):
-    x = F.relu(rnd(2, 64, 48, 64, seed=1))          # post-ReLU: many exact-zero ties
+@pytest.mark.parametrize('hw', [(48, 64), (30, 44), (17, 23), (6, 8)])       # wide (even H, W % 8 == 0) / W % 4 / scalar paths
+def test_maxpool_with_ties(ops, hw):
+    x = F.relu(rnd(2, 64, *hw, seed=1))             # post-ReLU: many exact-zero ties
     xr = x.clone().requires_grad_(True)
     y_ref = F.max_pool2d(xr, 3, 2, 1)
     gy = rnd(*y_ref.shape, seed=2)
