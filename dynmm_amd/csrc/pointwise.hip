@@ -5,6 +5,7 @@
 // site).  One workgroup owns (a chunk of) one NCHW plane; lanes walk the
 // contiguous HW axis with 16-byte accesses wherever size/alignment allow.
 #include "common.h"
+#include <initializer_list>
 #include "vec.h"
 
 namespace dynmm {
@@ -163,6 +164,37 @@ __global__ void __launch_bounds__(256) maxpool_fwd4_kernel(const float* __restri
 //   (2a, 2m): code 4 of w(a,m)            (2a,   2m+1): 5 of w(a,m), 3 of w(a,m+1)
 //   (2a+1, 2m): 7 of w(a,m), 1 of w(a+1,m)    (2a+1, 2m+1): 8 of w(a,m), 6 of w(a,m+1), 2 of w(a+1,m), 0 of w(a+1,m+1)
 // i.e. 2 pooled rows x 5 pooled columns of (gradient, code), fetched as one 16-byte + one scalar load each.
+// gradient of the 2 x 8 input pixels (rows 2a, 2a+1; columns 8t .. 8t+7) of one plane from the pooled gradient gp and
+// the arg-max codes ip: top[] = row 2a, bot[] = row 2a+1
+__device__ __forceinline__ void pool_bwd_block(const float* __restrict__ gp, const signed char* __restrict__ ip, int a,
+                                               int t, int Ho, int Wo, float (&top)[8], float (&bot)[8]) {
+    float gv[2][5];
+    int cd[2][5];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const bool rok = a + rr < Ho;
+        const size_t o = (size_t)(rok ? a + rr : a) * Wo + 4 * t;
+        const float4 g4 = *reinterpret_cast<const float4*>(gp + o);
+        const unsigned c4 = *reinterpret_cast<const unsigned*>(ip + o);
+        const bool cok = 4 * t + 4 < Wo;
+        const float g5 = cok ? gp[o + 4] : 0.f;
+        const int c5 = cok ? (int)ip[o + 4] : -1;
+        gv[rr][0] = g4.x; gv[rr][1] = g4.y; gv[rr][2] = g4.z; gv[rr][3] = g4.w; gv[rr][4] = g5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cd[rr][j] = rok ? (int)(signed char)((c4 >> (8 * j)) & 0xffu) : -1;
+        cd[rr][4] = rok ? c5 : -1;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float g00 = gv[0][m], g01 = gv[0][m + 1], g10 = gv[1][m], g11 = gv[1][m + 1];
+        const int c00 = cd[0][m], c01 = cd[0][m + 1], c10 = cd[1][m], c11 = cd[1][m + 1];
+        top[2 * m] = c00 == 4 ? g00 : 0.f;
+        top[2 * m + 1] = (c00 == 5 ? g00 : 0.f) + (c01 == 3 ? g01 : 0.f);
+        bot[2 * m] = (c00 == 7 ? g00 : 0.f) + (c10 == 1 ? g10 : 0.f);
+        bot[2 * m + 1] = ((c00 == 8 ? g00 : 0.f) + (c01 == 6 ? g01 : 0.f)) + ((c10 == 2 ? g10 : 0.f) + (c11 == 0 ? g11 : 0.f));
+    }
+}
+
 __global__ void __launch_bounds__(256) maxpool_bwd8_kernel(const float* __restrict__ g,
                                                            const signed char* __restrict__ idx,
                                                            float* __restrict__ dx, int H, int W, int Ho, int Wo) {
@@ -174,37 +206,144 @@ __global__ void __launch_bounds__(256) maxpool_bwd8_kernel(const float* __restri
     const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
     for (int q = beg + threadIdx.x; q < end; q += 256) {
         const int a = q / Wq, t = q - a * Wq;
-        float gv[2][5];
-        int cd[2][5];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const bool rok = a + rr < Ho;
-            const size_t o = (size_t)(rok ? a + rr : a) * Wo + 4 * t;
-            const float4 g4 = *reinterpret_cast<const float4*>(gp + o);
-            const unsigned c4 = *reinterpret_cast<const unsigned*>(ip + o);
-            const bool cok = 4 * t + 4 < Wo;
-            const float g5 = cok ? gp[o + 4] : 0.f;
-            const int c5 = cok ? (int)ip[o + 4] : -1;
-            gv[rr][0] = g4.x; gv[rr][1] = g4.y; gv[rr][2] = g4.z; gv[rr][3] = g4.w; gv[rr][4] = g5;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cd[rr][j] = rok ? (int)(signed char)((c4 >> (8 * j)) & 0xffu) : -1;
-            cd[rr][4] = rok ? c5 : -1;
-        }
         float top[8], bot[8];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float g00 = gv[0][m], g01 = gv[0][m + 1], g10 = gv[1][m], g11 = gv[1][m + 1];
-            const int c00 = cd[0][m], c01 = cd[0][m + 1], c10 = cd[1][m], c11 = cd[1][m + 1];
-            top[2 * m] = c00 == 4 ? g00 : 0.f;
-            top[2 * m + 1] = (c00 == 5 ? g00 : 0.f) + (c01 == 3 ? g01 : 0.f);
-            bot[2 * m] = (c00 == 7 ? g00 : 0.f) + (c10 == 1 ? g10 : 0.f);
-            bot[2 * m + 1] = ((c00 == 8 ? g00 : 0.f) + (c01 == 6 ? g01 : 0.f)) + ((c10 == 2 ? g10 : 0.f) + (c11 == 0 ? g11 : 0.f));
-        }
+        pool_bwd_block(gp, ip, a, t, Ho, Wo, top, bot);
         float* r0 = dp + (size_t)(2 * a) * W + 8 * t;
         *reinterpret_cast<float4*>(r0) = make_float4(top[0], top[1], top[2], top[3]);
         *reinterpret_cast<float4*>(r0 + 4) = make_float4(top[4], top[5], top[6], top[7]);
         *reinterpret_cast<float4*>(r0 + W) = make_float4(bot[0], bot[1], bot[2], bot[3]);
         *reinterpret_cast<float4*>(r0 + W + 4) = make_float4(bot[4], bot[5], bot[6], bot[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem fusion + both max-pools as one forward pass and two backward passes (…globalgate.py:258-261: fuse =
+// se_layer0(rgb, depth); rgb = max_pool(fuse); depth = max_pool(depth)).  The full-resolution fused map has no other
+// consumer, so it is never written: forward reads rgb / depth once and writes the two pooled maps (+ arg-max codes);
+// backward re-derives d(fuse) and d(pooled depth) block by block from the pooled gradients and the codes.  Unfused,
+// the same work is 7 passes over 629 MB tensors forward and 12 backward (batch 32).  Even H, W % 8 == 0 only.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pool_update(float& best, int& bi, float val, int code) {
+    if (bi < 0 || val > best || val != val) { best = val; bi = code; }
+}
+
+__global__ void __launch_bounds__(256) axpby_pool_fwd_kernel(const float* __restrict__ xr, const float* __restrict__ xd,
+                                                             const float* __restrict__ ca, const float* __restrict__ cb,
+                                                             float* __restrict__ yo, signed char* __restrict__ io,
+                                                             float* __restrict__ yd, signed char* __restrict__ id, int H,
+                                                             int W, int Ho, int Wo) {
+    const size_t plane = blockIdx.x;
+    const float* rp = xr + plane * (size_t)H * W;
+    const float* dp = xd + plane * (size_t)H * W;
+    const float fa = ca[plane], fb = cb[plane];
+    const int Wq = Wo / 4, nq = Ho * Wq;
+    const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
+    for (int q = beg + threadIdx.x; q < end; q += 256) {
+        const int oh = q / Wq, t = q - oh * Wq;
+        float bo[4], bd[4];
+        int co[4], cd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bo[j] = bd[j] = -INFINITY; co[j] = cd[j] = -1; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = 2 * oh - 1 + r;
+            if (ih < 0) continue;
+            const size_t o = (size_t)ih * W + 8 * t;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp + o), r1 = *reinterpret_cast<const float4*>(rp + o + 4);
+            const float4 d0 = *reinterpret_cast<const float4*>(dp + o), d1 = *reinterpret_cast<const float4*>(dp + o + 4);
+            const float rl = t > 0 ? rp[o - 1] : 0.f, dl = t > 0 ? dp[o - 1] : 0.f;
+            const float rv[9] = {rl, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const float dv[9] = {dl, d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float fv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) fv[k] = fa * rv[k] + fb * dv[k];         // axpby_fwd_kernel's expression
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    if (j == 0 && sx == 0 && t == 0) continue;                  // input column -1
+                    pool_update(bo[j], co[j], fv[2 * j + sx], r * 3 + sx);
+                    pool_update(bd[j], cd[j], dv[2 * j + sx], r * 3 + sx);
+                }
+        }
+        const size_t o = plane * (size_t)Ho * Wo + (size_t)oh * Wo + 4 * t;
+        *reinterpret_cast<float4*>(yo + o) = make_float4(bo[0], bo[1], bo[2], bo[3]);
+        *reinterpret_cast<float4*>(yd + o) = make_float4(bd[0], bd[1], bd[2], bd[3]);
+        *reinterpret_cast<unsigned*>(io + o) = (unsigned)(co[0] & 0xff) | ((unsigned)(co[1] & 0xff) << 8) |
+                                               ((unsigned)(co[2] & 0xff) << 16) | ((unsigned)(co[3] & 0xff) << 24);
+        *reinterpret_cast<unsigned*>(id + o) = (unsigned)(cd[0] & 0xff) | ((unsigned)(cd[1] & 0xff) << 8) |
+                                               ((unsigned)(cd[2] & 0xff) << 16) | ((unsigned)(cd[3] & 0xff) << 24);
+    }
+}
+
+// da[plane] = sum d(fuse) * rgb ; db[plane] = sum d(fuse) * depth   (one workgroup per plane: fixed summation order)
+__global__ void __launch_bounds__(256) axpby_pool_bwd_reduce_kernel(const float* __restrict__ go,
+                                                                    const signed char* __restrict__ io,
+                                                                    const float* __restrict__ xr,
+                                                                    const float* __restrict__ xd, float* __restrict__ da,
+                                                                    float* __restrict__ db, int H, int W, int Ho, int Wo) {
+    __shared__ float red[4];
+    const size_t plane = blockIdx.x;
+    const float* gp = go + plane * (size_t)Ho * Wo;
+    const signed char* ip = io + plane * (size_t)Ho * Wo;
+    const float* rp = xr + plane * (size_t)H * W;
+    const float* dp = xd + plane * (size_t)H * W;
+    const int Wq = Wo / 4, nq = Ho * Wq;
+    float sa = 0.f, sb = 0.f;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const int a = q / Wq, t = q - a * Wq;
+        float top[8], bot[8];
+        pool_bwd_block(gp, ip, a, t, Ho, Wo, top, bot);
+        const size_t o = (size_t)(2 * a) * W + 8 * t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 r0 = *reinterpret_cast<const float4*>(rp + o + 4 * h), r1 = *reinterpret_cast<const float4*>(rp + o + W + 4 * h);
+            const float4 d0 = *reinterpret_cast<const float4*>(dp + o + 4 * h), d1 = *reinterpret_cast<const float4*>(dp + o + W + 4 * h);
+            sa += top[4 * h] * r0.x + top[4 * h + 1] * r0.y + top[4 * h + 2] * r0.z + top[4 * h + 3] * r0.w;
+            sa += bot[4 * h] * r1.x + bot[4 * h + 1] * r1.y + bot[4 * h + 2] * r1.z + bot[4 * h + 3] * r1.w;
+            sb += top[4 * h] * d0.x + top[4 * h + 1] * d0.y + top[4 * h + 2] * d0.z + top[4 * h + 3] * d0.w;
+            sb += bot[4 * h] * d1.x + bot[4 * h + 1] * d1.y + bot[4 * h + 2] * d1.z + bot[4 * h + 3] * d1.w;
+        }
+    }
+    const float ta = block_reduce_sum_256<float>(sa, red);
+    const float tb = block_reduce_sum_256<float>(sb, red);
+    if (threadIdx.x == 0) { da[plane] = ta; db[plane] = tb; }
+}
+
+// d rgb = a * d(fuse) + ca*cscale ; d depth = b * d(fuse) + cb*cscale + d(pooled depth)
+__global__ void __launch_bounds__(256) axpby_pool_bwd_apply_kernel(
+    const float* __restrict__ go, const signed char* __restrict__ io, const float* __restrict__ gd,
+    const signed char* __restrict__ id, const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ ca, const float* __restrict__ cb, float cscale, float* __restrict__ dxr,
+    float* __restrict__ dxd, int H, int W, int Ho, int Wo) {
+    const size_t plane = blockIdx.x;
+    const size_t po = plane * (size_t)Ho * Wo;
+    const float fa = a[plane], fb = b[plane];
+    const float oa = ca ? ca[plane] * cscale : 0.f, ob = cb ? cb[plane] * cscale : 0.f;
+    float* rp = dxr + plane * (size_t)H * W;
+    float* dp = dxd + plane * (size_t)H * W;
+    const int Wq = Wo / 4, nq = Ho * Wq;
+    const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
+    for (int q = beg + threadIdx.x; q < end; q += 256) {
+        const int ar = q / Wq, t = q - ar * Wq;
+        float ft[8], fbm[8], dt[8], dbm[8];
+        pool_bwd_block(go + po, io + po, ar, t, Ho, Wo, ft, fbm);
+        pool_bwd_block(gd + po, id + po, ar, t, Ho, Wo, dt, dbm);
+        const size_t o = (size_t)(2 * ar) * W + 8 * t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // (axpby_bwd_apply_kernel's expressions; the pooled-depth gradient is added last, as add_n did)
+            *reinterpret_cast<float4*>(rp + o + 4 * h) = make_float4(fa * ft[4 * h] + oa, fa * ft[4 * h + 1] + oa,
+                                                                      fa * ft[4 * h + 2] + oa, fa * ft[4 * h + 3] + oa);
+            *reinterpret_cast<float4*>(rp + o + W + 4 * h) = make_float4(fa * fbm[4 * h] + oa, fa * fbm[4 * h + 1] + oa,
+                                                                          fa * fbm[4 * h + 2] + oa, fa * fbm[4 * h + 3] + oa);
+            *reinterpret_cast<float4*>(dp + o + 4 * h) =
+                make_float4((fb * ft[4 * h] + ob) + dt[4 * h], (fb * ft[4 * h + 1] + ob) + dt[4 * h + 1],
+                            (fb * ft[4 * h + 2] + ob) + dt[4 * h + 2], (fb * ft[4 * h + 3] + ob) + dt[4 * h + 3]);
+            *reinterpret_cast<float4*>(dp + o + W + 4 * h) =
+                make_float4((fb * fbm[4 * h] + ob) + dbm[4 * h], (fb * fbm[4 * h + 1] + ob) + dbm[4 * h + 1],
+                            (fb * fbm[4 * h + 2] + ob) + dbm[4 * h + 2], (fb * fbm[4 * h + 3] + ob) + dbm[4 * h + 3]);
+        }
     }
 }
 
@@ -913,6 +1052,55 @@ extern "C" int dynmm_axpby_bwd_apply(const float* g, const float* a, const float
         hipLaunchKernelGGL(axpby_bwd_apply_kernel<4>, grid, dim3(256), 0, ST, g, a, b, ca, cb, cscale, dxr, dxd, HW);
     else
         hipLaunchKernelGGL(axpby_bwd_apply_kernel<1>, grid, dim3(256), 0, ST, g, a, b, ca, cb, cscale, dxr, dxd, HW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+static bool pool_fusable(int H, int W, int Ho, int Wo, std::initializer_list<const void*> p16,
+                         std::initializer_list<const void*> p4) {
+    if (H % 2 != 0 || W % 8 != 0 || Ho != H / 2 || Wo != W / 2) return false;
+    for (const void* p : p16) if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
+    for (const void* p : p4) if (reinterpret_cast<uintptr_t>(p) & 3u) return false;
+    return true;
+}
+
+extern "C" int dynmm_axpby_pool_supported(int H, int W) { return (H > 0 && W > 0 && H % 2 == 0 && W % 8 == 0) ? 1 : 0; }
+
+extern "C" int dynmm_axpby_pool_fwd(const float* xr, const float* xd, const float* a, const float* b, float* y_out,
+                                    signed char* idx_out, float* y_depth, signed char* idx_depth, int NC, int H, int W,
+                                    void* stream) {
+    (void)hipGetLastError();
+    if (!xr || !xd || !a || !b || !y_out || !idx_out || !y_depth || !idx_depth || NC <= 0) return DYNMM_EINVAL;
+    const int Ho = H / 2, Wo = W / 2;
+    if (!pool_fusable(H, W, Ho, Wo, {xr, xd, y_out, y_depth}, {idx_out, idx_depth})) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(axpby_pool_fwd_kernel, dim3(NC, plane_chunks(Ho * Wo, kChunk)), dim3(256), 0, ST, xr, xd, a, b,
+                       y_out, idx_out, y_depth, idx_depth, H, W, Ho, Wo);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_axpby_pool_bwd_reduce(const float* g_out, const signed char* idx_out, const float* xr,
+                                           const float* xd, float* da, float* db, int NC, int H, int W, void* stream) {
+    (void)hipGetLastError();
+    if (!g_out || !idx_out || !xr || !xd || !da || !db || NC <= 0) return DYNMM_EINVAL;
+    const int Ho = H / 2, Wo = W / 2;
+    if (!pool_fusable(H, W, Ho, Wo, {g_out, xr, xd}, {idx_out})) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(axpby_pool_bwd_reduce_kernel, dim3(NC), dim3(256), 0, ST, g_out, idx_out, xr, xd, da, db, H, W,
+                       Ho, Wo);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_axpby_pool_bwd_apply(const float* g_out, const signed char* idx_out, const float* g_depth,
+                                          const signed char* idx_depth, const float* a, const float* b, const float* ca,
+                                          const float* cb, float cscale, float* dxr, float* dxd, int NC, int H, int W,
+                                          void* stream) {
+    (void)hipGetLastError();
+    if (!g_out || !idx_out || !g_depth || !idx_depth || !a || !b || !dxr || !dxd || NC <= 0) return DYNMM_EINVAL;
+    const int Ho = H / 2, Wo = W / 2;
+    if (!pool_fusable(H, W, Ho, Wo, {g_out, g_depth, dxr, dxd}, {idx_out, idx_depth})) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(axpby_pool_bwd_apply_kernel, dim3(NC, plane_chunks(Ho * Wo, kChunk)), dim3(256), 0, ST, g_out,
+                       idx_out, g_depth, idx_depth, a, b, ca, cb, cscale, dxr, dxd, H, W, Ho, Wo);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

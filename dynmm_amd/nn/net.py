@@ -212,10 +212,14 @@ class SkipGateESANet(nn.Module):
             ops.begin_step()
         r = er.forward_first_conv(rgb)
         d = ed.forward_first_conv(depth)
-        d, d_pool = ops.fan_out(d, 2)                               # depth stem output: stem fusion + its own max-pool
-        fuse = ops.se_fuse_blend(r, d, self._se(0))                 # stem fusion is always on
-        r = ops.max_pool_3x3_s2(fuse)
-        d = ops.max_pool_3x3_s2(d_pool)
+        if ops.se_fuse_pool_supported(r):
+            # stem fusion (always on) + both max-pools as one pass; the full-resolution fused map is never written
+            r, d = ops.se_fuse_pool(r, d, self._se(0))
+        else:
+            d, d_pool = ops.fan_out(d, 2)                           # depth stem output: stem fusion + its own max-pool
+            fuse = ops.se_fuse_blend(r, d, self._se(0))
+            r = ops.max_pool_3x3_s2(fuse)
+            d = ops.max_pool_3x3_s2(d_pool)
 
         bs = r.shape[0]
         host_branch = None                                           # branch per sample when the host already knows it

@@ -907,6 +907,89 @@ class _SEFuseBlend(Function):
         return (drgb, ddepth, dwcum, None, None, None, *dparams_ret)
 
 
+class _SEFusePool(Function):
+    """(max_pool(SE_rgb(rgb) + SE_depth(depth)), max_pool(depth)) — the stem fusion and both 3x3/s2 max-pools of
+    …globalgate.py:258-261 without ever writing the full-resolution fused map (csrc/pointwise.hip: axpby_pool_*)."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, use_se, *params):
+        lib = _lib()
+        st = _stream()
+        rgb, depth = _chk(rgb, 'rgb'), _chk(depth, 'depth')
+        _same_shape(rgb, depth, 'stem fusion')
+        N, Cc, H, W = rgb.shape
+        HW = H * W
+        f32 = dict(device=rgb.device, dtype=torch.float32)
+        sr = sd = hr = hd = gr = gd = None
+        parr = None
+        if use_se:
+            params = [_chk(p, 'se param') for p in params]
+            parr = _ptr_array(params)
+            sr, sd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            L.check(lib.dynmm_gap2_fwd(_p(rgb), _p(depth), _p(sr), _p(sd), N * Cc, HW, st), 'gap2')
+            hr, hd = torch.empty((N, Cc // 16), **f32), torch.empty((N, Cc // 16), **f32)
+            gr, gd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        a, b = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_se_coeff_fwd(_p(sr), _p(sd), parr, None, 0, _p(a), _p(b), _p(hr), _p(hd), _p(gr), _p(gd),
+                                       N, Cc, int(use_se), st), 'se_coeff_fwd')
+        Ho, Wo = H // 2, W // 2
+        yo, yd = torch.empty((N, Cc, Ho, Wo), **f32), torch.empty((N, Cc, Ho, Wo), **f32)
+        io = torch.empty((N, Cc, Ho, Wo), device=rgb.device, dtype=torch.int8)
+        idd = torch.empty_like(io)
+        L.check(lib.dynmm_axpby_pool_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(yo), io.data_ptr(), _p(yd), idd.data_ptr(),
+                                         N * Cc, H, W, st), 'axpby_pool_fwd')
+        ctx.use_se = use_se
+        ctx.n_params = len(params)
+        ctx.param_objs = list(params)
+        ctx.save_for_backward(rgb, depth, a, b, sr, sd, hr, hd, gr, gd, io, idd, *params)
+        return yo, yd
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        lib = _lib()
+        st = _stream()
+        rgb, depth, a, b, sr, sd, hr, hd, gr, gd, io, idd = ctx.saved_tensors[:12]
+        params = list(ctx.saved_tensors[12:])
+        N, Cc, H, W = rgb.shape
+        HW = H * W
+        f32 = dict(device=rgb.device, dtype=torch.float32)
+        g_o = torch.zeros_like(io, dtype=torch.float32) if g_o is None else _chk(g_o, 'grad')
+        g_d = torch.zeros_like(io, dtype=torch.float32) if g_d is None else _chk(g_d, 'grad')
+        da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_axpby_pool_bwd_reduce(_p(g_o), io.data_ptr(), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, H, W, st),
+                'axpby_pool_bwd_reduce')
+        dparams = dparams_ret = [None] * ctx.n_params
+        dsr = dsd = None
+        parr = dparr = None
+        if ctx.use_se:
+            pairs = [_grad_dst(po) for po in ctx.param_objs]
+            dparams, dparams_ret = [d for d, _ in pairs], [r for _, r in pairs]
+            parr, dparr = _ptr_array(params), _ptr_array(dparams)
+            dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        ws = torch.empty(lib.dynmm_se_coeff_bwd_workspace_bytes(N, Cc) // 4, **f32) if ctx.use_se else None
+        L.check(lib.dynmm_se_coeff_bwd(_p(da), _p(db), _p(sr), _p(sd), parr, None, 0, _p(hr), _p(hd), _p(gr), _p(gd),
+                                       dparr, _p(dsr), _p(dsd), None, 0, _p(ws), N, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
+        drgb, ddepth = torch.empty_like(rgb), torch.empty_like(depth)
+        L.check(lib.dynmm_axpby_pool_bwd_apply(_p(g_o), io.data_ptr(), _p(g_d), idd.data_ptr(), _p(a), _p(b), _p(dsr), _p(dsd),
+                                               1.0 / HW, _p(drgb), _p(ddepth), N * Cc, H, W, st), 'axpby_pool_bwd_apply')
+        _grads_enqueued()
+        return (drgb, ddepth, None, *dparams_ret)
+
+
+_FUSED_STEM_POOL = _os.environ.get('DYNMM_NO_FUSED_STEM_POOL') is None        # A/B switch
+
+
+def se_fuse_pool_supported(x):
+    """even H, W % 8 == 0 (the kernels' 16-byte row accesses); otherwise callers compose the unfused ops"""
+    return _FUSED_STEM_POOL and x.dim() == 4 and bool(_lib().dynmm_axpby_pool_supported(int(x.shape[2]), int(x.shape[3])))
+
+
+def se_fuse_pool(rgb, depth, se_params=None):
+    """(max_pool_3x3_s2(se_fuse_blend(rgb, depth, se_params)), max_pool_3x3_s2(depth)) in one forward pass."""
+    use_se = se_params is not None
+    return _SEFusePool.apply(rgb, depth, use_se, *(tuple(se_params) if use_se else ()))
+
+
 def se_fuse_blend(rgb, depth, se_params=None, wcum=None, col=0, inplace=False):
     """se_params: None ('add' fusion) or the 8 tensors (W1r,b1r,W2r,b2r,W1d,b1d,W2d,b2d).
     depth may hold only a PREFIX of rgb's batch (compaction): the remaining samples pass rgb through."""

@@ -215,6 +215,20 @@ int dynmm_axpby_bwd_apply(const float* g, const float* a, const float* b,
                           const float* ca, const float* cb, float cscale, float* dxr, float* dxd,
                           int NC, int HW, void* stream);
 
+/* Stem fusion + both 3x3/s2/p1 max-pools in one forward and two backward passes (…globalgate.py:258-261):
+ *   fuse = a*rgb + b*depth (never written);  y_out = max_pool(fuse);  y_depth = max_pool(depth);  idx_* = arg-max codes.
+ *   bwd_reduce: da/db [NC] = sum d(fuse)*rgb / *depth with d(fuse) = max_pool_backward(g_out, idx_out) on the fly;
+ *   bwd_apply : dxr = a*d(fuse) + ca*cscale;  dxd = b*d(fuse) + cb*cscale + max_pool_backward(g_depth, idx_depth).
+ * Even H and W % 8 == 0 only (dynmm_axpby_pool_supported); DYNMM_EUNSUPPORTED otherwise (callers keep the unfused ops). */
+int dynmm_axpby_pool_supported(int H, int W);
+int dynmm_axpby_pool_fwd(const float* xr, const float* xd, const float* a, const float* b, float* y_out,
+                         signed char* idx_out, float* y_depth, signed char* idx_depth, int NC, int H, int W, void* stream);
+int dynmm_axpby_pool_bwd_reduce(const float* g_out, const signed char* idx_out, const float* xr, const float* xd,
+                                float* da, float* db, int NC, int H, int W, void* stream);
+int dynmm_axpby_pool_bwd_apply(const float* g_out, const signed char* idx_out, const float* g_depth,
+                               const signed char* idx_depth, const float* a, const float* b, const float* ca,
+                               const float* cb, float cscale, float* dxr, float* dxd, int NC, int H, int W, void* stream);
+
 /* ---- SkipESANet per-stage gate + 2-way blend (rgb_depth_fusion.py:29-65, model_utils.py:54-70,
  *      model_skip_mod.py:235-311) ----
  * Gate (evaluated when wnext != NULL) from the pooled maps sr,sd [N,C] of the stage's rgb/depth features:

@@ -498,3 +498,40 @@ def test_fused_upsample_cross_entropy_tail(ops, shape):
     # fp64, invisible in the fp32 seed): every gradient is bit-reproducible
     for a, b in zip(runs[0][1:], runs[1][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('use_se', [True, False])
+@pytest.mark.parametrize('shape', [(2, 64, 24, 32), (3, 32, 6, 8)])
+def test_se_fuse_pool_equals_unfused_ops(ops, use_se, shape):
+    """axpby_pool_*: stem fusion + both max-pools fused (the full-resolution fused map never written) against the
+    composition se_fuse_blend -> max_pool, max_pool it replaces: outputs bit-identical (same expressions, same tie
+    rule on post-ReLU zeros), gradients to summation order."""
+    N, C, H, W = shape
+    assert ops.se_fuse_pool_supported(torch.empty(shape))
+    rgb, depth = F.relu(rnd(*shape, seed=1)), F.relu(rnd(*shape, seed=2))
+    prm = None
+    if use_se:
+        prm = []
+        for k in range(2):
+            prm += [rnd(C // 16, C, 1, 1, seed=3 + k, scale=0.2), rnd(C // 16, seed=5 + k, scale=0.1),
+                    rnd(C, C // 16, 1, 1, seed=7 + k, scale=0.2), rnd(C, seed=9 + k, scale=0.1)]
+    g1, g2 = rnd(N, C, H // 2, W // 2, seed=11), rnd(N, C, H // 2, W // 2, seed=12)
+
+    def run(fused):
+        r, d = rgb.cuda().requires_grad_(True), depth.cuda().requires_grad_(True)
+        p = [t.cuda().requires_grad_(True) for t in prm] if prm else None
+        if fused:
+            o, dp = ops.se_fuse_pool(r, d, p)
+        else:
+            o = ops.max_pool_3x3_s2(ops.se_fuse_blend(r, d, p))
+            dp = ops.max_pool_3x3_s2(d)
+        torch.autograd.backward([o, dp], [g1.cuda(), g2.cuda()])
+        return o.detach(), dp.detach(), r.grad, d.grad, [t.grad for t in p] if p else []
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert rel(a[2], b[2]) < 1e-5 and rel(a[3], b[3]) < 1e-5
+    for x, y in zip(a[4], b[4]):
+        assert rel(x, y) < 1e-4
+    a2 = run(True)                                               # bit-reproducible
+    for x, y in zip(a[2:4], a2[2:4]):
+        assert torch.equal(x, y)
