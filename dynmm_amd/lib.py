@@ -36,6 +36,7 @@ SIGNATURES = {
     'dynmm_packed_weight_floats': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'dynmm_pack_weight': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_pack_weight_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_pack_weight_multi_blocks': (c_i, [c_i] * 5),
     'dynmm_conv2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),

@@ -293,7 +293,7 @@ class PackedWeights:
             off += (ndg + 3) & ~3
             rows.append([(w.data_ptr() - base) // 4, dstf, dstd, Co | (Ci << 32), (KH * KW) | (blk << 32)])
             spans[id(w)] = (dstf, nf, dstd, ndg)
-            blk += -(-(nf + ndg) // 256)
+            blk += lib.dynmm_pack_weight_multi_blocks(Co, Ci, KH, KW, int(nd))
         self.arena = torch.empty(off, device=dev, dtype=torch.float32)
         self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.base, self.blocks = base, blk

@@ -65,8 +65,10 @@ int dynmm_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad,
 /* dynmm_pack_weight for many weights in one launch.  desc (device memory) = ndesc records of 5 int64 words:
  *   { src, dst_fwd, dst_dgrad (-1: none) : float offsets from src_base / dst_base ;
  *     Co | Ci << 32 ;  KH*KW | first_workgroup << 32 }
- * record d owns the workgroups [first_workgroup_d, first_workgroup_{d+1}) of 256 elements each, enough for its
- * dynmm_packed_weight_floats(.., 0) + (.., 1) output elements; total_blocks = their sum. */
+ * record d owns the workgroups [first_workgroup_d, first_workgroup_{d+1}), dynmm_pack_weight_multi_blocks(..) of them
+ * (32 x 32-channel tiles transposed through LDS for filters of up to 9 taps, 256 output elements per workgroup
+ * otherwise); total_blocks = their sum. */
+int dynmm_pack_weight_multi_blocks(int Co, int Ci, int KH, int KW, int dgrad);
 int dynmm_pack_weight_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
                             void* stream);
 
