@@ -99,6 +99,37 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     }
 }
 
+// The per-channel part of bn_apply_kernel on its own (training): batch statistics -> mean / invstd, running
+// statistics, step counter, and the affine pair scale = gamma*invstd, shift = beta - mean*scale that consumers apply on
+// load when the normalised tensor is never written (pointwise.hip: gap2 / axpby_pool kernels).
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd,
+                                                          long long* __restrict__ num_batches_tracked,
+                                                          float* __restrict__ scale, float* __restrict__ shift, int N, int C,
+                                                          int HW, float eps, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    const double M = (double)N * HW;
+    const double mu = sums[c] / M;
+    double var = sums[C + c] / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mu;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+        const double unb = var * (M / (M - 1.0));
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = fmaf(-mean, sc, beta[c]);
+}
+
 // sums[c] += sum g_eff ; sums[C+c] += sum g_eff * xhat
 template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
@@ -272,6 +303,21 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
         hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, st, x, sums, gamma, beta,
                            running_mean, running_var, save_mean, save_invstd, residual, y,
                            num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float* save_mean, float* save_invstd,
+                                 long long* num_batches_tracked, float* scale, float* shift, int N, int C, int HW,
+                                 float eps, float momentum, void* stream) {
+    (void)hipGetLastError();
+    if (!sums || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || N <= 0 || C <= 0 || HW <= 0 ||
+        (long long)N * HW <= 1)
+        return DYNMM_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, num_batches_tracked, scale, shift, N, C, HW, eps,
+                       momentum);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

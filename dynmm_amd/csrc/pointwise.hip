@@ -231,11 +231,16 @@ __global__ void __launch_bounds__(256) axpby_pool_fwd_kernel(const float* __rest
                                                              const float* __restrict__ ca, const float* __restrict__ cb,
                                                              float* __restrict__ yo, signed char* __restrict__ io,
                                                              float* __restrict__ yd, signed char* __restrict__ id, int H,
-                                                             int W, int Ho, int Wo) {
+                                                             int W, int Ho, int Wo, const float* __restrict__ tr, int C) {
     const size_t plane = blockIdx.x;
     const float* rp = xr + plane * (size_t)H * W;
     const float* dp = xd + plane * (size_t)H * W;
     const float fa = ca[plane], fb = cb[plane];
+    // tr = [4][C] {scale_r, shift_r, scale_d, shift_d}: xr / xd are the un-normalised stem conv outputs, BatchNorm +
+    // ReLU applied on load (gap2_kernel)
+    const int ch = tr ? (int)(plane % C) : 0;
+    const float scr = tr ? tr[ch] : 1.f, shr = tr ? tr[C + ch] : 0.f;
+    const float scd = tr ? tr[2 * C + ch] : 1.f, shd = tr ? tr[3 * C + ch] : 0.f;
     const int Wq = Wo / 4, nq = Ho * Wq;
     const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
     for (int q = beg + threadIdx.x; q < end; q += 256) {
@@ -252,11 +257,18 @@ __global__ void __launch_bounds__(256) axpby_pool_fwd_kernel(const float* __rest
             const float4 r0 = *reinterpret_cast<const float4*>(rp + o), r1 = *reinterpret_cast<const float4*>(rp + o + 4);
             const float4 d0 = *reinterpret_cast<const float4*>(dp + o), d1 = *reinterpret_cast<const float4*>(dp + o + 4);
             const float rl = t > 0 ? rp[o - 1] : 0.f, dl = t > 0 ? dp[o - 1] : 0.f;
-            const float rv[9] = {rl, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-            const float dv[9] = {dl, d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float rv[9] = {rl, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            float dv[9] = {dl, d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            if (tr) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    rv[k] = fmaxf(fmaf(rv[k], scr, shr), 0.f);
+                    dv[k] = fmaxf(fmaf(dv[k], scd, shd), 0.f);
+                }
+            }
             float fv[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) fv[k] = fa * rv[k] + fb * dv[k];         // axpby_fwd_kernel's expression
+            for (int k = 0; k < 9; ++k) fv[k] = fmaf(fa, rv[k], fb * dv[k]);     // axpby_fwd_kernel's expression
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -281,9 +293,13 @@ __global__ void __launch_bounds__(256) axpby_pool_bwd_reduce_kernel(const float*
                                                                     const signed char* __restrict__ io,
                                                                     const float* __restrict__ xr,
                                                                     const float* __restrict__ xd, float* __restrict__ da,
-                                                                    float* __restrict__ db, int H, int W, int Ho, int Wo) {
+                                                                    float* __restrict__ db, int H, int W, int Ho, int Wo,
+                                                                    const float* __restrict__ tr, int C) {
     __shared__ float red[4];
     const size_t plane = blockIdx.x;
+    const int ch = tr ? (int)(plane % C) : 0;
+    const float scr = tr ? tr[ch] : 1.f, shr = tr ? tr[C + ch] : 0.f;
+    const float scd = tr ? tr[2 * C + ch] : 1.f, shd = tr ? tr[3 * C + ch] : 0.f;
     const float* gp = go + plane * (size_t)Ho * Wo;
     const signed char* ip = io + plane * (size_t)Ho * Wo;
     const float* rp = xr + plane * (size_t)H * W;
@@ -297,8 +313,16 @@ __global__ void __launch_bounds__(256) axpby_pool_bwd_reduce_kernel(const float*
         const size_t o = (size_t)(2 * a) * W + 8 * t;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 r0 = *reinterpret_cast<const float4*>(rp + o + 4 * h), r1 = *reinterpret_cast<const float4*>(rp + o + W + 4 * h);
-            const float4 d0 = *reinterpret_cast<const float4*>(dp + o + 4 * h), d1 = *reinterpret_cast<const float4*>(dp + o + W + 4 * h);
+            float4 r0 = *reinterpret_cast<const float4*>(rp + o + 4 * h), r1 = *reinterpret_cast<const float4*>(rp + o + W + 4 * h);
+            float4 d0 = *reinterpret_cast<const float4*>(dp + o + 4 * h), d1 = *reinterpret_cast<const float4*>(dp + o + W + 4 * h);
+            if (tr) {
+#define DYNMM_BNRELU4(v, sc, sh) \
+    v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f); \
+    v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f)
+                DYNMM_BNRELU4(r0, scr, shr); DYNMM_BNRELU4(r1, scr, shr);
+                DYNMM_BNRELU4(d0, scd, shd); DYNMM_BNRELU4(d1, scd, shd);
+#undef DYNMM_BNRELU4
+            }
             sa += top[4 * h] * r0.x + top[4 * h + 1] * r0.y + top[4 * h + 2] * r0.z + top[4 * h + 3] * r0.w;
             sa += bot[4 * h] * r1.x + bot[4 * h + 1] * r1.y + bot[4 * h + 2] * r1.z + bot[4 * h + 3] * r1.w;
             sb += top[4 * h] * d0.x + top[4 * h + 1] * d0.y + top[4 * h + 2] * d0.z + top[4 * h + 3] * d0.w;
@@ -672,23 +696,28 @@ __global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // global average pool of two tensors; blend out = a*xr + b*xd and its backward passes
 // ------------------------------------------------------------------------------------------------
+// tr (optional) = [4][C] {scale_r, shift_r, scale_d, shift_d}: the inputs are BatchNorm+ReLU outputs that were never
+// written — relu(fma(x, scale, shift)) is applied on load (norm.hip: bn_apply_kernel's expression)
 template <int V>
 __global__ void __launch_bounds__(256) gap2_kernel(const float* __restrict__ xr,
                                                    const float* __restrict__ xd,
                                                    float* __restrict__ sr, float* __restrict__ sd,
-                                                   int HW) {
+                                                   int HW, const float* __restrict__ tr, int C) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * HW;
+    const int ch = tr ? (int)(blockIdx.x % C) : 0;
+    const float scr = tr ? tr[ch] : 1.f, shr = tr ? tr[C + ch] : 0.f;
+    const float scd = tr ? tr[2 * C + ch] : 1.f, shd = tr ? tr[3 * C + ch] : 0.f;
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
         float v[V];
         vload<V>(xr + base + i, v);
 #pragma unroll
-        for (int j = 0; j < V; ++j) a += v[j];
+        for (int j = 0; j < V; ++j) a += tr ? fmaxf(fmaf(v[j], scr, shr), 0.f) : v[j];
         if (xd) {
             vload<V>(xd + base + i, v);
 #pragma unroll
-            for (int j = 0; j < V; ++j) b += v[j];
+            for (int j = 0; j < V; ++j) b += tr ? fmaxf(fmaf(v[j], scd, shd), 0.f) : v[j];
         }
     }
     const float ta = block_reduce_sum_256<float>(a, red);
@@ -713,7 +742,7 @@ __global__ void __launch_bounds__(256) axpby_fwd_kernel(const float* __restrict_
         vload<V>(xr + base + i, r);
         vload<V>(xd + base + i, d);
 #pragma unroll
-        for (int j = 0; j < V; ++j) r[j] = ca * r[j] + cb * d[j];
+        for (int j = 0; j < V; ++j) r[j] = fmaf(ca, r[j], cb * d[j]);      // explicit: axpby_pool_fwd_kernel repeats it
         vstore<V>(out + base + i, r);
     }
 }
@@ -1004,15 +1033,29 @@ extern "C" int dynmm_upsample2x_dw3x3_bwd(const float* g, const float* x, const 
     return DYNMM_OK;
 }
 
+static int gap2_launch(const float* xr, const float* xd, float* sr, float* sd, int NC, int HW, const float* tr, int C,
+                       void* stream);
+
 extern "C" int dynmm_gap2_fwd(const float* xr, const float* xd, float* sr, float* sd, int NC, int HW,
                               void* stream) {
+    return gap2_launch(xr, xd, sr, sd, NC, HW, nullptr, 1, stream);
+}
+
+extern "C" int dynmm_gap2_bnrelu_fwd(const float* xr, const float* xd, const float* bn_tr, int C, float* sr, float* sd,
+                                     int NC, int HW, void* stream) {
+    if (!bn_tr || C <= 0 || NC % C != 0) return DYNMM_EINVAL;
+    return gap2_launch(xr, xd, sr, sd, NC, HW, bn_tr, C, stream);
+}
+
+static int gap2_launch(const float* xr, const float* xd, float* sr, float* sd, int NC, int HW, const float* tr, int C,
+                       void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!xr || !sr || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (xd && !sd) return DYNMM_EINVAL;
     if (can_vec4(HW, {xr, xd}))
-        hipLaunchKernelGGL(gap2_kernel<4>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW);
+        hipLaunchKernelGGL(gap2_kernel<4>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW, tr, C);
     else
-        hipLaunchKernelGGL(gap2_kernel<1>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW);
+        hipLaunchKernelGGL(gap2_kernel<1>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW, tr, C);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -1067,26 +1110,29 @@ static bool pool_fusable(int H, int W, int Ho, int Wo, std::initializer_list<con
 extern "C" int dynmm_axpby_pool_supported(int H, int W) { return (H > 0 && W > 0 && H % 2 == 0 && W % 8 == 0) ? 1 : 0; }
 
 extern "C" int dynmm_axpby_pool_fwd(const float* xr, const float* xd, const float* a, const float* b, float* y_out,
-                                    signed char* idx_out, float* y_depth, signed char* idx_depth, int NC, int H, int W,
-                                    void* stream) {
+                                    signed char* idx_out, float* y_depth, signed char* idx_depth, const float* bn_tr,
+                                    int C, int NC, int H, int W, void* stream) {
     (void)hipGetLastError();
     if (!xr || !xd || !a || !b || !y_out || !idx_out || !y_depth || !idx_depth || NC <= 0) return DYNMM_EINVAL;
+    if (bn_tr && (C <= 0 || NC % C != 0)) return DYNMM_EINVAL;
     const int Ho = H / 2, Wo = W / 2;
     if (!pool_fusable(H, W, Ho, Wo, {xr, xd, y_out, y_depth}, {idx_out, idx_depth})) return DYNMM_EUNSUPPORTED;
     hipLaunchKernelGGL(axpby_pool_fwd_kernel, dim3(NC, plane_chunks(Ho * Wo, kChunk)), dim3(256), 0, ST, xr, xd, a, b,
-                       y_out, idx_out, y_depth, idx_depth, H, W, Ho, Wo);
+                       y_out, idx_out, y_depth, idx_depth, H, W, Ho, Wo, bn_tr, C);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
 
 extern "C" int dynmm_axpby_pool_bwd_reduce(const float* g_out, const signed char* idx_out, const float* xr,
-                                           const float* xd, float* da, float* db, int NC, int H, int W, void* stream) {
+                                           const float* xd, float* da, float* db, const float* bn_tr, int C, int NC,
+                                           int H, int W, void* stream) {
     (void)hipGetLastError();
     if (!g_out || !idx_out || !xr || !xd || !da || !db || NC <= 0) return DYNMM_EINVAL;
+    if (bn_tr && (C <= 0 || NC % C != 0)) return DYNMM_EINVAL;
     const int Ho = H / 2, Wo = W / 2;
     if (!pool_fusable(H, W, Ho, Wo, {g_out, xr, xd}, {idx_out})) return DYNMM_EUNSUPPORTED;
     hipLaunchKernelGGL(axpby_pool_bwd_reduce_kernel, dim3(NC), dim3(256), 0, ST, g_out, idx_out, xr, xd, da, db, H, W,
-                       Ho, Wo);
+                       Ho, Wo, bn_tr, C);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -69,8 +69,10 @@ SIGNATURES = {
     'dynmm_axpby_bwd_reduce': (c_i, [c_f] * 5 + [c_i, c_i, c_f]),
     'dynmm_axpby_bwd_apply': (c_i, [c_f] * 5 + [c_fl, c_f, c_f, c_i, c_i, c_f]),
     'dynmm_axpby_pool_supported': (c_i, [c_i, c_i]),
-    'dynmm_axpby_pool_fwd': (c_i, [c_f] * 8 + [c_i] * 3 + [c_f]),
-    'dynmm_axpby_pool_bwd_reduce': (c_i, [c_f] * 6 + [c_i] * 3 + [c_f]),
+    'dynmm_axpby_pool_fwd': (c_i, [c_f] * 9 + [c_i] * 4 + [c_f]),
+    'dynmm_axpby_pool_bwd_reduce': (c_i, [c_f] * 7 + [c_i] * 4 + [c_f]),
+    'dynmm_gap2_bnrelu_fwd': (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 2 + [c_f]),
+    'dynmm_bn_finalize': (c_i, [c_f] * 10 + [c_i] * 3 + [c_fl, c_fl, c_f]),
     'dynmm_axpby_pool_bwd_apply': (c_i, [c_f] * 8 + [C.c_float] + [c_f] * 2 + [c_i] * 3 + [c_f]),
     'dynmm_reweigh_fwd': (c_i, [c_f, c_f, _PP, c_f, c_i, c_f, c_i, c_f, C.c_ulonglong, C.c_ulonglong, c_fl, c_i]
                           + [c_f] * 6 + [c_i, c_i, c_f]),

@@ -210,6 +210,18 @@ class SkipGateESANet(nn.Module):
         tab = self._flop_table(rgb.device)
         if self.training:
             ops.begin_step()
+        if ops.stem_bn_fuse_supported((rgb.shape[2] + 1) // 2, (rgb.shape[3] + 1) // 2, er.bn1, ed.bn1):
+            # training: stem BatchNorm + ReLU are applied on load by the fusion / pooling kernels (never written)
+            c_r, c_d = er.conv1, ed.conv1
+            r = ops.conv2d(rgb, c_r.weight, c_r.bias, c_r.stride, c_r.padding)
+            d = ops.conv2d(depth, c_d.weight, c_d.bias, c_d.stride, c_d.padding)
+            r, d = ops.stem_bn_fuse_pool(r, er.bn1, d, ed.bn1, self._se(0))
+        else:
+            r, d = self._stem_unfused(rgb, depth)
+        return self._forward_stages(rgb, r, d, tab, test, return_weight)
+
+    def _stem_unfused(self, rgb, depth):
+        er, ed = self.encoder_rgb, self.encoder_depth
         r = er.forward_first_conv(rgb)
         d = ed.forward_first_conv(depth)
         if ops.se_fuse_pool_supported(r):
@@ -220,7 +232,10 @@ class SkipGateESANet(nn.Module):
             fuse = ops.se_fuse_blend(r, d, self._se(0))
             r = ops.max_pool_3x3_s2(fuse)
             d = ops.max_pool_3x3_s2(d_pool)
+        return r, d
 
+    def _forward_stages(self, rgb, r, d, tab, test, return_weight):
+        er, ed = self.encoder_rgb, self.encoder_depth
         bs = r.shape[0]
         host_branch = None                                           # branch per sample when the host already knows it
         if self.baseline:                                            # …globalgate.py:264-266

@@ -937,7 +937,7 @@ class _SEFusePool(Function):
         io = torch.empty((N, Cc, Ho, Wo), device=rgb.device, dtype=torch.int8)
         idd = torch.empty_like(io)
         L.check(lib.dynmm_axpby_pool_fwd(_p(rgb), _p(depth), _p(a), _p(b), _p(yo), io.data_ptr(), _p(yd), idd.data_ptr(),
-                                         N * Cc, H, W, st), 'axpby_pool_fwd')
+                                         None, Cc, N * Cc, H, W, st), 'axpby_pool_fwd')
         ctx.use_se = use_se
         ctx.n_params = len(params)
         ctx.param_objs = list(params)
@@ -956,8 +956,8 @@ class _SEFusePool(Function):
         g_o = torch.zeros_like(io, dtype=torch.float32) if g_o is None else _chk(g_o, 'grad')
         g_d = torch.zeros_like(io, dtype=torch.float32) if g_d is None else _chk(g_d, 'grad')
         da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
-        L.check(lib.dynmm_axpby_pool_bwd_reduce(_p(g_o), io.data_ptr(), _p(rgb), _p(depth), _p(da), _p(db), N * Cc, H, W, st),
-                'axpby_pool_bwd_reduce')
+        L.check(lib.dynmm_axpby_pool_bwd_reduce(_p(g_o), io.data_ptr(), _p(rgb), _p(depth), _p(da), _p(db), None, Cc,
+                                                N * Cc, H, W, st), 'axpby_pool_bwd_reduce')
         dparams = dparams_ret = [None] * ctx.n_params
         dsr = dsd = None
         parr = dparr = None
@@ -976,7 +976,133 @@ class _SEFusePool(Function):
         return (drgb, ddepth, None, *dparams_ret)
 
 
-_FUSED_STEM_POOL = _os.environ.get('DYNMM_NO_FUSED_STEM_POOL') is None        # A/B switch
+class _StemBNFusePool(Function):
+    """Training form of the whole stem tail (resnet.py:229-231 BN + ReLU of both stems, …globalgate.py:258-261):
+        (max_pool(SE_rgb(y_r) + SE_depth(y_d)), max_pool(y_d)),   y = relu(batch_norm(x))
+    from the two stem CONV outputs x_r, x_d.  The normalised tensors y (2 x 629 MB at batch 32) are never written:
+    batch statistics -> dynmm_bn_finalize (mean / invstd / running statistics / scale, shift), then the squeeze and
+    the fused blend + pooling kernels apply relu(fma(x, scale, shift)) on load.  The backward first forms the
+    gradients of y (axpby_pool_bwd_*), then runs the ordinary BatchNorm backward kernels, which re-derive the ReLU
+    mask from x themselves."""
+
+    @staticmethod
+    def forward(ctx, xr, xd, gam_r, bet_r, rm_r, rv_r, nbt_r, gam_d, bet_d, rm_d, rv_d, nbt_d, mom_r, eps_r, mom_d,
+                eps_d, use_se, *params):
+        lib = _lib()
+        st = _stream()
+        xr, xd = _chk(xr, 'x_rgb'), _chk(xd, 'x_depth')
+        _same_shape(xr, xd, 'stem fusion')
+        N, Cc, H, W = xr.shape
+        HW = H * W
+        dev = xr.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        if N * HW <= 1:
+            raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(xr.shape)}')
+        note_mutation()
+        tr = torch.empty((4, Cc), **f32)                 # scale_r, shift_r, scale_d, shift_d
+        stats = torch.empty((4, Cc), **f32)              # mean_r, invstd_r, mean_d, invstd_d
+        for k, (x, gam, bet, rm, rv, nbt, mom, eps) in enumerate(((xr, gam_r, bet_r, rm_r, rv_r, nbt_r, mom_r, eps_r),
+                                                                  (xd, gam_d, bet_d, rm_d, rv_d, nbt_d, mom_d, eps_d))):
+            sums, zeroed = _zero_sums(2 * Cc, dev)
+            L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, zeroed, st), 'bn_stats')
+            L.check(lib.dynmm_bn_finalize(_p(sums), _p(gam), _p(bet), _p(rm), _p(rv), _p(stats[2 * k]), _p(stats[2 * k + 1]),
+                                          _p(nbt), _p(tr[2 * k]), _p(tr[2 * k + 1]), N, Cc, HW, eps, mom, st), 'bn_finalize')
+        sr = sd = hr = hd = gr = gd = None
+        parr = None
+        if use_se:
+            params = [_chk(p, 'se param') for p in params]
+            parr = _ptr_array(params)
+            sr, sd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+            L.check(lib.dynmm_gap2_bnrelu_fwd(_p(xr), _p(xd), _p(tr), Cc, _p(sr), _p(sd), N * Cc, HW, st), 'gap2_bnrelu')
+            hr, hd = torch.empty((N, Cc // 16), **f32), torch.empty((N, Cc // 16), **f32)
+            gr, gd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        a, b = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_se_coeff_fwd(_p(sr), _p(sd), parr, None, 0, _p(a), _p(b), _p(hr), _p(hd), _p(gr), _p(gd),
+                                       N, Cc, int(use_se), st), 'se_coeff_fwd')
+        Ho, Wo = H // 2, W // 2
+        yo, yd = torch.empty((N, Cc, Ho, Wo), **f32), torch.empty((N, Cc, Ho, Wo), **f32)
+        io = torch.empty((N, Cc, Ho, Wo), device=dev, dtype=torch.int8)
+        idd = torch.empty_like(io)
+        L.check(lib.dynmm_axpby_pool_fwd(_p(xr), _p(xd), _p(a), _p(b), _p(yo), io.data_ptr(), _p(yd), idd.data_ptr(),
+                                         _p(tr), Cc, N * Cc, H, W, st), 'axpby_pool_fwd')
+        ctx.use_se = use_se
+        ctx.n_params = len(params)
+        ctx.param_objs = list(params)
+        ctx.bn_params = (gam_r, bet_r, gam_d, bet_d)
+        ctx.save_for_backward(xr, xd, tr, stats, a, b, sr, sd, hr, hd, gr, gd, io, idd, gam_r, bet_r, gam_d, bet_d, *params)
+        return yo, yd
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        lib = _lib()
+        st = _stream()
+        xr, xd, tr, stats, a, b, sr, sd, hr, hd, gr, gd, io, idd, gam_r, bet_r, gam_d, bet_d = ctx.saved_tensors[:18]
+        params = list(ctx.saved_tensors[18:])
+        N, Cc, H, W = xr.shape
+        HW = H * W
+        dev = xr.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        g_o = torch.zeros_like(io, dtype=torch.float32) if g_o is None else _chk(g_o, 'grad')
+        g_d = torch.zeros_like(io, dtype=torch.float32) if g_d is None else _chk(g_d, 'grad')
+        da, db = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        L.check(lib.dynmm_axpby_pool_bwd_reduce(_p(g_o), io.data_ptr(), _p(xr), _p(xd), _p(da), _p(db), _p(tr), Cc,
+                                                N * Cc, H, W, st), 'axpby_pool_bwd_reduce')
+        dparams = dparams_ret = [None] * ctx.n_params
+        dsr = dsd = None
+        parr = dparr = None
+        if ctx.use_se:
+            pairs = [_grad_dst(po) for po in ctx.param_objs]
+            dparams, dparams_ret = [d for d, _ in pairs], [r for _, r in pairs]
+            parr, dparr = _ptr_array(params), _ptr_array(dparams)
+            dsr, dsd = torch.empty((N, Cc), **f32), torch.empty((N, Cc), **f32)
+        ws = torch.empty(lib.dynmm_se_coeff_bwd_workspace_bytes(N, Cc) // 4, **f32) if ctx.use_se else None
+        L.check(lib.dynmm_se_coeff_bwd(_p(da), _p(db), _p(sr), _p(sd), parr, None, 0, _p(hr), _p(hd), _p(gr), _p(gd),
+                                       dparr, _p(dsr), _p(dsd), None, 0, _p(ws), N, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
+        gy_r, gy_d = torch.empty_like(xr), torch.empty_like(xd)       # gradients of the (virtual) BN + ReLU outputs
+        L.check(lib.dynmm_axpby_pool_bwd_apply(_p(g_o), io.data_ptr(), _p(g_d), idd.data_ptr(), _p(a), _p(b), _p(dsr), _p(dsd),
+                                               1.0 / HW, _p(gy_r), _p(gy_d), N * Cc, H, W, st), 'axpby_pool_bwd_apply')
+        outs = []
+        for k, (x, gy, gam, bet, gp, bp) in enumerate(((xr, gy_r, gam_r, bet_r, ctx.bn_params[0], ctx.bn_params[1]),
+                                                       (xd, gy_d, gam_d, bet_d, ctx.bn_params[2], ctx.bn_params[3]))):
+            mean, invstd = stats[2 * k], stats[2 * k + 1]
+            sums, zeroed = _zero_sums(2 * Cc, dev)
+            L.check(lib.dynmm_bn_bwd_reduce(_p(gy), None, _p(x), _p(mean), _p(invstd), _p(gam), _p(bet), _p(sums),
+                                            N, Cc, HW, L.ACT_RELU, zeroed, st), 'bn_bwd_reduce')
+            dgamma, dgamma_ret = _grad_dst(gp)
+            dbeta, dbeta_ret = _grad_dst(bp)
+            # dx overwrites gy in place: element-wise, read-before-write per lane
+            L.check(lib.dynmm_bn_bwd_apply(_p(gy), None, _p(x), _p(mean), _p(invstd), _p(gam), _p(bet), _p(sums),
+                                           _p(gy), None, _p(dgamma), _p(dbeta), N, Cc, HW, 1, L.ACT_RELU, st), 'bn_bwd_apply')
+            outs.append((gy, dgamma_ret, dbeta_ret))
+        _grads_enqueued()
+        (dxr, dgr, dbr), (dxd, dgd, dbd) = outs
+        return (dxr, dxd, dgr, dbr, None, None, None, dgd, dbd, None, None, None, None, None, None, None, None,
+                *dparams_ret)
+
+
+def stem_bn_fuse_pool(x_rgb, bn_rgb, x_depth, bn_depth, se_params=None):
+    """see _StemBNFusePool; bn_* are the stems' nn.BatchNorm2d modules (training mode)."""
+    use_se = se_params is not None
+    for bn in (bn_rgb, bn_depth):
+        nbt = bn.num_batches_tracked
+        if nbt.dtype != torch.int64 or not nbt.is_cuda:
+            raise L.DynmmHipError('BatchNorm num_batches_tracked must be an int64 tensor on the HIP device')
+    return _StemBNFusePool.apply(x_rgb, x_depth, bn_rgb.weight, bn_rgb.bias, bn_rgb.running_mean, bn_rgb.running_var,
+                                 bn_rgb.num_batches_tracked, bn_depth.weight, bn_depth.bias, bn_depth.running_mean,
+                                 bn_depth.running_var, bn_depth.num_batches_tracked, float(bn_rgb.momentum),
+                                 float(bn_rgb.eps), float(bn_depth.momentum), float(bn_depth.eps), use_se,
+                                 *(tuple(se_params) if use_se else ()))
+
+
+_FUSED_STEM_POOL = _os.environ.get('DYNMM_NO_FUSED_STEM_POOL') is None        # A/B switches
+_FUSED_STEM_BN = _os.environ.get('DYNMM_NO_FUSED_STEM_BN') is None
+
+
+def stem_bn_fuse_supported(h, w, bn_a, bn_b):
+    """h, w: spatial size of the stem conv outputs"""
+    return _FUSED_STEM_BN and _FUSED_STEM_POOL and bool(_lib().dynmm_axpby_pool_supported(int(h), int(w))) and \
+        bn_a.training and bn_b.training and torch.is_grad_enabled() and bn_a.momentum is not None and \
+        bn_b.momentum is not None
 
 
 def se_fuse_pool_supported(x):

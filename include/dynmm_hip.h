@@ -139,6 +139,11 @@ int dynmm_bn_apply(const float* x, const double* sums, const float* gamma, const
                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                    const float* residual, float* y, long long* num_batches_tracked, int N, int C, int HW,
                    float eps, float momentum, int training, int act, void* stream);
+/* The per-channel part of dynmm_bn_apply alone (training mode): mean / invstd, running statistics (+ step counter),
+ * and scale = gamma*invstd, shift = beta - mean*scale for consumers that normalise on load. */
+int dynmm_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* save_mean, float* save_invstd, long long* num_batches_tracked,
+                      float* scale, float* shift, int N, int C, int HW, float eps, float momentum, void* stream);
 /* backward: sums[2*C] <- (sum g_eff, sum g_eff*xhat), g_eff = g*act'(y).
  * y may be NULL for act = ReLU when the forward had no residual: the mask [y > 0] is then re-derived from
  * x as fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0 — bit-identical to the forward's own evaluation
@@ -224,9 +229,15 @@ int dynmm_axpby_bwd_apply(const float* g, const float* a, const float* b,
  * Even H and W % 8 == 0 only (dynmm_axpby_pool_supported); DYNMM_EUNSUPPORTED otherwise (callers keep the unfused ops). */
 int dynmm_axpby_pool_supported(int H, int W);
 int dynmm_axpby_pool_fwd(const float* xr, const float* xd, const float* a, const float* b, float* y_out,
-                         signed char* idx_out, float* y_depth, signed char* idx_depth, int NC, int H, int W, void* stream);
+                         signed char* idx_out, float* y_depth, signed char* idx_depth, const float* bn_tr, int C,
+                         int NC, int H, int W, void* stream);
 int dynmm_axpby_pool_bwd_reduce(const float* g_out, const signed char* idx_out, const float* xr, const float* xd,
-                                float* da, float* db, int NC, int H, int W, void* stream);
+                                float* da, float* db, const float* bn_tr, int C, int NC, int H, int W, void* stream);
+/* bn_tr (optional, [4][C] = scale_r, shift_r, scale_d, shift_d from dynmm_bn_finalize): xr / xd are the stem conv
+ * outputs BEFORE their BatchNorm + ReLU (resnet.py:229-231), which the kernels apply on load — the normalised
+ * 629 MB tensors are then never written either.  dynmm_gap2_bnrelu_fwd: the SE squeeze of the same virtual tensors. */
+int dynmm_gap2_bnrelu_fwd(const float* xr, const float* xd, const float* bn_tr, int C, float* sr, float* sd, int NC,
+                          int HW, void* stream);
 int dynmm_axpby_pool_bwd_apply(const float* g_out, const signed char* idx_out, const float* g_depth,
                                const signed char* idx_depth, const float* a, const float* b, const float* ca,
                                const float* cb, float cscale, float* dxr, float* dxd, int NC, int H, int W, void* stream);

@@ -535,3 +535,50 @@ def test_se_fuse_pool_equals_unfused_ops(ops, use_se, shape):
     a2 = run(True)                                               # bit-reproducible
     for x, y in zip(a[2:4], a2[2:4]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('use_se', [True, False])
+def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
+    """_StemBNFusePool: stem BatchNorm + ReLU applied on load by the squeeze / blend + pooling kernels (the normalised
+    tensors never written) against batch_norm_act x 2 -> se_fuse_blend -> max_pool x 2: outputs, running statistics
+    and step counters bit-identical, gradients to summation order."""
+    import torch.nn as nn
+    N, C, H, W = 3, 32, 12, 16
+    xr0, xd0 = rnd(N, C, H, W, seed=1, scale=2.0), rnd(N, C, H, W, seed=2, scale=1.5) + 0.3
+    prm = None
+    if use_se:
+        prm = []
+        for k in range(2):
+            prm += [rnd(C // 16, C, 1, 1, seed=3 + k, scale=0.2), rnd(C // 16, seed=5 + k, scale=0.1),
+                    rnd(C, C // 16, 1, 1, seed=7 + k, scale=0.2), rnd(C, seed=9 + k, scale=0.1)]
+    g1, g2 = rnd(N, C, H // 2, W // 2, seed=11), rnd(N, C, H // 2, W // 2, seed=12)
+
+    def run(fused):
+        bns = []
+        for k in range(2):
+            bn = nn.BatchNorm2d(C, eps=1e-5 if k == 0 else 1e-3).cuda().train()
+            with torch.no_grad():
+                bn.weight.copy_(rnd(C, seed=20 + k).abs() + 0.5)
+                bn.bias.copy_(rnd(C, seed=22 + k, scale=0.3))
+                bn.running_mean.copy_(rnd(C, seed=24 + k, scale=0.1))
+            bns.append(bn)
+        xr, xd = xr0.cuda().requires_grad_(True), xd0.cuda().requires_grad_(True)
+        p = [t.cuda().requires_grad_(True) for t in prm] if prm else None
+        if fused:
+            assert ops.stem_bn_fuse_supported(H, W, *bns)
+            o, dp = ops.stem_bn_fuse_pool(xr, bns[0], xd, bns[1], p)
+        else:
+            yr, yd = ops.batch_norm_act(xr, bns[0], 'relu'), ops.batch_norm_act(xd, bns[1], 'relu')
+            yd1, yd2 = ops.fan_out(yd, 2)
+            o = ops.max_pool_3x3_s2(ops.se_fuse_blend(yr, yd1, p))
+            dp = ops.max_pool_3x3_s2(yd2)
+        torch.autograd.backward([o, dp], [g1.cuda(), g2.cuda()])
+        bufs = [t.detach().clone() for bn in bns for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
+        grads = [xr.grad, xd.grad] + [t.grad for bn in bns for t in (bn.weight, bn.bias)] + ([t.grad for t in p] if p else [])
+        return o.detach(), dp.detach(), bufs, grads
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
+    for i, (x, y) in enumerate(zip(a[3], b[3])):
+        assert rel(x, y) < 2e-4, i
