@@ -357,16 +357,16 @@ __global__ void __launch_bounds__(256) axpby_pool_bwd_apply_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // (axpby_bwd_apply_kernel's expressions; the pooled-depth gradient is added last, as add_n did)
-            *reinterpret_cast<float4*>(rp + o + 4 * h) = make_float4(fa * ft[4 * h] + oa, fa * ft[4 * h + 1] + oa,
-                                                                      fa * ft[4 * h + 2] + oa, fa * ft[4 * h + 3] + oa);
-            *reinterpret_cast<float4*>(rp + o + W + 4 * h) = make_float4(fa * fbm[4 * h] + oa, fa * fbm[4 * h + 1] + oa,
-                                                                          fa * fbm[4 * h + 2] + oa, fa * fbm[4 * h + 3] + oa);
+            *reinterpret_cast<float4*>(rp + o + 4 * h) = make_float4(fmaf(fa, ft[4 * h], oa), fmaf(fa, ft[4 * h + 1], oa),
+                                                                      fmaf(fa, ft[4 * h + 2], oa), fmaf(fa, ft[4 * h + 3], oa));
+            *reinterpret_cast<float4*>(rp + o + W + 4 * h) = make_float4(fmaf(fa, fbm[4 * h], oa), fmaf(fa, fbm[4 * h + 1], oa),
+                                                                          fmaf(fa, fbm[4 * h + 2], oa), fmaf(fa, fbm[4 * h + 3], oa));
             *reinterpret_cast<float4*>(dp + o + 4 * h) =
-                make_float4((fb * ft[4 * h] + ob) + dt[4 * h], (fb * ft[4 * h + 1] + ob) + dt[4 * h + 1],
-                            (fb * ft[4 * h + 2] + ob) + dt[4 * h + 2], (fb * ft[4 * h + 3] + ob) + dt[4 * h + 3]);
+                make_float4(fmaf(fb, ft[4 * h], ob) + dt[4 * h], fmaf(fb, ft[4 * h + 1], ob) + dt[4 * h + 1],
+                            fmaf(fb, ft[4 * h + 2], ob) + dt[4 * h + 2], fmaf(fb, ft[4 * h + 3], ob) + dt[4 * h + 3]);
             *reinterpret_cast<float4*>(dp + o + W + 4 * h) =
-                make_float4((fb * fbm[4 * h] + ob) + dbm[4 * h], (fb * fbm[4 * h + 1] + ob) + dbm[4 * h + 1],
-                            (fb * fbm[4 * h + 2] + ob) + dbm[4 * h + 2], (fb * fbm[4 * h + 3] + ob) + dbm[4 * h + 3]);
+                make_float4(fmaf(fb, fbm[4 * h], ob) + dbm[4 * h], fmaf(fb, fbm[4 * h + 1], ob) + dbm[4 * h + 1],
+                            fmaf(fb, fbm[4 * h + 2], ob) + dbm[4 * h + 2], fmaf(fb, fbm[4 * h + 3], ob) + dbm[4 * h + 3]);
         }
     }
 }
@@ -1099,6 +1099,121 @@ extern "C" int dynmm_axpby_bwd_apply(const float* g, const float* a, const float
     return DYNMM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward of a stem whose output gradient is never written either (ops._StemBNFusePool):
+//   gy = coef[plane] * pool_bwd(go, io) + off[plane]*cscale (+ pool_bwd(gd, id))      (axpby_pool_bwd_apply's rows)
+//   g_eff = gy * [fma(x, sc, sh) > 0]                                                  (the stem's ReLU, mask from x)
+//   reduce: sums[c] += sum g_eff, sums[C+c] += sum g_eff * xhat        apply: dx = gamma*invstd*(g_eff - m1 - xhat*m2)
+// i.e. bn_bwd_reduce / bn_bwd_apply (norm.hip) with their gradient operand derived block by block from the pooled
+// gradients: 3 passes over a 629 MB tensor per stem instead of 6 (+1 shared).
+// ------------------------------------------------------------------------------------------------
+struct StemBnArgs {
+    const float* go; const signed char* io;        // pooled gradient / codes of the fused map
+    const float* gd; const signed char* id;        // ... of the pooled depth map (NULL for the RGB stem)
+    const float* coef; const float* off; float cscale;
+    const float* x; const float* mean; const float* invstd; const float* gamma; const float* beta;
+    int N, C, H, W, Ho, Wo;
+};
+
+__device__ __forceinline__ void stem_gy_block(const StemBnArgs& a, size_t plane, int ar, int t, float fc, float fo,
+                                              float (&top)[8], float (&bot)[8]) {
+    const size_t po = plane * (size_t)a.Ho * a.Wo;
+    pool_bwd_block(a.go + po, a.io + po, ar, t, a.Ho, a.Wo, top, bot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { top[k] = fmaf(fc, top[k], fo); bot[k] = fmaf(fc, bot[k], fo); }
+    if (a.gd) {
+        float dt[8], db[8];
+        pool_bwd_block(a.gd + po, a.id + po, ar, t, a.Ho, a.Wo, dt, db);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { top[k] += dt[k]; bot[k] += db[k]; }
+    }
+}
+
+__global__ void __launch_bounds__(256) stem_bn_bwd_reduce_kernel(const StemBnArgs a, double* __restrict__ sums) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, S = gridDim.y;
+    const float mu = a.mean[c], is = a.invstd[c];
+    const float sc = a.gamma[c] * is;
+    const float sh = fmaf(-mu, sc, a.beta[c]);
+    const int Wq = a.Wo / 4, nq = a.Ho * Wq;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = blockIdx.y; n < a.N; n += S) {
+        const size_t plane = (size_t)n * a.C + c;
+        const float fc = a.coef[plane], fo = a.off ? a.off[plane] * a.cscale : 0.f;
+        const float* xp = a.x + plane * (size_t)a.H * a.W;
+        float a1 = 0.f, a2 = 0.f;
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const int ar = q / Wq, t = q - ar * Wq;
+            float top[8], bot[8];
+            stem_gy_block(a, plane, ar, t, fc, fo, top, bot);
+            const size_t o = (size_t)(2 * ar) * a.W + 8 * t;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 x0 = *reinterpret_cast<const float4*>(xp + o + 4 * h);
+                const float4 x1 = *reinterpret_cast<const float4*>(xp + o + a.W + 4 * h);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float gy = k < 4 ? top[4 * h + k] : bot[4 * h + k - 4];
+                    const float ge = fmaf(xv[k], sc, sh) > 0.f ? gy : 0.f;
+                    a1 += ge;
+                    a2 += ge * (xv[k] - mu) * is;
+                }
+            }
+        }
+        s1 += a1; s2 += a2;
+    }
+    const float t1 = block_reduce_sum_256<float>(s1, red);
+    const float t2 = block_reduce_sum_256<float>(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], (double)t1);
+        atomicAdd(&sums[a.C + c], (double)t2);
+    }
+}
+
+__global__ void __launch_bounds__(256) stem_bn_bwd_apply_kernel(const StemBnArgs a, const double* __restrict__ sums,
+                                                                float* __restrict__ dx, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+    const size_t plane = blockIdx.x;
+    const int c = (int)(plane % a.C);
+    const float mu = a.mean[c], is = a.invstd[c];
+    const float sc = a.gamma[c] * is;
+    const float sh = fmaf(-mu, sc, a.beta[c]);
+    const float sg = (float)sums[c], sgx = (float)sums[a.C + c];
+    if (plane < (size_t)a.C && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = sgx;
+        if (dbeta) dbeta[c] = sg;
+    }
+    const float invM = 1.f / ((float)a.N * (float)(a.H * a.W));
+    const float k0 = sc, m1 = sg * invM, m2 = sgx * invM;
+    const float fc = a.coef[plane], fo = a.off ? a.off[plane] * a.cscale : 0.f;
+    const float* xp = a.x + plane * (size_t)a.H * a.W;
+    float* dp = dx + plane * (size_t)a.H * a.W;
+    const int Wq = a.Wo / 4, nq = a.Ho * Wq;
+    const int beg = blockIdx.y * (kChunk / 4), end = min(nq, beg + kChunk / 4);
+    for (int q = beg + threadIdx.x; q < end; q += 256) {
+        const int ar = q / Wq, t = q - ar * Wq;
+        float top[8], bot[8];
+        stem_gy_block(a, plane, ar, t, fc, fo, top, bot);
+        const size_t o = (size_t)(2 * ar) * a.W + 8 * t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 x0 = *reinterpret_cast<const float4*>(xp + o + 4 * h);
+            const float4 x1 = *reinterpret_cast<const float4*>(xp + o + a.W + 4 * h);
+            const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            float ov[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gy = k < 4 ? top[4 * h + k] : bot[4 * h + k - 4];
+                const float ge = fmaf(xv[k], sc, sh) > 0.f ? gy : 0.f;
+                ov[k] = k0 * (ge - m1 - (xv[k] - mu) * is * m2);
+            }
+            *reinterpret_cast<float4*>(dp + o + 4 * h) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            *reinterpret_cast<float4*>(dp + o + a.W + 4 * h) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+        }
+    }
+}
+
 static bool pool_fusable(int H, int W, int Ho, int Wo, std::initializer_list<const void*> p16,
                          std::initializer_list<const void*> p4) {
     if (H % 2 != 0 || W % 8 != 0 || Ho != H / 2 || Wo != W / 2) return false;
@@ -1147,6 +1262,53 @@ extern "C" int dynmm_axpby_pool_bwd_apply(const float* g_out, const signed char*
     if (!pool_fusable(H, W, Ho, Wo, {g_out, g_depth, dxr, dxd}, {idx_out, idx_depth})) return DYNMM_EUNSUPPORTED;
     hipLaunchKernelGGL(axpby_pool_bwd_apply_kernel, dim3(NC, plane_chunks(Ho * Wo, kChunk)), dim3(256), 0, ST, g_out,
                        idx_out, g_depth, idx_depth, a, b, ca, cb, cscale, dxr, dxd, H, W, Ho, Wo);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+static int stem_bn_args(StemBnArgs& a, const float* g_out, const signed char* idx_out, const float* g_depth,
+                        const signed char* idx_depth, const float* coef, const float* off, float cscale, const float* x,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta, int N, int C, int H,
+                        int W) {
+    if (!g_out || !idx_out || !coef || !x || !mean || !invstd || !gamma || !beta || N <= 0 || C <= 0) return DYNMM_EINVAL;
+    if ((g_depth != nullptr) != (idx_depth != nullptr)) return DYNMM_EINVAL;
+    const int Ho = H / 2, Wo = W / 2;
+    if (!pool_fusable(H, W, Ho, Wo, {g_out, g_depth, x}, {idx_out, idx_depth})) return DYNMM_EUNSUPPORTED;
+    a = StemBnArgs{g_out, idx_out, g_depth, idx_depth, coef, off, cscale, x, mean, invstd, gamma, beta, N, C, H, W, Ho, Wo};
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_stem_bn_bwd_reduce(const float* g_out, const signed char* idx_out, const float* g_depth,
+                                        const signed char* idx_depth, const float* coef, const float* off, float cscale,
+                                        const float* x, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, double* sums, int N, int C, int H, int W, int sums_are_zero,
+                                        void* stream) {
+    (void)hipGetLastError();
+    StemBnArgs a;
+    const int rc = stem_bn_args(a, g_out, idx_out, g_depth, idx_depth, coef, off, cscale, x, mean, invstd, gamma, beta, N, C,
+                                H, W);
+    if (rc != DYNMM_OK || !sums) return rc != DYNMM_OK ? rc : DYNMM_EINVAL;
+    if (!sums_are_zero) DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ST));
+    int S = 2048 / C;
+    S = S < 1 ? 1 : (S > N ? N : S);
+    hipLaunchKernelGGL(stem_bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, ST, a, sums);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_stem_bn_bwd_apply(const float* g_out, const signed char* idx_out, const float* g_depth,
+                                       const signed char* idx_depth, const float* coef, const float* off, float cscale,
+                                       const float* x, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta,
+                                       int N, int C, int H, int W, void* stream) {
+    (void)hipGetLastError();
+    StemBnArgs a;
+    const int rc = stem_bn_args(a, g_out, idx_out, g_depth, idx_depth, coef, off, cscale, x, mean, invstd, gamma, beta, N, C,
+                                H, W);
+    if (rc != DYNMM_OK || !sums || !dx) return rc != DYNMM_OK ? rc : DYNMM_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dx) & 15u) return DYNMM_EUNSUPPORTED;
+    hipLaunchKernelGGL(stem_bn_bwd_apply_kernel, dim3(N * C, plane_chunks(a.Ho * a.Wo, kChunk)), dim3(256), 0, ST, a, sums,
+                       dx, dgamma, dbeta);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -71,6 +71,8 @@ SIGNATURES = {
     'dynmm_axpby_pool_supported': (c_i, [c_i, c_i]),
     'dynmm_axpby_pool_fwd': (c_i, [c_f] * 9 + [c_i] * 4 + [c_f]),
     'dynmm_axpby_pool_bwd_reduce': (c_i, [c_f] * 7 + [c_i] * 4 + [c_f]),
+    'dynmm_stem_bn_bwd_reduce': (c_i, [c_f] * 6 + [c_fl] + [c_f] * 6 + [c_i] * 5 + [c_f]),
+    'dynmm_stem_bn_bwd_apply': (c_i, [c_f] * 6 + [c_fl] + [c_f] * 9 + [c_i] * 4 + [c_f]),
     'dynmm_gap2_bnrelu_fwd': (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 2 + [c_f]),
     'dynmm_bn_finalize': (c_i, [c_f] * 10 + [c_i] * 3 + [c_fl, c_fl, c_f]),
     'dynmm_axpby_pool_bwd_apply': (c_i, [c_f] * 8 + [C.c_float] + [c_f] * 2 + [c_i] * 3 + [c_f]),

@@ -1058,22 +1058,23 @@ class _StemBNFusePool(Function):
         ws = torch.empty(lib.dynmm_se_coeff_bwd_workspace_bytes(N, Cc) // 4, **f32) if ctx.use_se else None
         L.check(lib.dynmm_se_coeff_bwd(_p(da), _p(db), _p(sr), _p(sd), parr, None, 0, _p(hr), _p(hd), _p(gr), _p(gd),
                                        dparr, _p(dsr), _p(dsd), None, 0, _p(ws), N, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
-        gy_r, gy_d = torch.empty_like(xr), torch.empty_like(xd)       # gradients of the (virtual) BN + ReLU outputs
-        L.check(lib.dynmm_axpby_pool_bwd_apply(_p(g_o), io.data_ptr(), _p(g_d), idd.data_ptr(), _p(a), _p(b), _p(dsr), _p(dsd),
-                                               1.0 / HW, _p(gy_r), _p(gy_d), N * Cc, H, W, st), 'axpby_pool_bwd_apply')
+        # BatchNorm backward of both stems with their incoming gradient derived on the fly from the pooled gradients
+        # (dynmm_stem_bn_bwd_*): gy_rgb = a * d(fuse) + dsr/HW ; gy_depth = b * d(fuse) + dsd/HW + d(pooled depth)
         outs = []
-        for k, (x, gy, gam, bet, gp, bp) in enumerate(((xr, gy_r, gam_r, bet_r, ctx.bn_params[0], ctx.bn_params[1]),
-                                                       (xd, gy_d, gam_d, bet_d, ctx.bn_params[2], ctx.bn_params[3]))):
+        for k, (x, coef, off, gdp, idp, gam, bet, gp, bp) in enumerate((
+                (xr, a, dsr, None, None, gam_r, bet_r, ctx.bn_params[0], ctx.bn_params[1]),
+                (xd, b, dsd, g_d, idd, gam_d, bet_d, ctx.bn_params[2], ctx.bn_params[3]))):
             mean, invstd = stats[2 * k], stats[2 * k + 1]
             sums, zeroed = _zero_sums(2 * Cc, dev)
-            L.check(lib.dynmm_bn_bwd_reduce(_p(gy), None, _p(x), _p(mean), _p(invstd), _p(gam), _p(bet), _p(sums),
-                                            N, Cc, HW, L.ACT_RELU, zeroed, st), 'bn_bwd_reduce')
+            head = (_p(g_o), io.data_ptr(), _p(gdp), None if idp is None else idp.data_ptr(), _p(coef), _p(off), 1.0 / HW,
+                    _p(x), _p(mean), _p(invstd), _p(gam), _p(bet))
+            L.check(lib.dynmm_stem_bn_bwd_reduce(*head, _p(sums), N, Cc, H, W, zeroed, st), 'stem_bn_bwd_reduce')
             dgamma, dgamma_ret = _grad_dst(gp)
             dbeta, dbeta_ret = _grad_dst(bp)
-            # dx overwrites gy in place: element-wise, read-before-write per lane
-            L.check(lib.dynmm_bn_bwd_apply(_p(gy), None, _p(x), _p(mean), _p(invstd), _p(gam), _p(bet), _p(sums),
-                                           _p(gy), None, _p(dgamma), _p(dbeta), N, Cc, HW, 1, L.ACT_RELU, st), 'bn_bwd_apply')
-            outs.append((gy, dgamma_ret, dbeta_ret))
+            dx = torch.empty_like(x)
+            L.check(lib.dynmm_stem_bn_bwd_apply(*head, _p(sums), _p(dx), _p(dgamma), _p(dbeta), N, Cc, H, W, st),
+                    'stem_bn_bwd_apply')
+            outs.append((dx, dgamma_ret, dbeta_ret))
         _grads_enqueued()
         (dxr, dgr, dbr), (dxd, dgd, dbd) = outs
         return (dxr, dxd, dgr, dbr, None, None, None, dgd, dbd, None, None, None, None, None, None, None, None,

@@ -238,6 +238,19 @@ int dynmm_axpby_pool_bwd_reduce(const float* g_out, const signed char* idx_out, 
  * 629 MB tensors are then never written either.  dynmm_gap2_bnrelu_fwd: the SE squeeze of the same virtual tensors. */
 int dynmm_gap2_bnrelu_fwd(const float* xr, const float* xd, const float* bn_tr, int C, float* sr, float* sd, int NC,
                           int HW, void* stream);
+/* BatchNorm(+ReLU) backward of a stem whose output gradient is never written (the training backward of the chain above):
+ *   gy = coef[n,c] * max_pool_backward(g_out, idx_out) + off[n,c]*cscale (+ max_pool_backward(g_depth, idx_depth)),
+ * i.e. the rows of dynmm_axpby_pool_bwd_apply, fed block by block into dynmm_bn_bwd_reduce / _apply's arithmetic
+ * (ReLU mask re-derived from x).  g_depth / idx_depth / off may be NULL. */
+int dynmm_stem_bn_bwd_reduce(const float* g_out, const signed char* idx_out, const float* g_depth,
+                             const signed char* idx_depth, const float* coef, const float* off, float cscale,
+                             const float* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, double* sums, int N, int C, int H, int W, int sums_are_zero, void* stream);
+int dynmm_stem_bn_bwd_apply(const float* g_out, const signed char* idx_out, const float* g_depth,
+                            const signed char* idx_depth, const float* coef, const float* off, float cscale,
+                            const float* x, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta,
+                            int N, int C, int H, int W, void* stream);
 int dynmm_axpby_pool_bwd_apply(const float* g_out, const signed char* idx_out, const float* g_depth,
                                const signed char* idx_depth, const float* a, const float* b, const float* ca,
                                const float* cb, float cscale, float* dxr, float* dxd, int NC, int H, int W, void* stream);
