@@ -1414,8 +1414,18 @@ extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const 
     return launch_igemm<true>(a, (hipStream_t)stream);
 }
 
+static size_t generic_wgrad_workspace_bytes(const dynmm_conv_geom* g);
+
 extern "C" size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    // (the stem kernel is chosen at call time only when no bias gradient is asked for: size for either path)
+    const size_t stem = stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split < g->Ci, false)
+                            ? stem_conv_wgrad_workspace_bytes(g->N, g->Ci, g->Ho, g->Wo) : 0;
+    const size_t gen = generic_wgrad_workspace_bytes(g);
+    return stem > gen ? stem : gen;
+}
+
+static size_t generic_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
     const WgradPlan p = plan_wgrad(g);
     if (p.splits <= 1) return 0;
     // [splits][Co*K] weight-gradient slabs, then [splits][Co] bias-gradient slabs (16-byte aligned start)
@@ -1429,8 +1439,14 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !dy || !dw || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (x2 != nullptr)) return DYNMM_EINVAL;
+    if (stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, x2 != nullptr, dbias != nullptr) &&
+        ((reinterpret_cast<uintptr_t>(dy) & 15u) == 0)) {
+        const size_t need_s = stem_conv_wgrad_workspace_bytes(g->N, g->Ci, g->Ho, g->Wo);
+        if (!workspace || workspace_bytes < need_s) return DYNMM_EWORKSPACE;
+        return launch_stem_conv_wgrad(x, dy, dw, (float*)workspace, g->N, g->Ci, g->H, g->W, g->Ho, g->Wo, (hipStream_t)stream);
+    }
     const WgradPlan p = plan_wgrad(g);
-    const size_t need = dynmm_conv2d_wgrad_workspace_bytes(g);
+    const size_t need = generic_wgrad_workspace_bytes(g);
     if (need > 0 && (!workspace || workspace_bytes < need)) return DYNMM_EWORKSPACE;
     WgradArgs a{};
     a.x = x; a.x2 = x2; a.dy = dy;

@@ -14,6 +14,18 @@ struct SmallConvArgs {
     int N, Ci, H, W, Co, Ho, Wo, KH, KW, SH, SW, PH, PW, c_split, CiR, CoP, act;
 };
 
+struct StemWgradArgs {
+    const float* x;
+    const float* dy;
+    float* slabs;           // [workgroups][64][k-tiles * 32] partial weight gradients
+    int N, H, W, Ho, Wo;
+};
+
+bool stem_conv_wgrad_eligible(int Ci, int Co, int KH, int KW, int SH, int SW, int PH, int PW, bool has_x2, bool has_bias);
+size_t stem_conv_wgrad_workspace_bytes(int N, int Ci, int Ho, int Wo);
+int launch_stem_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int Ci, int H, int W,
+                           int Ho, int Wo, hipStream_t st);
+
 bool small_conv_fwd_eligible(const SmallConvArgs& a, const float* residual);
 int launch_small_conv_fwd(const SmallConvArgs& a, hipStream_t st);
 bool stem_conv_fwd_eligible(const SmallConvArgs& a, const float* residual);

@@ -17,6 +17,12 @@
 
 namespace dynmm {
 
+// DYNMM_NO_SMALL_CO = 1 | gate | stem | stemw : A/B switch back to the implicit-GEMM kernels
+static bool small_off_early(const char* which) {
+    const char* v = getenv("DYNMM_NO_SMALL_CO");
+    return v && (strcmp(v, which) == 0 || strcmp(v, "1") == 0);
+}
+
 constexpr int kSP = 5;                // output pixels per lane (consecutive along W)
 constexpr int kSRows = 4;             // output rows per workgroup
 constexpr int kSColGroups = 16;       // lanes along W
@@ -280,10 +286,194 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
     }
 }
 
-// DYNMM_NO_SMALL_CO = 1 | gate | stem : A/B switch back to the implicit-GEMM kernels
-static bool small_off(const char* which) {
-    const char* v = getenv("DYNMM_NO_SMALL_CO");
-    return v && (strcmp(v, which) == 0 || strcmp(v, "1") == 0);
+static bool small_off(const char* which) { return small_off_early(which); }
+
+// ---- stem weight gradient: the forward's LDS-patch scheme with the pixel axis as the MFMA reduction -------------
+// dW[co][k] = sum_pix dY[co][pix] * X[k][pix], k = (ci, kh, kw8).  A = dY (lane: channel l31, pixel parity khalf) from
+// an LDS tile [co][pixel] (odd pitch), B = X (lane: k-row l31, pixel parity khalf) = patch[koff(k) + pixel offset]: each
+// lane keeps the patch offset of its k-rows, the pixel part is a compile-time immediate.  A workgroup owns 2 output
+// rows x 64 columns of one image per step and is persistent; wave w accumulates channel tile w & 1 x its share of the
+// k-tiles (3 of 6 for Ci = 3, 1 of 2 for Ci = 1) over ALL of its tiles in registers and writes one partial slab;
+// stem_wgrad_finish sums the slabs in a fixed order and drops the padded tap column.
+template <int CI>
+__global__ void __launch_bounds__(256, CI == 1 ? 4 : 2) conv_stem_wgrad_kernel(const StemWgradArgs a) {
+    constexpr int KS = 7, S = 2, PAD = 3, KW8 = 8;
+    constexpr int TRW = 2, TCW = 64, NPX = TRW * TCW;         // pixel tile
+    constexpr int IR = (TRW - 1) * S + KS;                    // 9 input rows
+    constexpr int ICP = (TCW - 1) * S + KW8 + 1;              // 135
+    constexpr int KT = CI * KS * KW8;                         // 168 / 56 real k-rows
+    constexpr int NKT = (KT + 31) / 32;                       // 6 / 2 k-tiles
+    constexpr int KPW = NKT / 2;                              // k-tiles per wave (3 / 1)
+    constexpr int PP = NPX + 1;                               // dY tile pitch (odd: conflict-free channel-strided reads)
+    __shared__ float patch[CI * IR * ICP];
+    __shared__ float dyt[64 * PP];
+
+    const int lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int cot = wave & 1, kt0 = (wave >> 1) * KPW;
+    const int tw = (a.Wo + TCW - 1) / TCW, th = (a.Ho + TRW - 1) / TRW;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int tiles = a.N * th * tw;
+
+    int boff[KPW];                                            // patch offset of the lane's k-row in each of its k-tiles
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        int k = (kt0 + j) * 32 + l31;
+        if (k >= KT) k = 0;                                   // padding rows of the last k-tile: any mapped address
+        const int ci = k / (KS * KW8), rem = k - ci * (KS * KW8);
+        boff[j] = (ci * IR + (rem >> 3)) * ICP + (rem & 7) + S * khalf;
+    }
+    const float* ab = dyt + (cot * 32 + l31) * PP + khalf;
+    f32x16 acc[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        int b = tile;
+        const int n = b / (th * tw);
+        b -= n * th * tw;
+        const int oh0 = (b / tw) * TRW, ow0 = (b - (b / tw) * tw) * TCW;
+        const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        __syncthreads();                                      // previous tile's MFMA phase is done with both buffers
+        {
+            constexpr int NIT = (CI * IR * ICP + 255) / 256;
+            float sv[NIT];
+            const float* xn = a.x + (size_t)n * CI * HW;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = it * 256 + threadIdx.x;
+                const int ci = min(e / (IR * ICP), CI - 1), rem = e - ci * (IR * ICP);
+                const int rr = rem / ICP, cc = rem - rr * ICP;
+                const int ih = ih0 + rr, iw = iw0 + cc;
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                const float v = xn[(size_t)ci * HW + (size_t)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)];
+                sv[it] = ok ? v : 0.f;
+            }
+            // dY tile: 64 channels x (2 rows x 64 cols), 16-byte loads where the row allows it
+            float4 dv[8];
+            const float* dn = a.dy + (size_t)n * 64 * HoWo;
+            const bool vec = (a.Wo & 3) == 0;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int i4 = it * 256 + threadIdx.x;
+                const int co = i4 >> 5, q = i4 & 31, r = q >> 4, c4 = (q & 15) * 4;
+                const int oh = oh0 + r, ow = ow0 + c4;
+                const float* src = dn + (size_t)co * HoWo + (size_t)min(oh, a.Ho - 1) * a.Wo;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oh < a.Ho) {
+                    if (vec && ow + 3 < a.Wo) v = *reinterpret_cast<const float4*>(src + ow);
+                    else {
+                        if (ow < a.Wo) v.x = src[ow];
+                        if (ow + 1 < a.Wo) v.y = src[ow + 1];
+                        if (ow + 2 < a.Wo) v.z = src[ow + 2];
+                        if (ow + 3 < a.Wo) v.w = src[ow + 3];
+                    }
+                }
+                dv[it] = v;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = it * 256 + threadIdx.x;
+                if (e < CI * IR * ICP) patch[e] = sv[it];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int i4 = it * 256 + threadIdx.x;
+                const int co = i4 >> 5, q = i4 & 31;
+                float* dst = dyt + co * PP + q * 4;
+                dst[0] = dv[it].x; dst[1] = dv[it].y; dst[2] = dv[it].z; dst[3] = dv[it].w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPX / 2; ++ps) {                // pixel pair (2ps, 2ps+1): same output row
+            const int row = (2 * ps) / TCW, col = (2 * ps) % TCW;
+            const int poff = S * row * ICP + S * col;
+            const float av = ab[2 * ps];
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const float bv = patch[boff[j] + poff];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // partial slab of this workgroup: slab[co][k], k < NKT*32
+    float* slab = a.slabs + (size_t)blockIdx.x * 64 * (NKT * 32);
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = cot * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+            slab[(size_t)co * (NKT * 32) + (kt0 + j) * 32 + l31] = acc[j][e];
+        }
+}
+
+// dw[co][ci][kh][kw] = sum over slabs (ascending) of slab[co][(ci*7 + kh)*8 + kw]
+__global__ void __launch_bounds__(256) stem_wgrad_finish_kernel(const float* __restrict__ slabs, int nslabs, int kpad,
+                                                                int CI, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per_co = CI * 49;
+    if (i >= 64 * per_co) return;
+    const int co = i / per_co, rem = i - co * per_co;
+    const int ci = rem / 49, t = rem - ci * 49;
+    const int k = (ci * 7 + t / 7) * 8 + t % 7;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const size_t stride = (size_t)64 * kpad;
+    const float* p = slabs + (size_t)co * kpad + k;
+    int sl = 0;
+    for (; sl + 3 < nslabs; sl += 4) {
+        s0 += p[(size_t)sl * stride];
+        s1 += p[(size_t)(sl + 1) * stride];
+        s2 += p[(size_t)(sl + 2) * stride];
+        s3 += p[(size_t)(sl + 3) * stride];
+    }
+    for (; sl < nslabs; ++sl) s0 += p[(size_t)sl * stride];
+    dw[i] = (s0 + s1) + (s2 + s3);
+}
+
+static int stem_wgrad_grid(long tiles, int Ci) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const long cap = (long)cus * (Ci == 1 ? 4 : 2);        // resident workgroups per CU (registers: 112 / 210 VGPRs)
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+bool stem_conv_wgrad_eligible(int Ci, int Co, int KH, int KW, int SH, int SW, int PH, int PW, bool has_x2, bool has_bias) {
+    static const bool off = small_off_early("stemw");
+    if (off || has_x2 || has_bias) return false;
+    if (KH != 7 || KW != 7 || SH != 2 || SW != 2 || PH != 3 || PW != 3) return false;
+    return (Ci == 1 || Ci == 3) && Co == 64;
+}
+
+size_t stem_conv_wgrad_workspace_bytes(int N, int Ci, int Ho, int Wo) {
+    const long tiles = (long)N * ceil_div(Ho, 2) * ceil_div(Wo, 64);
+    const int kpad = ((Ci * 56 + 31) / 32) * 32;
+    return sizeof(float) * (size_t)stem_wgrad_grid(tiles, Ci) * 64 * kpad;
+}
+
+int launch_stem_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int Ci, int H, int W,
+                           int Ho, int Wo, hipStream_t st) {
+    const long tiles = (long)N * ceil_div(Ho, 2) * ceil_div(Wo, 64);
+    if (tiles > 0x7fffffffL) return DYNMM_EUNSUPPORTED;
+    const int grid = stem_wgrad_grid(tiles, Ci);
+    const int kpad = ((Ci * 56 + 31) / 32) * 32;
+    StemWgradArgs a{x, dy, workspace, N, H, W, Ho, Wo};
+    if (Ci == 3)
+        hipLaunchKernelGGL((conv_stem_wgrad_kernel<3>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_stem_wgrad_kernel<1>), dim3(grid), dim3(256), 0, st, a);
+    DYNMM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3(ceil_div(64 * Ci * 49, 256)), dim3(256), 0, st, workspace, grid, kpad,
+                       Ci, dw);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
 }
 
 bool stem_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
