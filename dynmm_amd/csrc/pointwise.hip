@@ -1099,6 +1099,8 @@ extern "C" int dynmm_axpby_bwd_apply(const float* g, const float* a, const float
     return DYNMM_OK;
 }
 
+namespace dynmm {
+
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward of a stem whose output gradient is never written either (ops._StemBNFusePool):
 //   gy = coef[plane] * pool_bwd(go, io) + off[plane]*cscale (+ pool_bwd(gd, id))      (axpby_pool_bwd_apply's rows)
@@ -1213,6 +1215,8 @@ __global__ void __launch_bounds__(256) stem_bn_bwd_apply_kernel(const StemBnArgs
         }
     }
 }
+
+}  // namespace dynmm
 
 static bool pool_fusable(int H, int W, int Ho, int Wo, std::initializer_list<const void*> p16,
                          std::initializer_list<const void*> p4) {
