@@ -900,8 +900,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 //     instructions before).
 // Eligible: one input tensor, Ci % 64 == 0, Co > 64, stride 1 along W with 'same' padding and KW in {1, 3},
 // W % 4 == 0, (Ho*Wo) % 4 == 0, 16-byte aligned x / dy.  Everything else stays on conv_wgrad_kernel.
+// Up to 4 weight gradients of identical geometry in ONE launch (dynmm_conv2d_wgrad_group): the workgroups of problem p are
+// [p*per, (p+1)*per).  A launch holds one residency round whatever the number of problems, so each workgroup walks a
+// nprob-times longer pixel range of its problem: the fixed costs of a launch (cold prologue, slab burst, tail) and the slab
+// traffic are paid once per group instead of once per convolution.
+struct WgradGroup {
+    const float* x[4];
+    const float* dy[4];
+    float* out[4];
+    float* out_bias[4];
+    int nprob, per;
+};
+
 template <int TCO, int TK, int NBUF>
-__global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a_in, const WgradGroup grp) {
+    WgradArgs a = a_in;
     // NBUF = 2: double-buffered tiles, one barrier per step (72 KB of LDS per workgroup: fastest when the kernel has
     // the GPU to itself).  NBUF = 1: 36 KB, two barriers per step — leaves LDS for the workgroups of the other
     // streams' kernels (the training step runs the weight gradients beside the dgrad / BatchNorm chain).
@@ -917,7 +930,15 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
     const int wave_co = wave / WAVES_K, wave_k = wave % WAVES_K;
     const int khalf = lane >> 5, l31 = lane & 31;
     const int n_tiles = a.n_co_tiles * a.n_k_tiles;          // XCD-aware order, see conv_wgrad_kernel
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    if (grp.nprob > 1) {
+        const int p = lin / grp.per;
+        lin -= p * grp.per;
+        a.x = grp.x[p];
+        a.dy = grp.dy[p];
+        a.out = grp.out[p];
+        a.out_bias = grp.out_bias[p];
+    }
     const int tile = lin % n_tiles;
     const int co0 = (tile % a.n_co_tiles) * TCO;
     const int k0 = (tile / a.n_co_tiles) * TK;
@@ -1091,12 +1112,28 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
 // out[(co*Ci + ci)*KHKW + tap] = sum_s slabs[s][co*K + tap*Ci + ci], fixed order (4 slab groups in flight per
 // column, combined through LDS like reduce_slabs_kernel); each lane owns 4 consecutive ci (Ci % 4 == 0).
 // Workgroups >= nb1 reduce the optional bias-gradient slabs (plain layout).
+// grp (grouped launches, dynmm_conv2d_wgrad_group): blockIdx.y selects the problem's slabs / destinations.
+struct ReduceGroup {
+    const float* slabs[4];
+    float* out[4];
+    const float* slabs2[4];
+    float* out2[4];
+    int nprob;
+};
+
 __global__ void __launch_bounds__(256) reduce_slabs_perm_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 int n, int nslabs, int Ci, int KHKW, int K,
                                                                 const float* __restrict__ slabs2,
-                                                                float* __restrict__ out2, int n2, int nb1) {
+                                                                float* __restrict__ out2, int n2, int nb1,
+                                                                const ReduceGroup grp) {
     __shared__ float part[4][64][4];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (grp.nprob > 0) {
+        slabs = grp.slabs[blockIdx.y];
+        out = grp.out[blockIdx.y];
+        slabs2 = grp.slabs2[blockIdx.y];
+        out2 = grp.out2[blockIdx.y];
+    }
     int bx = blockIdx.x;
     const bool second = bx >= nb1;
     if (second) { bx -= nb1; slabs = slabs2; out = out2; n = n2; }
@@ -1479,15 +1516,15 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     if (v4) {
         static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
         if (v4_nbuf == 2)
-            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, WgradGroup{});
         else
-            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a, WgradGroup{});
         DYNMM_LAUNCH_CHECK();
         if (perm) {
             const int n = g->Co * a.K, nb1 = ceil_div(n / 4, 64), nb2 = dbias ? ceil_div(g->Co / 4, 64) : 0;
             hipLaunchKernelGGL(reduce_slabs_perm_kernel, dim3(nb1 + nb2), dim3(256), 0, st, (const float*)workspace, dw,
                                n, p.splits, g->Ci, g->KH * g->KW, a.K, dbias ? bias_slabs : nullptr, dbias,
-                               dbias ? g->Co : 0, nb1);
+                               dbias ? g->Co : 0, nb1, ReduceGroup{});
             DYNMM_LAUNCH_CHECK();
             return DYNMM_OK;
         }
@@ -1518,6 +1555,116 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
                             dbias, dbias ? g->Co : 0);
         DYNMM_LAUNCH_CHECK();
     }
+    return DYNMM_OK;
+}
+
+// ---- grouped weight gradients --------------------------------------------------------------------------------------
+static bool wgrad_v4_shape_ok(const dynmm_conv_geom* g, const WgradPlan& p) {
+    static const int no_v4 = env_int("DYNMM_WGRAD_NO_V4");
+    return !no_v4 && g->c_split == g->Ci && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
+           (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
+           ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH && (g->Co % 4 == 0);
+}
+
+// the plan of n same-shape problems sharing one residency round
+static WgradPlan plan_wgrad_group(const dynmm_conv_geom* g, int n) {
+    WgradPlan p = plan_wgrad(g);
+    const int total_steps = ceil_div(g->N * g->Ho * g->Wo, 32);
+    const int tiles = p.n_co_tiles * p.n_k_tiles * n;
+    int splits = 512 / tiles;
+    if (splits < 1) splits = 1;
+    const int max_splits = ceil_div(total_steps, 8);
+    if (splits > max_splits) splits = max_splits;
+    p.steps_per_split = ceil_div(total_steps, splits);
+    p.splits = ceil_div(total_steps, p.steps_per_split);
+    return p;
+}
+
+static size_t group_problem_floats(const dynmm_conv_geom* g, const WgradPlan& p) {
+    const size_t wslab = ((size_t)p.splits * g->Co * g->Ci * g->KH * g->KW + 3) & ~(size_t)3;
+    return (wslab + (size_t)p.splits * g->Co + 3) & ~(size_t)3;
+}
+
+extern "C" int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g) {
+    static const int off = env_int("DYNMM_NO_WGRAD_GROUP");
+    if (off || !geom_ok(g)) return 0;
+    const WgradPlan p = plan_wgrad(g);
+    return (wgrad_v4_shape_ok(g, p) && p.splits > 1) ? 1 : 0;
+}
+
+extern "C" size_t dynmm_conv2d_wgrad_group_workspace_bytes(const dynmm_conv_geom* g, int n) {
+    if (!geom_ok(g) || n < 1 || n > 4) return 0;
+    if (n == 1 || !dynmm_conv2d_wgrad_groupable(g)) return dynmm_conv2d_wgrad_workspace_bytes(g);
+    const WgradPlan p = plan_wgrad_group(g, n);
+    return sizeof(float) * group_problem_floats(g, p) * (size_t)n;
+}
+
+extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const float* const* dys, float* const* dws,
+                                        float* const* dbiases, void* workspace, size_t workspace_bytes,
+                                        const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (n < 1 || n > 4 || !xs || !dys || !dws || !geom_ok(g)) return DYNMM_EINVAL;
+    bool aligned = (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
+    for (int i = 0; i < n; ++i) {
+        if (!xs[i] || !dys[i] || !dws[i]) return DYNMM_EINVAL;
+        aligned = aligned && ((reinterpret_cast<uintptr_t>(xs[i]) | reinterpret_cast<uintptr_t>(dys[i])) & 15u) == 0 &&
+                  (!dbiases || !dbiases[i] || (reinterpret_cast<uintptr_t>(dbiases[i]) & 15u) == 0);
+        if (dbiases && ((dbiases[i] != nullptr) != (dbiases[0] != nullptr))) return DYNMM_EINVAL;      // all or none
+    }
+    if (n == 1 || !aligned || !dynmm_conv2d_wgrad_groupable(g)) {       // one ordinary launch per problem
+        for (int i = 0; i < n; ++i) {
+            const int rc = dynmm_conv2d_wgrad(xs[i], nullptr, dys[i], dws[i], dbiases ? dbiases[i] : nullptr, workspace,
+                                              workspace_bytes, g, stream);
+            if (rc != DYNMM_OK) return rc;
+        }
+        return DYNMM_OK;
+    }
+    const WgradPlan p = plan_wgrad_group(g, n);
+    const size_t per_floats = group_problem_floats(g, p);
+    if (!workspace || workspace_bytes < sizeof(float) * per_floats * (size_t)n) return DYNMM_EWORKSPACE;
+    const bool has_bias = dbiases && dbiases[0];
+    const size_t wslab = ((size_t)p.splits * g->Co * g->Ci * g->KH * g->KW + 3) & ~(size_t)3;
+    WgradArgs a{};
+    WgradGroup grp{};
+    grp.nprob = n;
+    grp.per = p.n_co_tiles * p.n_k_tiles * p.splits;
+    for (int i = 0; i < n; ++i) {
+        float* base = (float*)workspace + per_floats * (size_t)i;
+        grp.x[i] = xs[i];
+        grp.dy[i] = dys[i];
+        grp.out[i] = base;
+        grp.out_bias[i] = has_bias ? base + wslab : nullptr;
+    }
+    a.x = xs[0]; a.x2 = nullptr; a.dy = dys[0]; a.out = grp.out[0]; a.out_bias = grp.out_bias[0];
+    a.N = g->N; a.Ci = g->Ci; a.H = g->H; a.W = g->W; a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo;
+    a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    a.c_split = g->c_split;
+    a.M = g->N * g->Ho * g->Wo;
+    a.K = g->KH * g->KW * g->Ci;
+    a.n_co_tiles = p.n_co_tiles; a.n_k_tiles = p.n_k_tiles; a.steps_per_split = p.steps_per_split;
+    a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
+    a.k_major_out = 1;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(grp.per * n));
+    static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
+    if (v4_nbuf == 2)
+        hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, grp);
+    else
+        hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a, grp);
+    DYNMM_LAUNCH_CHECK();
+    const int nel = g->Co * a.K, nb1 = ceil_div(nel / 4, 64), nb2 = has_bias ? ceil_div(g->Co / 4, 64) : 0;
+    ReduceGroup rg{};
+    rg.nprob = n;
+    for (int i = 0; i < n; ++i) {
+        rg.slabs[i] = grp.out[i];
+        rg.out[i] = dws[i];
+        rg.slabs2[i] = has_bias ? grp.out_bias[i] : nullptr;
+        rg.out2[i] = has_bias ? dbiases[i] : nullptr;
+    }
+    hipLaunchKernelGGL(reduce_slabs_perm_kernel, dim3(nb1 + nb2, n), dim3(256), 0, st, (const float*)nullptr, (float*)nullptr,
+                       nel, p.splits, g->Ci, g->KH * g->KW, a.K, (const float*)nullptr, (float*)nullptr,
+                       has_bias ? g->Co : 0, nb1, rg);
+    DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
 

@@ -175,7 +175,10 @@ def direct_gradients(async_wgrad):
     try:
         yield
     finally:
-        ops.DIRECT_GRAD, ops.ASYNC_WGRAD = saved
+        try:
+            ops.flush_wgrad_groups()         # nothing queued may outlive the protocol's scope
+        finally:
+            ops.DIRECT_GRAD, ops.ASYNC_WGRAD = saved
 
 
 class TrainStep:

@@ -41,6 +41,9 @@ SIGNATURES = {
     'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),
     'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
+    'dynmm_conv2d_wgrad_groupable': (c_i, [_GP]),
+    'dynmm_conv2d_wgrad_group_workspace_bytes': (c_sz, [_GP, c_i]),
+    'dynmm_conv2d_wgrad_group': (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv_bf16x3_eligible': (c_i, [_GP, c_i]),
     'dynmm_pack_weight_bf16': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_conv2d_fwd_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),

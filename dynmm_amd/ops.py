@@ -99,11 +99,68 @@ def _wgrad_stream():
 
 
 def join_async():
+    flush_wgrad_groups()
     if _INFLIGHT:
         cur = torch.cuda.current_stream()
         for s in _WGRAD_POOL:
             cur.wait_stream(s)
     _INFLIGHT.clear()
+
+
+# Grouped weight gradients (dynmm_conv2d_wgrad_group): under the in-place gradient protocol a convolution's weight
+# gradient is queued by geometry instead of launched; WGRAD_GROUP same-shape problems (the factorised convs of
+# consecutive residual blocks, RGB and depth encoder alike) go out as ONE launch.  Queues are flushed by join_async()
+# at the end of backward at the latest; the parameters are reported to the gradient reducer when their launch is
+# actually enqueued.
+WGRAD_GROUP = int(_os.environ.get('DYNMM_WGRAD_GROUP', '4'))
+_WGRAD_QUEUES = {}
+
+
+def _queue_wgrad(g, x, gy, w_param, b_param):
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, b_param is not None)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())              # gy is produced on this stream
+    q = _WGRAD_QUEUES.setdefault(key, [])
+    q.append((g, x, gy, w_param, b_param, ev))
+    if len(q) >= WGRAD_GROUP:
+        _flush_wgrad_queue(key)
+
+
+def _flush_wgrad_queue(key):
+    q = _WGRAD_QUEUES.pop(key, None)
+    if not q:
+        return
+    lib = _lib()
+    g = q[0][0]
+    n = len(q)
+    use_async = ASYNC_WGRAD and PROFILE is None
+    stream = _wgrad_stream() if use_async else torch.cuda.current_stream()
+    for item in q:
+        stream.wait_event(item[5])
+    dws = [_grad_dst(item[3])[0] for item in q]
+    dbs = [_grad_dst(item[4])[0] for item in q] if q[0][4] is not None else None
+    nbytes = lib.dynmm_conv2d_wgrad_group_workspace_bytes(C.byref(g), n)
+    with torch.cuda.stream(stream):
+        ws = torch.empty(max(nbytes // 4, 1), device=q[0][1].device, dtype=torch.float32)
+        xs = (C.c_void_p * n)(*[item[1].data_ptr() for item in q])
+        dys = (C.c_void_p * n)(*[item[2].data_ptr() for item in q])
+        dwa = (C.c_void_p * n)(*[t.data_ptr() for t in dws])
+        dba = (C.c_void_p * n)(*[t.data_ptr() for t in dbs]) if dbs is not None else None
+
+        def call():
+            return lib.dynmm_conv2d_wgrad_group(n, xs, dys, dwa, dba, _p(ws), nbytes, C.byref(g), stream.cuda_stream)
+        if PROFILE is not None:
+            L.check(_timed('wgrad', g, call, n), 'conv2d_wgrad_group')
+        else:
+            L.check(call(), 'conv2d_wgrad_group')
+    if use_async:
+        _INFLIGHT.append(tuple(t for item in q for t in (item[1], item[2])))
+    _grads_enqueued(stream)
+
+
+def flush_wgrad_groups():
+    for key in list(_WGRAD_QUEUES):
+        _flush_wgrad_queue(key)
 
 
 # Bookkeeping of the in-place gradient protocol.  Every backward that writes a parameter gradient straight
@@ -124,6 +181,12 @@ def touched_reset():
 
 def touched_ids():
     return frozenset(_TOUCHED)
+
+
+def _direct_ok(param):
+    """_grad_dst(param) would hand out the parameter's own .grad view"""
+    return DIRECT_GRAD and param is not None and getattr(param, 'grad', None) is not None and \
+        param.grad.is_contiguous() and param.grad.dtype == torch.float32
 
 
 def _grad_dst(param, like=None):
@@ -166,7 +229,7 @@ def _tile(co, m=1 << 30):
 _SMALL_DIRECT = _os.environ.get('DYNMM_NO_SMALL_CO') is None
 
 
-def _timed(kind, g, call):
+def _timed(kind, g, call, nprob=1):
     if PROFILE is None:
         return call()
     co = g.Ci if kind == 'dgrad' else g.Co
@@ -186,7 +249,7 @@ def _timed(kind, g, call):
             name = 'conv_co8_fwd<direct,valu>'
         elif k7 and g.Ci in (1, 3) and g.Co == 64 and g.c_split == g.Ci:
             name = f'conv_stem_fwd<ci{g.Ci},mfma>'
-    flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co      # algorithmic (= forward MACs x2)
+    flops = 2.0 * g.N * g.Ho * g.Wo * g.KH * g.KW * g.Ci * g.Co * nprob      # algorithmic (= forward MACs x2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = call()
@@ -393,7 +456,11 @@ class _Conv2d(Function):
         # The bias gradient (sum of the masked gy over pixels) rides along with the weight-gradient kernel,
         # which stages every gy tile anyway; only when the weights take no gradient does it need its own pass.
         bias_in_wgrad = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.has_bias:
+        # queued for a grouped launch (in-place gradient protocol only: the gradients go straight into .grad views)
+        defer = (ctx.needs_input_grad[2] and DIRECT_GRAD and WGRAD_GROUP > 1 and x2 is None and
+                 _direct_ok(ctx.w_param) and (not ctx.has_bias or _direct_ok(ctx.b_param)) and
+                 bool(lib.dynmm_conv2d_wgrad_groupable(C.byref(g))))
+        if ctx.has_bias and not (defer and bias_in_wgrad):
             dbias, dbias_ret = _grad_dst(ctx.b_param)
         if act != L.ACT_NONE or (ctx.has_bias and not bias_in_wgrad):
             ge = torch.empty_like(gy) if act != L.ACT_NONE else None
@@ -421,7 +488,9 @@ class _Conv2d(Function):
                                                                           _p(dx2), C.byref(g), st)), 'conv2d_dgrad')
         dw_ret = None
         ws_stream = None
-        if ctx.needs_input_grad[2]:
+        if defer:
+            _queue_wgrad(g, x, gy, ctx.w_param, ctx.b_param if bias_in_wgrad else None)
+        elif ctx.needs_input_grad[2]:
             dw, dw_ret = _grad_dst(ctx.w_param)
             nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
             if ASYNC_WGRAD and dw_ret is None and PROFILE is None:

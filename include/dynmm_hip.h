@@ -99,6 +99,17 @@ int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* 
                        void* workspace, size_t workspace_bytes,
                        const dynmm_conv_geom* g, void* stream);
 
+/* Weight gradients of n <= 4 convolutions of IDENTICAL geometry (e.g. the factorised convs of consecutive residual
+ * blocks) in one launch: one residency round whatever n is, so every workgroup walks an n-times longer pixel range and
+ * the per-launch fixed costs and the split-K slab traffic are paid once per group.  xs / dys / dws / dbiases: host arrays
+ * of n device pointers (dbiases NULL, or all entries set / all NULL).  Falls back to n ordinary launches when the
+ * geometry is not groupable (dynmm_conv2d_wgrad_groupable: the vectorised 128x128 kernel, single input). */
+int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g);
+size_t dynmm_conv2d_wgrad_group_workspace_bytes(const dynmm_conv_geom* g, int n);
+int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const float* const* dys, float* const* dws,
+                             float* const* dbiases, void* workspace, size_t workspace_bytes,
+                             const dynmm_conv_geom* g, void* stream);
+
 /* ---- split-precision variant (csrc/conv_bf16x3.hip) ----
  * fp32 tensors; every operand is split on the fly into `nsplit` bf16 pieces and the piece products with
  * p+q < nsplit are accumulated in fp32 on v_mfma_f32_32x32x16_bf16:
