@@ -610,8 +610,22 @@ struct WgradArgs {
     int k_major_out;       // v4 slabs: out[co][k] with k = tap*Ci + ci (128-byte store runs); permuted by the slab reduction
 };
 
+// Up to 8 weight gradients of identical geometry in ONE launch (dynmm_conv2d_wgrad_group): the workgroups of problem p are
+// [p*per, (p+1)*per).  A launch holds one residency round whatever the number of problems, so each workgroup walks a
+// nprob-times longer pixel range of its problem: the fixed costs of a launch (cold prologue, slab burst, tail) and the slab
+// traffic are paid once per group instead of once per convolution.
+constexpr int kWgradGroupMax = 8;
+struct WgradGroup {
+    const float* x[kWgradGroupMax];
+    const float* dy[kWgradGroupMax];
+    float* out[kWgradGroupMax];
+    float* out_bias[kWgradGroupMax];
+    int nprob, per;
+};
+
 template <int TCO, int TK, int WCO, int WK, bool DUAL, bool FAST>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a_in, const WgradGroup grp) {
+    WgradArgs a = a_in;
     static_assert(!(DUAL && FAST), "FAST is the single-input, Ci % 64 == 0 specialisation");
     constexpr int BP = 32, LDP = BP + 1;     // +1 pad: column reads of the [row][pixel] tiles
     constexpr int MCO = WCO / 32, MK = WK / 32;
@@ -632,7 +646,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
     // the other tiles (PMC, round 2: with blockIdx.x = tile the k-tiles of a split sat on different XCDs and every one
     // of them re-fetched dy: 2 x FETCH_SIZE = 2.2 x the algorithmic bytes).
     const int n_tiles = a.n_co_tiles * a.n_k_tiles;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    if (grp.nprob > 1) {                                     // grouped launch: problem p owns workgroups [p*per, (p+1)*per)
+        const int p = lin / grp.per;
+        lin -= p * grp.per;
+        a.x = grp.x[p];
+        a.dy = grp.dy[p];
+        a.out = grp.out[p];
+        a.out_bias = grp.out_bias[p];
+    }
     const int tile = lin % n_tiles;
     const int co0 = (tile % a.n_co_tiles) * TCO;
     const int k0 = (tile / a.n_co_tiles) * TK;
@@ -900,18 +922,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a) {
 //     instructions before).
 // Eligible: one input tensor, Ci % 64 == 0, Co > 64, stride 1 along W with 'same' padding and KW in {1, 3},
 // W % 4 == 0, (Ho*Wo) % 4 == 0, 16-byte aligned x / dy.  Everything else stays on conv_wgrad_kernel.
-// Up to 4 weight gradients of identical geometry in ONE launch (dynmm_conv2d_wgrad_group): the workgroups of problem p are
-// [p*per, (p+1)*per).  A launch holds one residency round whatever the number of problems, so each workgroup walks a
-// nprob-times longer pixel range of its problem: the fixed costs of a launch (cold prologue, slab burst, tail) and the slab
-// traffic are paid once per group instead of once per convolution.
-struct WgradGroup {
-    const float* x[4];
-    const float* dy[4];
-    float* out[4];
-    float* out_bias[4];
-    int nprob, per;
-};
-
 template <int TCO, int TK, int NBUF>
 __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a_in, const WgradGroup grp) {
     WgradArgs a = a_in;
@@ -1114,10 +1124,10 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
 // Workgroups >= nb1 reduce the optional bias-gradient slabs (plain layout).
 // grp (grouped launches, dynmm_conv2d_wgrad_group): blockIdx.y selects the problem's slabs / destinations.
 struct ReduceGroup {
-    const float* slabs[4];
-    float* out[4];
-    const float* slabs2[4];
-    float* out2[4];
+    const float* slabs[8];
+    float* out[8];
+    const float* slabs2[8];
+    float* out2[8];
     int nprob;
 };
 
@@ -1451,6 +1461,30 @@ extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const 
     return launch_igemm<true>(a, (hipStream_t)stream);
 }
 
+static void launch_wgrad_generic(const WgradArgs& a, const WgradGroup& grp, const WgradPlan& p, dim3 grid, bool dual,
+                                 bool fast, hipStream_t st) {
+#define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
+    do {                                                                                              \
+        if (dual)                                                                                     \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, true, false>), grid, dim3(256), 0, st, a, grp);  \
+        else if (fast)                                                                                \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false, true>), grid, dim3(256), 0, st, a, grp);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false, false>), grid, dim3(256), 0, st, a, grp); \
+    } while (0)
+    if (p.tco == 128)
+        DYNMM_WGRAD_LAUNCH(128, 128, 64, 64);
+    else if (p.tco == 64 && p.tk == 192)
+        DYNMM_WGRAD_LAUNCH(64, 192, 32, 96);
+    else if (p.tco == 64 && p.tk == 64)
+        DYNMM_WGRAD_LAUNCH(64, 64, 32, 32);
+    else if (p.tco == 64)
+        DYNMM_WGRAD_LAUNCH(64, 128, 64, 32);
+    else
+        DYNMM_WGRAD_LAUNCH(32, 128, 32, 32);
+#undef DYNMM_WGRAD_LAUNCH
+}
+
 static size_t generic_wgrad_workspace_bytes(const dynmm_conv_geom* g);
 
 extern "C" size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
@@ -1529,26 +1563,7 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
             return DYNMM_OK;
         }
     } else
-#define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
-    do {                                                                                              \
-        if (dual)                                                                                     \
-            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, true, false>), grid, dim3(256), 0, st, a);  \
-        else if (fast)                                                                                \
-            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false, true>), grid, dim3(256), 0, st, a);  \
-        else                                                                                          \
-            hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TK, WCO, WK, false, false>), grid, dim3(256), 0, st, a); \
-    } while (0)
-    if (p.tco == 128)
-        DYNMM_WGRAD_LAUNCH(128, 128, 64, 64);
-    else if (p.tco == 64 && p.tk == 192)
-        DYNMM_WGRAD_LAUNCH(64, 192, 32, 96);
-    else if (p.tco == 64 && p.tk == 64)
-        DYNMM_WGRAD_LAUNCH(64, 64, 32, 32);
-    else if (p.tco == 64)
-        DYNMM_WGRAD_LAUNCH(64, 128, 64, 32);
-    else
-        DYNMM_WGRAD_LAUNCH(32, 128, 32, 32);
-#undef DYNMM_WGRAD_LAUNCH
+        launch_wgrad_generic(a, WgradGroup{}, p, grid, dual, fast, st);
     DYNMM_LAUNCH_CHECK();
     if (p.splits > 1) {
         launch_reduce_slabs((const float*)workspace, dw, g->Co * a.K, p.splits, st, dbias ? bias_slabs : nullptr,
@@ -1585,15 +1600,19 @@ static size_t group_problem_floats(const dynmm_conv_geom* g, const WgradPlan& p)
     return (wslab + (size_t)p.splits * g->Co + 3) & ~(size_t)3;
 }
 
+// 2: the vectorised 128x128 kernel; 1: the generic tiles (single input, split pixel range); 0: not groupable
 extern "C" int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g) {
     static const int off = env_int("DYNMM_NO_WGRAD_GROUP");
-    if (off || !geom_ok(g)) return 0;
+    if (off || !geom_ok(g) || g->c_split != g->Ci) return 0;
+    if (stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, false, false)) return 0;
     const WgradPlan p = plan_wgrad(g);
-    return (wgrad_v4_shape_ok(g, p) && p.splits > 1) ? 1 : 0;
+    if (p.splits <= 1) return 0;
+    static const int no_generic = env_int("DYNMM_NO_WGRAD_GROUP_GENERIC");
+    return wgrad_v4_shape_ok(g, p) ? 2 : (no_generic ? 0 : 1);
 }
 
 extern "C" size_t dynmm_conv2d_wgrad_group_workspace_bytes(const dynmm_conv_geom* g, int n) {
-    if (!geom_ok(g) || n < 1 || n > 4) return 0;
+    if (!geom_ok(g) || n < 1 || n > kWgradGroupMax) return 0;
     if (n == 1 || !dynmm_conv2d_wgrad_groupable(g)) return dynmm_conv2d_wgrad_workspace_bytes(g);
     const WgradPlan p = plan_wgrad_group(g, n);
     return sizeof(float) * group_problem_floats(g, p) * (size_t)n;
@@ -1603,7 +1622,7 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
                                         float* const* dbiases, void* workspace, size_t workspace_bytes,
                                         const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();
-    if (n < 1 || n > 4 || !xs || !dys || !dws || !geom_ok(g)) return DYNMM_EINVAL;
+    if (n < 1 || n > kWgradGroupMax || !xs || !dys || !dws || !geom_ok(g)) return DYNMM_EINVAL;
     bool aligned = (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
     for (int i = 0; i < n; ++i) {
         if (!xs[i] || !dys[i] || !dws[i]) return DYNMM_EINVAL;
@@ -1611,7 +1630,8 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
                   (!dbiases || !dbiases[i] || (reinterpret_cast<uintptr_t>(dbiases[i]) & 15u) == 0);
         if (dbiases && ((dbiases[i] != nullptr) != (dbiases[0] != nullptr))) return DYNMM_EINVAL;      // all or none
     }
-    if (n == 1 || !aligned || !dynmm_conv2d_wgrad_groupable(g)) {       // one ordinary launch per problem
+    const int kind = dynmm_conv2d_wgrad_groupable(g);
+    if (n == 1 || kind == 0 || (kind == 2 && !aligned)) {               // one ordinary launch per problem
         for (int i = 0; i < n; ++i) {
             const int rc = dynmm_conv2d_wgrad(xs[i], nullptr, dys[i], dws[i], dbiases ? dbiases[i] : nullptr, workspace,
                                               workspace_bytes, g, stream);
@@ -1643,9 +1663,23 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
     a.K = g->KH * g->KW * g->Ci;
     a.n_co_tiles = p.n_co_tiles; a.n_k_tiles = p.n_k_tiles; a.steps_per_split = p.steps_per_split;
     a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
-    a.k_major_out = 1;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(grp.per * n));
+    if (kind == 1) {
+        // generic tiles: plain [Co][Ci][KH][KW] slabs, summed by reduce_slabs_kernel (one launch per problem)
+        a.k_major_out = 0;
+        const bool fast = (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
+        launch_wgrad_generic(a, grp, p, grid, false, fast, st);
+        DYNMM_LAUNCH_CHECK();
+        for (int i = 0; i < n; ++i) {
+            launch_reduce_slabs((const float*)grp.out[i], dws[i], g->Co * a.K, p.splits, st,
+                                has_bias ? (const float*)grp.out_bias[i] : nullptr, has_bias ? dbiases[i] : nullptr,
+                                has_bias ? g->Co : 0);
+            DYNMM_LAUNCH_CHECK();
+        }
+        return DYNMM_OK;
+    }
+    a.k_major_out = 1;
     static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
     if (v4_nbuf == 2)
         hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, grp);

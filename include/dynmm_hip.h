@@ -99,7 +99,7 @@ int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* 
                        void* workspace, size_t workspace_bytes,
                        const dynmm_conv_geom* g, void* stream);
 
-/* Weight gradients of n <= 4 convolutions of IDENTICAL geometry (e.g. the factorised convs of consecutive residual
+/* Weight gradients of n <= 8 convolutions of IDENTICAL geometry (e.g. the factorised convs of consecutive residual
  * blocks) in one launch: one residency round whatever n is, so every workgroup walks an n-times longer pixel range and
  * the per-launch fixed costs and the split-K slab traffic are paid once per group.  xs / dys / dws / dbiases: host arrays
  * of n device pointers (dbiases NULL, or all entries set / all NULL).  Falls back to n ordinary launches when the
