@@ -251,10 +251,11 @@ def kernel_timing(step_fn, model):
     agg, shapes = {}, {}
     for name, flops, e0, e1, shape in rec:
         ms = e0.elapsed_time(e1)
-        n_, ci, h, w, co, kh, kw, sh, sw = shape
-        # algorithmic bytes of the launch: every operand once (input + output/gradient tensor + weights), fp32
+        n_, ci, h, w, co, kh, kw, sh, sw, nprob = shape
+        # algorithmic bytes of the launch: every operand once (input + output/gradient tensor + weights), fp32;
+        # nprob > 1: a grouped weight-gradient launch (dynmm_conv2d_wgrad_group) of that many same-shape convolutions
         ho, wo = -(-h // sh), -(-w // sw)
-        abytes = 4.0 * (n_ * ci * h * w + n_ * co * ho * wo + co * ci * kh * kw)
+        abytes = 4.0 * nprob * (n_ * ci * h * w + n_ * co * ho * wo + co * ci * kh * kw)
         for d, key in ((agg, name), (shapes, (name, shape))):
             a = d.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1

@@ -254,7 +254,7 @@ def _timed(kind, g, call, nprob=1):
     e0.record()
     r = call()
     e1.record()
-    PROFILE.append((name, flops, e0, e1, (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW)))
+    PROFILE.append((name, flops, e0, e1, (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, nprob)))
     return r
 
 
