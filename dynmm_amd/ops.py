@@ -113,7 +113,18 @@ def join_async():
 # at the end of backward at the latest; the parameters are reported to the gradient reducer when their launch is
 # actually enqueued.
 WGRAD_GROUP = int(_os.environ.get('DYNMM_WGRAD_GROUP', '4'))
+WGRAD_GROUP_AGE = int(_os.environ.get('DYNMM_WGRAD_GROUP_AGE', '4'))
 _WGRAD_QUEUES = {}
+_WGRAD_TICK = [0]          # conv backward calls seen; a queue that got nothing for WGRAD_GROUP_AGE of them is flushed
+_WGRAD_LAST = {}           # (the backward has left the run of layers with that geometry: do not hold its gradients back)
+
+
+def _age_wgrad_queues():
+    _WGRAD_TICK[0] += 1
+    if _WGRAD_QUEUES:
+        now = _WGRAD_TICK[0]
+        for key in [k for k in _WGRAD_QUEUES if now - _WGRAD_LAST.get(k, now) > WGRAD_GROUP_AGE]:
+            _flush_wgrad_queue(key)
 
 
 def _queue_wgrad(g, x, gy, w_param, b_param):
@@ -122,12 +133,14 @@ def _queue_wgrad(g, x, gy, w_param, b_param):
     ev.record(torch.cuda.current_stream())              # gy is produced on this stream
     q = _WGRAD_QUEUES.setdefault(key, [])
     q.append((g, x, gy, w_param, b_param, ev))
+    _WGRAD_LAST[key] = _WGRAD_TICK[0]
     if len(q) >= WGRAD_GROUP:
         _flush_wgrad_queue(key)
 
 
 def _flush_wgrad_queue(key):
     q = _WGRAD_QUEUES.pop(key, None)
+    _WGRAD_LAST.pop(key, None)
     if not q:
         return
     lib = _lib()
@@ -488,6 +501,8 @@ class _Conv2d(Function):
                                                                           _p(dx2), C.byref(g), st)), 'conv2d_dgrad')
         dw_ret = None
         ws_stream = None
+        if DIRECT_GRAD and WGRAD_GROUP > 1:
+            _age_wgrad_queues()
         if defer:
             _queue_wgrad(g, x, gy, ctx.w_param, ctx.b_param if bias_in_wgrad else None)
         elif ctx.needs_input_grad[2]:
