@@ -150,6 +150,9 @@ def _flush_wgrad_queue(key):
     stream = _wgrad_stream() if use_async else torch.cuda.current_stream()
     for item in q:
         stream.wait_event(item[5])
+    # parameters registered by the backward that triggered this flush belong to ITS streams: set them aside
+    held = _PENDING[:]
+    del _PENDING[:]
     dws = [_grad_dst(item[3])[0] for item in q]
     dbs = [_grad_dst(item[4])[0] for item in q] if q[0][4] is not None else None
     nbytes = lib.dynmm_conv2d_wgrad_group_workspace_bytes(C.byref(g), n)
@@ -169,6 +172,7 @@ def _flush_wgrad_queue(key):
     if use_async:
         _INFLIGHT.append(tuple(t for item in q for t in (item[1], item[2])))
     _grads_enqueued(stream)
+    _PENDING.extend(held)
 
 
 def flush_wgrad_groups():

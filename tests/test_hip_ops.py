@@ -582,3 +582,50 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
         assert torch.equal(x, y)
     for i, (x, y) in enumerate(zip(a[3], b[3])):
         assert rel(x, y) < 2e-4, i
+
+
+@pytest.mark.parametrize('case', [(4, 128, 24, 32, 128, (3, 1), (1, 0), True),      # vectorised 128x128 kernel
+                                  (4, 64, 24, 32, 64, (1, 3), (0, 1), True),        # generic 64co x 192k tiles
+                                  (4, 128, 24, 32, 128, (3, 3), (1, 1), False)])
+def test_grouped_weight_gradients(ops, case):
+    """dynmm_conv2d_wgrad_group through the C ABI: 3 same-geometry convolutions in one launch against fp64 torch (and
+    the bias gradients that ride along), bit-identical between two calls, and the n = 1 / not-groupable fallbacks."""
+    import ctypes as C
+    from dynmm_amd import lib as L
+    lib = L.load()
+    N, Ci, H, W, Co, k, pad, bias = case
+    st = torch.cuda.current_stream().cuda_stream
+    xs = [rnd(N, Ci, H, W, seed=10 + i).cuda() for i in range(3)]
+    w0 = torch.empty(Co, Ci, *k)
+    g = ops._geom(xs[0], None, w0, (1, 1), pad)
+    dys = [rnd(N, Co, g.Ho, g.Wo, seed=20 + i).cuda() for i in range(3)]
+    ref_w, ref_b = [], []
+    for x, dy in zip(xs, dys):
+        xd = x.double().cpu()
+        wd = torch.zeros(Co, Ci, *k, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xd, wd, None, 1, pad)
+        y.backward(dy.double().cpu())
+        ref_w.append(wd.grad)
+        ref_b.append(dy.double().cpu().sum((0, 2, 3)))
+    assert lib.dynmm_conv2d_wgrad_groupable(C.byref(g)) in (1, 2)
+
+    def run(n):
+        dws = [torch.empty(Co, Ci, *k, device='cuda') for _ in range(n)]
+        dbs = [torch.empty(Co, device='cuda') for _ in range(n)] if bias else None
+        nbytes = lib.dynmm_conv2d_wgrad_group_workspace_bytes(C.byref(g), n)
+        ws = torch.empty(max(nbytes // 4, 1), device='cuda')
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts[:n]])
+        L.check(lib.dynmm_conv2d_wgrad_group(n, arr(xs), arr(dys), arr(dws), arr(dbs) if bias else None, ws.data_ptr(), nbytes,
+                                             C.byref(g), st), 'wgrad_group')
+        torch.cuda.synchronize()
+        return dws, dbs
+    a_w, a_b = run(3)
+    for i in range(3):
+        assert rel(a_w[i], ref_w[i]) < GTOL
+        if bias:
+            assert rel(a_b[i], ref_b[i]) < GTOL
+    b_w, _ = run(3)
+    for x, y in zip(a_w, b_w):
+        assert torch.equal(x, y)
+    s_w, _ = run(1)                                   # a "group" of one = the ordinary launch
+    assert rel(s_w[0], ref_w[0]) < GTOL
