@@ -435,13 +435,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)           # before the process group: RCCL binds the communicator to the current device
+    device = torch.device('cuda', local_rank)
     if world > 1:
         # nccl == RCCL on ROCm.  DYNMM_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a
         # single-GPU box (ranks then share device 0).
         dist.init_process_group(os.environ.get('DYNMM_DIST_BACKEND', 'nccl'))
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
     train = args.mode == 'train'
 
     ts = None
