@@ -11,6 +11,8 @@ BatchNorm statistics stay per replica (DDP semantics; the reference has no SyncB
 Works with any torch.distributed backend: `nccl` (= RCCL) on GPUs, `gloo` on CPU for the
 world_size-2 tests in tests/test_dp_gloo.py.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,6 +22,8 @@ class GradBucketReducer:
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # tests: run the collectives of a 1-rank group too (exercises the RCCL path on a single-GPU box)
+        self.force = dist.is_initialized() and os.environ.get('DYNMM_DP_FORCE_COLLECTIVES') is not None
         dev = self.params[0].device
         # buckets are filled in REVERSE parameter order: backward produces the last layers' grads first
         order = list(reversed(self.params))
@@ -44,7 +48,7 @@ class GradBucketReducer:
         for p in order:
             self._count[self._bucket_of[p]] += 1
         self._works = []
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and (self.world > 1 or self.force)
         self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda') else None
         self._hooks = []
         self._streams = [dict() for _ in self.buckets]      # per bucket: producer streams seen this step
@@ -111,7 +115,7 @@ class GradBucketReducer:
 
     def finish(self):
         """After backward: make sure every bucket is reduced, then average."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if not self.overlap:
             for b in range(len(self.buckets)):

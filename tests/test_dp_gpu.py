@@ -89,3 +89,50 @@ def test_real_model_two_ranks_overlap_and_exact_mean():
         assert spread > 0                                        # the two shards really had different gradients
     assert np.array_equal(res[0][5], res[1][5])                  # replicas agree on the reduced gradient
     assert np.array_equal(res[0][6], res[1][6])                  # ... and on the updated parameters
+
+
+def _rccl_worker(port, q):
+    """one rank over the 'nccl' (= RCCL) backend: the collective is trivial, the code path is not — communicator
+    creation on the selected device, async all-reduce of every bucket on the communication stream DURING backward,
+    stream joins, division by the world size, fused optimizer."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+                      DYNMM_DP_FORCE_COLLECTIVES='1')
+    torch.cuda.set_device(0)
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    except Exception as e:                                       # no RCCL on this box: report, do not fail the suite
+        q.put(('skip', repr(e)))
+        return
+    from dynmm_amd import engine, synth
+    from dynmm_amd.nn.net import SkipGateESANet
+    h, w, n = 96, 128, 2
+    m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+    synth.fill_state_dict(m.state_dict(), seed=0)
+    m = m.cuda().train()
+    m.temp, m.hard_gate = 1.0, False
+    rgb, depth = synth.synth_inputs(n, h, w, seed=100, device='cuda')
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s, device='cuda').to(torch.uint8) for s in (1, 8, 16, 32)]
+    step = engine.TrainStep(m, np.linspace(0.5, 2.0, 40), lr=0.01, loss_ratio=0.1, bucket_mb=8.0, overlap=True)
+    red = step.reducer
+    assert red.force and red.overlap           # a 1-rank reducer normally skips the collectives: forced through RCCL here
+    step._body(rgb, depth, labels)
+    launched = red.launched_in_backward
+    red.finish()
+    torch.cuda.synchronize()
+    flat = red.flat.clone()
+    q.put(('ok', launched, len(red.buckets), bool(torch.isfinite(flat).all().item()), float(flat.abs().sum().item())))
+    dist.destroy_process_group()
+
+
+def test_bucket_allreduce_over_rccl_single_rank():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    if res[0] == 'skip':
+        pytest.skip(f'RCCL process group unavailable: {res[1]}')
+    _, launched, nb, finite, mass = res
+    assert launched == nb and nb >= 4          # every bucket's all-reduce went out during backward, through RCCL
+    assert finite and mass > 0
