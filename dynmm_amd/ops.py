@@ -539,6 +539,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_in
       defer_mask : this op's ReLU backward is applied by its (single) consumer — pair with
       mask_input : x is the output of a `defer_mask` op: the dgrad epilogue applies [x > 0];
       link       : GradLink whose residual-branch gradient is added in the dgrad epilogue."""
+    if not torch.is_grad_enabled() and isinstance(weight, torch.nn.Parameter) and w_owner is None:
+        # inference: the packed weight is cached on the parameter (conv2d_fused_eval) instead of re-laid-out per call
+        # (the factorised blocks' conv -> ReLU pairs were 83 pack launches per forward of config P)
+        return conv2d_fused_eval(x, weight, bias, None, act, None, stride, padding, x2)
     return _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
                          bool(defer_mask), link, _split_forward_allowed(), w_owner)
 
