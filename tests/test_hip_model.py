@@ -507,3 +507,48 @@ def test_compacted_training_backward_matches_dense():
         checked += 1
     assert checked > 400
     assert any('gate' in k and v.abs().max() > 0 for k, v in gc.items())      # the gate still trains
+
+
+def test_benchmark_config_train_step_invariants():
+    """BASELINE configs[2] at its FULL size (batch 32, 480x640, config P, soft gates, weighted 4-scale CE + FLOP loss),
+    where the oracle is too slow: size-independent properties of the whole step body instead —
+      * the weighted CE normalises by the weight mass, so doubling every class weight (an exact power-of-two scaling)
+        must leave all losses and every parameter gradient unchanged (exercises the fused up-sampling + CE tail, the
+        loss head's per-scale seeds and everything downstream);
+      * BatchNorm statistics, the FLOP loss and the mean-reduced losses are symmetric in the batch, so permuting the
+        samples (inputs and labels alike) changes only summation orders: same losses to 1e-5, same gradient direction
+        (the gradient itself carries the chaotic ReLU-flip noise of DESIGN.md section 1, hence a cosine bar);
+      * finite everywhere, every trainable parameter receives a gradient."""
+    from dynmm_amd import engine
+    h, w, n = 480, 640, 32
+    rgb, depth = synth.synth_inputs(n, h, w, seed=11, device='cuda')
+    labels = [synth.synth_labels(n, h // s, w // s, seed=40 + s, device='cuda').to(torch.uint8) for s in (1, 8, 16, 32)]
+    cw = np.linspace(0.5, 2.0, 40).astype(np.float32)
+
+    def run(cwv, perm=None):
+        m = hip_model('P_se', h, w, seed=2)
+        m.train()
+        m.temp, m.hard_gate = 1.0, False
+        step = engine.TrainStep(m, cwv, lr=0.0, loss_ratio=0.5, flop_budget=0.0)
+        r, d, ls = (rgb, depth, labels) if perm is None else (rgb[perm], depth[perm], [t[perm] for t in labels])
+        step._body(r.contiguous(), d.contiguous(), [t.contiguous() for t in ls])
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.detach().flatten() for p in m.parameters()]).double()
+        touched = len(step._touched)
+        out = (step.last['losses'].double().cpu(), step.last['total'].double().cpu(), grads, touched,
+               sum(1 for _ in m.parameters()))
+        del step, m
+        torch.cuda.empty_cache()
+        return out
+    base = run(cw)
+    assert torch.isfinite(base[0]).all() and torch.isfinite(base[2]).all()
+    assert base[3] == base[4]                                         # every parameter took part in the step
+    scaled = run(2.0 * cw)
+    assert torch.allclose(scaled[0], base[0], rtol=1e-6, atol=0) and torch.allclose(scaled[1], base[1], rtol=1e-6, atol=0)
+    assert ((scaled[2] - base[2]).norm() / base[2].norm()).item() < 1e-6
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(5)).cuda()
+    shuffled = run(cw, perm)
+    assert torch.allclose(shuffled[0], base[0], rtol=1e-5, atol=0) and torch.allclose(shuffled[1], base[1], rtol=1e-5, atol=0)
+    cos = torch.nn.functional.cosine_similarity(shuffled[2], base[2], dim=0).item()
+    assert cos > 0.999, cos
+    assert abs((shuffled[2].norm() / base[2].norm()).item() - 1) < 2e-2
