@@ -550,5 +550,8 @@ def test_benchmark_config_train_step_invariants():
     shuffled = run(cw, perm)
     assert torch.allclose(shuffled[0], base[0], rtol=1e-5, atol=0) and torch.allclose(shuffled[1], base[1], rtol=1e-5, atol=0)
     cos = torch.nn.functional.cosine_similarity(shuffled[2], base[2], dim=0).item()
+    print(f'batch 32 invariants: class-weight x2 gradient diff {((scaled[2] - base[2]).norm() / base[2].norm()).item():.2e}; '
+          f'batch permutation: loss diff {((shuffled[1] - base[1]).abs() / base[1].abs()).item():.2e}, gradient cosine '
+          f'{cos:.6f}, |g| ratio {(shuffled[2].norm() / base[2].norm()).item():.5f}')
     assert cos > 0.999, cos
     assert abs((shuffled[2].norm() / base[2].norm()).item() - 1) < 2e-2
