@@ -552,7 +552,7 @@ def main():
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'height': args.height, 'width': args.width,
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
-                       'streams': 1 if args.single_stream else (3 if train else 2),
+                       'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
                        'dp': dp_info,
                        'model_tflops': round(value * gflop_img / 1e3, 2) if dense_work else None,

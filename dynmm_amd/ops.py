@@ -85,7 +85,7 @@ DIRECT_GRAD = False
 # the main backward chain and fills its ramp-up / tail bubbles.  Tensors it reads are kept alive in
 # _INFLIGHT until join_async() (call it after backward, on the stream that consumes the gradients).
 ASYNC_WGRAD = False
-WGRAD_STREAMS = int(_os.environ.get('DYNMM_WGRAD_STREAMS', '1'))
+WGRAD_STREAMS = int(_os.environ.get('DYNMM_WGRAD_STREAMS', '2'))
 _WGRAD_POOL = []
 _WGRAD_RR = [0]
 _INFLIGHT = []
