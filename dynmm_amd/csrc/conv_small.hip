@@ -166,8 +166,12 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
     constexpr int NSTEP = CI * KS * KW8 / 2;           // 84 / 28 MFMA steps (2 k's each)
     constexpr int OP = TCW + 8;                        // output-chunk row pitch: rows cl and cl + 4 (the two half-waves) on disjoint banks
     constexpr int OCH = 16 * OP;                       // floats of one output chunk (16 channels x 64 columns)
-    constexpr int PATCH = CI * IR * ICP > 4 * OCH ? CI * IR * ICP : 4 * OCH;
-    __shared__ __attribute__((aligned(16))) float patch[PATCH];
+    constexpr int NPATCH = CI * IR * ICP;
+    constexpr int PATCH = ((NPATCH > 4 * OCH ? NPATCH : 4 * OCH) + 63) & ~63;
+    constexpr int NIT = (NPATCH + 255) / 256;          // staging loads per lane and tile
+    // Two patch buffers: the next tile's patch is fetched by direct global->LDS loads (global_load_lds_dword: no VGPR
+    // staging, nothing waits on them until the end of the iteration) while this tile's MFMAs and stores run.
+    __shared__ __attribute__((aligned(16))) float patch2[2][PATCH];
 
     const int lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
     const int wave = threadIdx.x >> 6;
@@ -185,40 +189,49 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
         const int kw = 2 * kp + khalf;
         areg[st] = kw < KS ? a.wp[((size_t)(kh * KS + kw) * a.CiR + ci) * a.CoP + mi * 32 + l31] : 0.f;
     }
-    const float* pb = patch + (S * 2 * rp) * ICP + S * l31 + khalf;     // row 0, pixel tile 0 of the wave
-    float* const ostage = patch + wave * OCH;                           // the wave's output chunk (patch is dead then)
+    const int pb_off = (S * 2 * rp) * ICP + S * l31 + khalf;            // row 0, pixel tile 0 of the wave
     const bool vec_out = (a.Wo & 3) == 0;
 
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // element e = it*256 + tid of the flat [CI][IR][ICP] patch: a wave instruction fills 64 consecutive floats of LDS.
+    // Lanes outside the image (the conv's zero padding) or past the patch issue no load: their slot gets a plain
+    // ds_write of 0 instead (a masked lane of global_load_lds leaves its LDS slot untouched).
+    auto fetch_patch = [&](int tile, float* dst) __attribute__((always_inline)) {
+        int b = tile;
+        const int n = b / (th * tw);
+        b -= n * th * tw;
+        const int ih0 = (b / tw) * TRW * S - PAD, iw0 = (b - (b / tw) * tw) * TCW * S - PAD;
+        const float* xn = a.x + (size_t)n * CI * HW;
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {          // (rolled: the addresses are cheap, hoisting all of them spills)
+            const int e = it * 256 + threadIdx.x;
+            const int ci = min(e / (IR * ICP), CI - 1), rem = e - ci * (IR * ICP);
+            const int rr = rem / ICP, cc = rem - rr * ICP;
+            const int ih = ih0 + rr, iw = iw0 + cc;
+            const bool inside = e < NPATCH;
+            const bool ok = inside && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            float* slot = dst + it * 256 + (threadIdx.x & ~63);         // wave-uniform LDS base of this instruction
+            if (ok)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xn + (size_t)ci * HW + (size_t)ih * a.W + iw),
+                                                 (__attribute__((address_space(3))) void*)slot, 4, 0, 0);
+            else if (inside)
+                dst[e] = 0.f;
+        }
+    };
+
+    int buf = 0;
+    if ((int)blockIdx.x < tiles) fetch_patch(blockIdx.x, patch2[0]);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, buf ^= 1) {
         int b = tile;
         const int n = b / (th * tw);
         b -= n * th * tw;
         const int oh0 = (b / tw) * TRW, ow0 = (b - (b / tw) * tw) * TCW;
-        const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-        __syncthreads();                                                // previous tile's output staging is done
-        {
-            // all loads of the patch are issued before the first LDS write (clamped addresses + selects: a loop of
-            // load -> wait -> store iterations left the workgroup waiting 21 memory round trips per tile)
-            constexpr int NIT = (CI * IR * ICP + 255) / 256;
-            float sv[NIT];
-            const float* xn = a.x + (size_t)n * CI * HW;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = it * 256 + threadIdx.x;
-                const int ci = min(e / (IR * ICP), CI - 1), rem = e - ci * (IR * ICP);
-                const int rr = rem / ICP, cc = rem - rr * ICP;
-                const int ih = ih0 + rr, iw = iw0 + cc;
-                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                const float v = xn[(size_t)ci * HW + (size_t)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)];
-                sv[it] = ok ? v : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = it * 256 + threadIdx.x;
-                if (e < CI * IR * ICP) patch[e] = sv[it];
-            }
-        }
-        __syncthreads();
+        const float* patch = patch2[buf];
+        const float* pb = patch + pb_off;
+        float* const ostage = patch2[buf] + wave * OCH;                 // the wave's output chunk (this patch is dead then)
+        const int next = tile + (int)gridDim.x;
+        if (next < tiles) fetch_patch(next, patch2[buf ^ 1]);           // in flight under the MFMAs and the stores below
 
         f32x16 acc[2][2];                                               // [row of the pair][pixel tile]
 #pragma unroll
@@ -242,7 +255,7 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b10, acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b11, acc[1][1], 0, 0, 0);
                 }
-        __syncthreads();                                                // every wave is done reading the patch
+        __syncthreads();                                                // every wave is done reading this patch
 
         // Epilogue through LDS: the accumulator layout gives 128-byte runs per half-wave (dword stores, ~2 TB/s
         // measured on this 629 MB output); transposed, a lane stores 16 bytes and a wave 4 x 256 contiguous bytes.
@@ -283,10 +296,10 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+        __builtin_amdgcn_s_waitcnt(0);                                  // the next patch has landed (this wave's part)
+        __syncthreads();                                                // ... everyone's; this patch / output staging is free
     }
 }
-
-static bool small_off(const char* which) { return small_off_early(which); }
 
 // ---- stem weight gradient: the forward's LDS-patch scheme with the pixel axis as the MFMA reduction -------------
 // dW[co][k] = sum_pix dY[co][pix] * X[k][pix], k = (ci, kh, kw8).  A = dY (lane: channel l31, pixel parity khalf) from
@@ -477,7 +490,7 @@ int launch_stem_conv_wgrad(const float* x, const float* dy, float* dw, float* wo
 }
 
 bool stem_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
-    static const bool off = small_off("stem");
+    static const bool off = small_off_early("stem");
     if (off || residual || a.x2) return false;
     if (a.KH != 7 || a.KW != 7 || a.SH != 2 || a.SW != 2 || a.PH != 3 || a.PW != 3) return false;
     return (a.Ci == 1 || a.Ci == 3) && a.Co == 64;
@@ -506,7 +519,7 @@ int launch_stem_conv_fwd(const SmallConvArgs& a_in, hipStream_t st) {
 }
 
 bool small_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
-    static const bool off = small_off("gate");
+    static const bool off = small_off_early("gate");
     if (off || residual) return false;
     if (a.Co < 5 || a.Co > 8) return false;                       // packed rows of exactly 8 floats
     if (a.KH != 5 || a.KW != 5 || a.SH != 2 || a.SW != 2 || a.PH != 0 || a.PW != 0) return false;
