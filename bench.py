@@ -44,7 +44,7 @@ TRAFFIC_NOTE = ('HBM bytes per launch from profiles/pmc_dominant_kernel.json (se
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None, help='ranks (= GPUs) of this node; default: WORLD_SIZE or 1')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
@@ -73,7 +73,9 @@ def parse():
                          '(RGB encoder | depth encoder | weight gradients) overlaps better un-captured')
     ap.add_argument('--single-stream', action='store_true', help='disable the depth-encoder and wgrad side streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-batch', type=int, default=4, help='batch of the thread sweep + parity sample')
+    ap.add_argument('--no-cpu-full-batch', dest='cpu_full_batch', action='store_false',
+                    help='skip the single full-batch oracle step (report the small-sample rate)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary lines (configs[1] fwd-only, hard-gate)')
     return ap.parse_args()
@@ -139,26 +141,28 @@ def cpu_baseline_and_parity(args, device):
     train = args.mode == 'train'
     keep = {}
 
-    def one():
+    def one(batch=None):
+        """one oracle step on `batch` (default: the batch-n sample whose results the parity check uses)"""
+        rgb_, depth_, labels_, noise_, out = (rgb, depth, labels, noise, keep) if batch is None else batch + ({},)
         sd_run = {k: (v.detach().clone() if 'running_' in k or not v.dtype.is_floating_point else v) for k, v in sd.items()}
         if not train:
             with torch.no_grad():
                 if args.model == 'skip':
-                    keep['out'] = O.forward_skip(sd_run, rgb, depth, cfg, noise, test=True)
+                    out['out'] = O.forward_skip(sd_run, rgb_, depth_, cfg, noise_, test=True)
                 else:
-                    keep['out'] = O.forward(sd_run, rgb, depth, cfg, test=True, baseline=True)
+                    out['out'] = O.forward(sd_run, rgb_, depth_, cfg, test=True, baseline=True)
             return
         for p in params.values():
             p.grad = None
         if args.model == 'skip':
-            outs, lf = O.forward_skip(sd_run, rgb, depth, cfg, noise, training=True), torch.zeros(())
+            outs, lf = O.forward_skip(sd_run, rgb_, depth_, cfg, noise_, training=True), torch.zeros(())
         else:
-            outs, lf = O.forward(sd_run, rgb, depth, cfg, training=True, temp=1.0)
-        losses = O.cross_entropy_2d(outs, labels, cw)
+            outs, lf = O.forward(sd_run, rgb_, depth_, cfg, training=True, temp=1.0)
+        losses = O.cross_entropy_2d(outs, labels_, cw)
         total = sum(losses) + torch.clamp(lf, min=0.0)
         total.backward()
-        keep.update(out=outs[0].detach(), losses=torch.stack([l.detach() for l in losses]), lf=lf.detach(),
-                    total=total.detach())
+        out.update(out=outs[0].detach(), losses=torch.stack([l.detach() for l in losses]), lf=lf.detach(),
+                   total=total.detach())
 
     model_name, phys, logical = host_cpu()
     default_threads = torch.get_num_threads()
@@ -175,19 +179,31 @@ def cpu_baseline_and_parity(args, device):
         if best is None or dt < best[1]:
             best = (t, dt)
     torch.set_num_threads(best[0])
-    times = []
-    for _ in range(2):
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    med = min(best[1], sorted(times)[0])
+    small = round(n / best[1], 4)
+    # the workload's own batch: ONE timed step at the winning thread count (one step is the whole 10-30 s CPU budget;
+    # thread widths are compared on the small sample above because a sweep at full batch would take minutes)
+    full_n, value, sample_n, why = args.batch if train else 16, small, n, None
+    if args.cpu_full_batch and full_n > n:
+        try:
+            gb = torch.Generator().manual_seed(99)
+            big = make_batch(full_n, args.height, args.width, 'cpu', 4322) + \
+                ([torch.empty(full_n, 2).exponential_(generator=gb) for _ in range(4)],)
+            t0 = time.perf_counter()
+            one(big)
+            dt = time.perf_counter() - t0
+            value, sample_n = round(full_n / dt, 4), full_n
+            del big
+        except (RuntimeError, MemoryError) as e:       # host RAM: a batch-32 training step keeps ~45 GB of activations
+            why = f'batch {full_n} step failed on this host ({type(e).__name__}); batch {n} figure reported'
+    one()                                              # the parity reference below is THIS run (batch n, winning width)
     torch.set_num_threads(default_threads)
-    cpu = {'value': round(n / med, 4), 'unit': 'images/s', 'cores': best[0], 'kind': 'port',
+    cpu = {'value': value, 'unit': 'images/s', 'cores': best[0], 'kind': 'port',
            'cpu_model': model_name, 'physical_cores': phys, 'logical_cpus': logical,
+           'batch': sample_n, f'batch{n}_images_per_s': small,
            'threads_sweep_images_per_s': {str(k): v for k, v in sweep.items()},
-           'sample': f'oracle (PyTorch CPU fp32), batch {n} of the same {args.height}x{args.width} {args.mode} step '
-                     f'(fwd + weighted 4-scale CE + flop loss + bwd); thread sweep {cands}, best of 3 timed runs at the '
-                     f'winning width ({best[0]} threads)'}
+           'sample': f'oracle (PyTorch CPU fp32): ONE {args.height}x{args.width} {args.mode} step (fwd + weighted 4-scale CE + '
+                     f'flop loss + bwd) at batch {sample_n} with {best[0]} threads; thread count chosen by a sweep {cands} '
+                     f'over batch-{n} steps of the same workload' + (f'; {why}' if why else '')}
 
     # ---- parity: the HIP path on the same inputs, against the oracle run above ----
     parity = None
@@ -309,11 +325,27 @@ def timed(step, steps, warmup, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed.per_rank = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        timed.per_rank = [float(x.item()) for x in every]
+        elapsed = max(timed.per_rank)                 # MAX over ranks
     return elapsed
+
+
+def timed_local(step, steps, warmup):
+    """Every rank's own loop time WITHOUT the closing barrier (the spread between ranks that the barrier hides:
+    hard-gate compaction gives ranks different amounts of work)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -430,10 +462,49 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     return res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: re-run this script as N ranks of one node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and hand its exit code back.  Under a launcher
+    (WORLD_SIZE set — the driver's `python -m torch.distributed.run … bench.py --gpus N`) this is a no-op."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: the only mode the host driver supports (RCCL)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     rank = int(os.environ.get('RANK', '0'))
+    if os.environ.get('DYNMM_BENCH_LAUNCH_PROBE'):
+        # tests/test_bench_launch.py (no GPU needed): the launcher started `world` ranks and they can talk
+        for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', str(_free_port())), ('RANK', '0'), ('WORLD_SIZE', '1')):
+            os.environ.setdefault(k, v)
+        dist.init_process_group('gloo')
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({'probe': True, 'n_gpus': world, 'ranks_seen': int(ones.item()), 'steps': args.steps}))
+        dist.destroy_process_group()
+        return
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)           # before the process group: RCCL binds the communicator to the current device
@@ -456,11 +527,35 @@ def main():
     value = args.batch * world * args.steps / elapsed
 
     dp_info = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                          # every rank of the job answers: the line proves N ranks ran
+        per_rank_ms = [1000.0 * t / args.steps for t in timed.per_rank]
+        dp_info = {'backend': dist.get_backend(), 'ranks_seen': int(round(ones.item())),
+                   'devices_visible': torch.cuda.device_count(),
+                   'ms_per_step_rank_min_mean_max': [round(min(per_rank_ms), 3), round(sum(per_rank_ms) / world, 3),
+                                                     round(max(per_rank_ms), 3)]}
+        if dp_info['ranks_seen'] != args.gpus:
+            raise SystemExit(f"bench.py: {dp_info['ranks_seen']} ranks answered the all-reduce, --gpus {args.gpus}")
     if ts is not None and world > 1:
         red = ts.reducer
-        dp_info = {'buckets': len(red.buckets), 'launched_during_backward': red.launched_in_backward,
-                   'bucket_mb': round(4 * max(e - s for s, e in red.buckets) / 2 ** 20, 1),
-                   'backend': dist.get_backend()}
+        dp_info.update({'buckets': len(red.buckets), 'launched_during_backward': red.launched_in_backward,
+                        'bucket_mb': round(4 * max(e - s for s, e in red.buckets) / 2 ** 20, 1)})
+        # what the exchange costs: the same step with the reducer switched off (no collective, local gradients), and
+        # each rank's own loop time with no barrier at the end (rank skew)
+        k2 = max(3, args.steps // 2)
+        red.enabled = False
+        el_nc = timed(step, k2, 1, world, device)
+        red.enabled = True
+        local = timed_local(step, k2, 1)
+        t = torch.tensor([local], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        loc = [1000.0 * float(x.item()) / k2 for x in every]
+        dp_info.update({'ms_per_step_no_collectives': round(1000.0 * el_nc / k2, 3),
+                        'comm_exposed_ms': round(ms_per_step - 1000.0 * el_nc / k2, 3),
+                        'ms_per_step_unbarriered_rank_min_mean_max': [round(min(loc), 3), round(sum(loc) / world, 3),
+                                                                      round(max(loc), 3)]})
 
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
@@ -544,8 +639,6 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
-                       'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
-                              f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
                        'branches': args.branches if (args.hard or not train) else None,
                        'compaction': (args.compact if args.hard else None) if train else (not args.no_compact),
                        'stage_batch': stage_batch,
@@ -554,10 +647,13 @@ def main():
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
-                       'dp': dp_info,
-                       'model_tflops': round(value * gflop_img / 1e3, 2) if dense_work else None,
-                       'model_frac_of_fp32_mfma_peak': round(value * gflop_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
-                       if dense_work else None},
+                       'dp': dp_info},
+            'whole_step': {'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
+                                  f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
+                           'algorithmic_gflop_per_image': gflop_img,
+                           'tflops': round(value * gflop_img / 1e3, 2) if dense_work else None,
+                           'frac_of_fp32_mfma_peak': round(value * gflop_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
+                           if dense_work else None},
             'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'extra': extra,
         }
         print(json.dumps(line))

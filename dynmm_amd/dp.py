@@ -28,7 +28,11 @@ class GradBucketReducer:
         # buckets are filled in REVERSE parameter order: backward produces the last layers' grads first
         order = list(reversed(self.params))
         total = sum(p.numel() for p in order)
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        # one extra element behind the gradients: the step's total loss rides in the LAST bucket's all-reduce, so every
+        # rank takes the same skip / raise decision on a non-finite loss (a NaN on one rank is a NaN in the sum)
+        self._store = torch.zeros(total + 1, device=dev, dtype=torch.float32)
+        self.flat = self._store[:total]
+        self.loss_slot = self._store[total:]
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = []          # (start, end) element ranges in self.flat
         self._bucket_of = {}
@@ -43,6 +47,7 @@ class GradBucketReducer:
                 bstart, bidx = off, bidx + 1
         if off > bstart:
             self.buckets.append((bstart, off))
+        self._total = total
         self._pending = [0] * len(self.buckets)
         self._count = [0] * len(self.buckets)
         for p in order:
@@ -53,6 +58,9 @@ class GradBucketReducer:
         self._hooks = []
         self._streams = [dict() for _ in self.buckets]      # per bucket: producer streams seen this step
         self.active = True                                   # False: gradient hooks are ignored (tests: un-reduced pass)
+        self.enabled = True                                  # False: no collective at all (bench: the step without its exchange)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0                                       # buckets are launched strictly in index order (see _arrived)
         self.launched_in_backward = 0                        # buckets whose all-reduce started before finish()
         self.launch_log = []                                 # (bucket, 'backward' | 'finish') of the last step
         if self.overlap:
@@ -67,8 +75,10 @@ class GradBucketReducer:
     # -- step protocol --------------------------------------------------------------------------
     def zero(self):
         """Start of a step: clear the flat buffer (grads accumulate in place into their views)."""
-        self.flat.zero_()
+        self._store.zero_()
         self._pending = list(self._count)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._works = []
         self._streams = [dict() for _ in self.buckets]
         self.launched_in_backward = 0
@@ -76,7 +86,9 @@ class GradBucketReducer:
 
     def _launch(self, b, where='finish'):
         s, e = self.buckets[b]
-        chunk = self.flat[s:e]
+        if b == len(self.buckets) - 1:
+            e = self._total + 1                          # + the loss slot
+        chunk = self._store[s:e]
         self.launch_log.append((b, where))
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
@@ -89,12 +101,18 @@ class GradBucketReducer:
 
     def _arrived(self, p):
         b = self._bucket_of.get(p)
-        if b is None or self._pending[b] <= 0 or not self.active:
+        if b is None or self._pending[b] <= 0 or not self.active or not self.enabled:
             return
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            self.launched_in_backward += 1
-            self._launch(b, 'backward')
+            # Collectives of one communicator must be issued in the SAME order on every rank.  Completion order can
+            # differ between ranks (hard-gate compaction: a rank whose shard skips a depth stage never touches those
+            # parameters), so a complete bucket waits until every bucket before it has been launched.
+            self._ready[b] = True
+            while self._next < len(self.buckets) and self._ready[self._next]:
+                self.launched_in_backward += 1
+                self._launch(self._next, 'backward')
+                self._next += 1
 
     def _on_grad_ready(self, p):
         # autograd runs a parameter's AccumulateGrad node — and this hook — even when the backward returned None for
@@ -115,22 +133,28 @@ class GradBucketReducer:
 
     def finish(self):
         """After backward: make sure every bucket is reduced, then average."""
-        if self.world == 1 and not self.force:
+        if (self.world == 1 and not self.force) or not self.enabled:
             return
-        if not self.overlap:
-            for b in range(len(self.buckets)):
-                self._launch(b)
-        else:
-            for b, left in enumerate(self._pending):   # params that received no grad this step
-                if left > 0:
-                    self._pending[b] = 0
-                    self._launch(b)
+        first = self._next if self.overlap else 0
+        for b in range(first, len(self.buckets)):       # the rest (incl. buckets with parameters that got no gradient), in order
+            self._pending[b] = 0
+            self._launch(b)
+        self._next = len(self.buckets)
         for w in self._works:
             w.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self.flat.mul_(1.0 / self.world)
+        self._store.mul_(1.0 / self.world)
         self._works = []
+
+    def set_loss(self, total):
+        """Record this rank's total loss (device scalar) for the shared non-finite decision; call before backward."""
+        if self.world > 1 or self.force:
+            self.loss_slot.copy_(total.detach().reshape(1))
+
+    def reduced_loss(self, local):
+        """The loss every rank should base its skip decision on: the mean over ranks after finish(), else `local`."""
+        return self.loss_slot if ((self.world > 1 or self.force) and self.enabled) else local
 
     def remove_hooks(self):
         for h in self._hooks:

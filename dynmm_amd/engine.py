@@ -186,6 +186,8 @@ class TrainStep:
     only parameters with requires_grad take part (flat buffers, reducer buckets and optimizer state cover
     exactly those, as torch.optim skips parameters without gradients)."""
 
+    MAX_GRAPHS = 4             # captures kept alive at once (train / ragged last batch / hard vs soft gates)
+
     def __init__(self, model, class_weight, lr, momentum=0.9, weight_decay=1e-4, loss_ratio=0.0,
                  flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True, optimizer='SGD',
                  overlap=True, fuse_tail=None):
@@ -214,7 +216,7 @@ class TrainStep:
             model.dual_stream = self.multi_stream
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)
         self.use_graph = use_graph
-        self._graphs = {}      # key -> (graph, static inputs, static outputs, touched set)
+        self._graphs = {}      # key -> (graph, static inputs, static outputs, touched set, gate temperature)
         self.last = None       # dict of device tensors: losses[4], loss_flop, total
         self._touched = None
 
@@ -237,8 +239,13 @@ class TrainStep:
                 outs, lf = res, torch.zeros((), device=rgb.device)   # SkipESANet: the four outputs only
             # weighted 4-scale CE, total-loss rule and the seeds of the backward pass on the device (no PyTorch
             # arithmetic kernels between the forward and the backward of the model)
+            red = self.reducer
+            shared = (red.world > 1 or red.force) and red.enabled
+            # data parallel: the total is written into the slot that rides in the last gradient bucket, so after
+            # finish() it holds the mean over ranks and every rank takes the same non-finite-loss decision
             self.last = ops.multi_scale_loss_backward(outs, targets, self.cw, lf if self.loss_ratio > 0 else None,
-                                                      self.loss_ratio, self.flop_budget)
+                                                      self.loss_ratio, self.flop_budget,
+                                                      total_out=red.loss_slot if shared else None)
             self.last['loss_flop'] = lf.detach()
             ops.join_async()
             self._touched = ops.touched_ids()
@@ -257,14 +264,31 @@ class TrainStep:
                 self.prepack.invalidate()
             ops.PREPACK = prev
 
+    def _rank_dependent_touch(self):
+        """Can the set of parameters that received a gradient differ between ranks?  Dense execution launches the
+        same kernels whatever the data; gate-decision compaction (a rank whose shard holds no sample for a depth
+        stage skips that stage's kernels) and the host-drawn ini_stage branches do not."""
+        m = self.model
+        return bool(getattr(m, 'compact_train', False) or getattr(m, 'ini_stage', False))
+
     def _finish(self):
-        self.reducer.finish()
-        self.opt.step(self._touched, self.last['total'])
+        red = self.reducer
+        red.finish()
+        touched = self._touched
+        if red.world > 1 and red.enabled and touched is not None and self._rank_dependent_touch():
+            # the all-reduced gradient of a parameter is non-zero on EVERY rank as soon as one rank touched it: update the
+            # union, or the replicas drift apart (one MAX all-reduce of a per-parameter mask; these modes already pay a
+            # host read per forward for the stage counts)
+            ids = self.opt._all
+            mask = torch.tensor([1 if i in touched else 0 for i in ids], dtype=torch.int32, device=red.flat.device)
+            dp.dist.all_reduce(mask, op=dp.dist.ReduceOp.MAX, group=red.group)
+            touched = {i for i, v in zip(ids, mask.tolist()) if v}
+        self.opt.step(touched, red.reduced_loss(self.last['total']))
 
     def _graph_key(self, rgb, depth, targets):
         m = self.model
         return (tuple(rgb.shape), tuple(depth.shape), tuple(tuple(t.shape) for t in targets), bool(m.training),
-                float(getattr(m, 'temp', 0.0)), bool(getattr(m, 'hard_gate', False)), bool(getattr(m, 'baseline', False)),
+                bool(getattr(m, 'hard_gate', False)), bool(getattr(m, 'baseline', False)),
                 tuple(getattr(m, 'block_rule', ()) or ()))
 
     def __call__(self, rgb, depth, targets):
@@ -276,14 +300,25 @@ class TrainStep:
             self._body(rgb, depth, targets)
             self._finish()
             return self.last
-        # temp / hard_gate / baseline reach the kernels as by-value arguments or host branches: a capture is
-        # valid for one combination of them (and of the input shapes) only, so captures are keyed on it.
+        # hard_gate / baseline / block_rule reach the kernels as host branches: a capture is valid for one combination
+        # of them (and of the input shapes) only, so captures are keyed on it.  The gate temperature is a by-value
+        # kernel argument that train.py changes EVERY epoch (ExpDecayTemp): it is not part of the key — one capture
+        # per key is kept; when the temperature has moved the old capture is reset (its private memory pool goes back
+        # to the allocator) before the new one is taken, so a long run holds a handful of step-sized pools, not one
+        # per epoch.
         key = self._graph_key(rgb, depth, targets)
+        temp = float(getattr(self.model, 'temp', 0.0))
         entry = self._graphs.get(key)
+        if entry is not None and entry[4] != temp:
+            entry[0].reset()
+            entry = None
         if entry is None:
-            entry = self._capture(rgb, depth, targets)
+            if len(self._graphs) >= self.MAX_GRAPHS and key not in self._graphs:
+                old = next(iter(self._graphs))             # oldest capture (dict order = insertion order)
+                self._graphs.pop(old)[0].reset()
+            entry = self._capture(rgb, depth, targets) + (temp,)
             self._graphs[key] = entry
-        graph, (s_rgb, s_depth, s_t), s_last, touched = entry
+        graph, (s_rgb, s_depth, s_t), s_last, touched, _ = entry
         s_rgb.copy_(rgb)
         s_depth.copy_(depth)
         for a, b in zip(s_t, targets):

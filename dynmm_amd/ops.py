@@ -1525,12 +1525,14 @@ def _param_grad_commit(param, t, ret):
         param.grad = ret if param.grad is None else param.grad + ret
 
 
-def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio=0.0, budget=0.0):
+def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio=0.0, budget=0.0, total_out=None):
     """train.py:313-323 for the HIP path, without a single PyTorch arithmetic kernel: the weighted CE of every
     scale (fp64 accumulators), total = sum_s CE_s + ratio * max(0, flop_loss - budget), and the backward pass of
     the whole step — the gradients of the logits come straight from dynmm_ce2d_bwd, seeded on the device, and are
     handed to autograd as the incoming gradients of the model outputs.
-    Returns {'losses': [S], 'loss_flop': (), 'total': [1]} (detached device tensors)."""
+    Returns {'losses': [S], 'loss_flop': (), 'total': [1]} (detached device tensors).  `total_out`: a 1-element fp32
+    device tensor that receives the total instead of a fresh one (data parallel: the slot that travels with the last
+    gradient bucket, dp.GradBucketReducer.loss_slot)."""
     lib = _lib()
     st = _stream()
     outs = [o if isinstance(o, DeferredLogits) else _chk(o, 'logits') for o in outs]
@@ -1558,6 +1560,10 @@ def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio
         L.check(lib.dynmm_ce2d_fwd(_p(o), _p(t), _p(cw), acc.data_ptr() + 16 * s_, N, Cc, H * W, 1, st), 'ce2d_fwd')
     f32 = dict(device=dev, dtype=torch.float32)
     losses, total, gscale = torch.empty(S, **f32), torch.empty(1, **f32), torch.empty(S, **f32)
+    if total_out is not None:
+        if total_out.numel() != 1 or total_out.dtype != torch.float32 or total_out.device != dev:
+            raise L.DynmmHipError('total_out must be a 1-element fp32 tensor on the logits\' device')
+        total = total_out
     use_flop = flop_loss is not None and flop_loss.requires_grad and ratio > 0
     d_flop = torch.empty((), **f32) if use_flop else None
     lf = flop_loss.detach() if flop_loss is not None else None

@@ -1,0 +1,42 @@
+"""bench.py's own launcher: `python bench.py --gpus N` with no torchrun around it must start N
+ranks; under a launcher (WORLD_SIZE set) it must not spawn again and must refuse a --gpus / WORLD_SIZE mismatch.
+Runs on CPU: DYNMM_BENCH_LAUNCH_PROBE makes every rank join a gloo group, all-reduce a 1 and exit."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, extra_env=None, drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(DYNMM_BENCH_LAUNCH_PROBE='1', OMP_NUM_THREADS='1')
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + argv, env=env, capture_output=True,
+                          text=True, timeout=600)
+
+
+def _line(out):
+    rows = [json.loads(ln) for ln in out.splitlines() if ln.startswith('{')]
+    assert len(rows) == 1, out                     # ONE JSON line, printed by rank 0
+    return rows[0]
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    r = _run(['--gpus', '2', '--steps', '4'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['steps'] == 4
+
+
+def test_single_rank_does_not_spawn():
+    r = _run(['--gpus', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 1 and line['ranks_seen'] == 1
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(['--gpus', '4'], extra_env={'WORLD_SIZE': '1', 'RANK': '0', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29533'})
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)

@@ -80,6 +80,63 @@ def test_bucketed_allreduce_matches_single_process(overlap):
     assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))   # replicas agree bit-for-bit
 
 
+def _worker_uneven(rank, world, port, q):
+    """rank 1 never uses the middle convolution (a rank whose shard skips a depth stage under gate-decision
+    compaction): its buckets complete in a different order than rank 0's — launches must still pair up."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dynmm_amd import dp
+    m = _model()
+    red = dp.GradBucketReducer(m.parameters(), bucket_mb=0.00001, overlap=True)      # one bucket per parameter
+    assert len(red.buckets) == 6
+    torch.manual_seed(100)
+    x = torch.randn(4, 3, 8, 8)
+    lo, hi = dp.shard_batch(4, rank, world)
+    for _ in range(2):
+        red.zero()
+        h = torch.relu(m[0](x[lo:hi]))
+        if rank == 0:
+            h = torch.relu(m[2](h))
+        loss = m[4](h).sum() / 4.0
+        red.set_loss(loss if rank == 0 else loss * float('nan'))     # one rank sees a non-finite loss
+        loss.backward()
+        red.finish()
+    q.put((rank, [p.grad.numpy().copy() for p in m.parameters()], list(red.launch_log),
+           float(red.reduced_loss(loss.detach()).item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_touch_sets_keep_bucket_order_and_share_the_nan():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)
+    x = torch.randn(4, 3, 8, 8)
+    want = None
+    for rank in range(2):
+        ref = _model()
+        h = torch.relu(ref[0](x[2 * rank:2 * rank + 2]))
+        if rank == 0:
+            h = torch.relu(ref[2](h))
+        (ref[4](h).sum() / 4.0).backward()
+        g = [(p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for p in ref.parameters()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    for rank, grads, log, shared_loss in res:
+        assert [b for b, _ in log] == sorted(b for b, _ in log), log        # strictly ascending bucket order on every rank
+        for g, w in zip(grads, want):
+            assert np.allclose(g * 2.0, w, atol=1e-6), rank
+        assert np.isnan(shared_loss)                                         # BOTH ranks see the non-finite loss
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+
+
 def test_shard_batch_partitions():
     from dynmm_amd import dp
     for n, w in ((256, 8), (10, 4), (3, 8)):

@@ -284,7 +284,15 @@ def test_hip_graph_follows_epoch_schedule():
         torch.cuda.synchronize()
         runs[use_graph] = outs
         if use_graph:
-            assert len(step._graphs) == 3                          # (1.0 soft), (0.5 soft), (0.25 hard); ini ran eagerly
+            # one capture per (shapes, hard_gate, baseline, …) key: soft (taken at temp 1.0, RE-captured at 0.5 — the
+            # temperature is not part of the key, ADVICE r2: one capture per epoch would exhaust memory) and hard;
+            # ini ran eagerly
+            assert len(step._graphs) == 2
+            for t_ in (0.2, 0.1, 0.05, 0.02):                      # ExpDecayTemp over further "epochs": the cache stays put
+                m.temp = t_
+                step(rgb, depth, labels)
+            assert len(step._graphs) == 2 and len(step._graphs) <= step.MAX_GRAPHS
+            m.temp = 0.25
         step.opt.check_finite()
     assert len({o['total'].data_ptr() for o in runs[True]}) == len(runs[True])       # no aliasing of `last`
     for a, b in zip(runs[False], runs[True]):
