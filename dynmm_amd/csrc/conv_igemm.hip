@@ -17,34 +17,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_igemm.h"
 #include "conv_small.h"
 #include "vec.h"
 
 namespace dynmm {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct IgemmArgs {
-    const float* x;        // gemm input  [N, Ci, H, W]  (first c_in_split channels)
-    const float* x2;       // remaining input channels or nullptr
-    const float* wp;       // packed weights [K][CoP]  (CoP = Co rounded up to 4)
-    const float* scale;    // [Co] or nullptr
-    const float* shift;    // [Co] or nullptr
-    const float* residual; // like y or nullptr
-    const float* mask;     // like y or nullptr : y *= (mask > 0)
-    float* y;              // gemm output [N, Co(first c_out_split), Ho, Wo]
-    float* y2;             // remaining output channels or nullptr
-    int N, Ci, H, W;
-    int Co, Ho, Wo;
-    int KH, KW, SH, SW, PH, PW;
-    int c_in_split, c_out_split;
-    int act;
-    int M, K, CoP;
-    int CiR;               // weight rows per filter tap: Ci, or Ci rounded up to 16 (zero rows) when 8 <= Ci, Ci % 16 != 0
-    int n_co_tiles, n_pix_tiles;
-    int subpix;            // DGRAD with stride > 1 and Ho % SH == Wo % SW == 0: output pixels are enumerated
-                           // parity class by parity class (see pix_decode), so a tile is (mostly) class-pure
-};
 
 // uniform (SGPR) base + 32-bit per-lane byte offset: lets the compiler pick the
 // `global_load_dword v, v_off, s[base:base+1]` form — one VALU-free address per load instead of a
@@ -56,17 +34,6 @@ __device__ __forceinline__ float4 ldg_f32x4(const float* sbase, unsigned voff_by
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
 }
 
-// Per-workgroup phase timestamps for kernel-structure experiments (scratch/trace/): compiled in only
-// with -DDYNMM_TRACE, never in the shipped library.
-#ifdef DYNMM_TRACE
-__device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: wall clock at start, after prologue, after loop, after epilogue; shader clock at entry, exit
-#define DYNMM_TRACE_MARK(slot)                                                                  \
-    do {                                                                                        \
-        if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 6 + (slot)] = wall_clock64(); \
-    } while (0)
-#else
-#define DYNMM_TRACE_MARK(slot) do {} while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
@@ -547,6 +514,10 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     a.CoP = (a.Co + 3) & ~3;
     static const int no_subpix = env_int("DYNMM_NO_SUBPIX");
     a.subpix = (DGRAD && !generic && !no_subpix && a.SH * a.SW > 1 && a.Ho % a.SH == 0 && a.Wo % a.SW == 0) ? 1 : 0;
+    if (!generic && launch_igemm_v5(a, DGRAD, st)) {      // stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3: the operand-ring kernels
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
 #define DYNMM_IGEMM_LAUNCH(TCO, TPIX, WCO, WPIX)                                               \
     do {                                                                                       \
         a.n_co_tiles = ceil_div(a.Co, TCO);                                                    \
@@ -1709,3 +1680,7 @@ extern "C" int dynmm_reduce_slabs(const float* slabs, float* out, int n, int nsl
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
+
+#ifdef DYNMM_TRACE
+#include "conv_igemm_v5.hip"      // trace build: one translation unit, so both kernel families see g_trace
+#endif

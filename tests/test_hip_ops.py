@@ -56,6 +56,13 @@ CONV_CASES = [
     (3, 128, 8, 8, 64, (3, 3), (2, 2), (1, 1), False, None),         # 4 parity classes, 3x3: 1/2/2/4 live taps
     (2, 32, 21, 37, 8, (5, 5), (2, 2), (0, 0), True, None),          # gate-conv class: direct (no-MFMA) kernel
     (1, 128, 30, 171, 6, (5, 5), (2, 2), (0, 0), True, 'relu'),      # ... 84 output columns = 2 column tiles, Co = 6
+    # operand-ring kernels (conv_igemm_v5.hip): stride 1, same padding, Ci % 32 == 0 >= 64, Co % 64 == 0, W % 4 == 0
+    (3, 128, 10, 12, 128, (3, 3), (1, 1), (1, 1), False, 'relu'),    # 120-pixel images: every 64-pixel tile straddles two
+    (2, 256, 30, 40, 256, (1, 3), (1, 1), (0, 1), True, None),       # halo taps across row ends, 2 channel tiles
+    (5, 64, 6, 8, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),         # 48-pixel images under a 128-pixel tile, ragged M = 240
+    (2, 64, 12, 16, 128, (1, 1), (1, 1), (0, 0), False, None),       # 1x1: no padding at all, 4 K-steps (ring depth)
+    (2, 512, 15, 20, 512, (3, 1), (1, 1), (1, 0), True, None),       # K = 1536: 96 K-steps
+    (1, 96, 8, 16, 192, (3, 3), (1, 1), (1, 1), True, None),         # Ci = 6 chunks, Co = 3 x 64
 ]
 
 
