@@ -37,7 +37,9 @@ __device__ __forceinline__ void wait_vm() {
 
 // One wave instruction: lane l copies the 16 bytes at sbase + voff[l] to LDS byte address lds + 16*l.
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"
+    // (an SALU write of M0 needs one wait state before an LDS-DMA instruction reads it — ISA "manually inserted wait states";
+    // the compiler pads its own code, not inline assembly)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :
                  : "s"(lds_addr), "v"(voff_bytes), "s"(sbase)
                  : "memory", "m0");
@@ -46,9 +48,11 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, u
 template <int I>
 using ic = std::integral_constant<int, I>;
 
-template <int TCO, int TPIX, int WCO, int WPIX, int KW, bool DGRAD>
-__global__ void __launch_bounds__(256, 2) conv_igemm_v5_kernel(const IgemmArgs a) {
-    constexpr int BK = 16, SA = 4, SB = (KW == 3 ? 2 : 4), HALO = (KW == 3 ? 4 : 0);
+template <int TCO, int TPIX, int WCO, int WPIX, int KW, bool DGRAD, int SA, int SB>
+__global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a) {
+    // ring depths: SA weight stages; SB activation stages (KW = 3: two stages of three K-steps each; KW = 1: one per step)
+    constexpr int BK = 16, HALO = (KW == 3 ? 4 : 0);
+    static_assert((SA == 3 || SA == 4) && (KW == 3 ? SB == 2 : (SB == 3 || SB == 4)), "ring depths");
     constexpr int PIXW = TPIX + 2 * HALO;
     constexpr int MCO = WCO / 32, MPIX = WPIX / 32, WAVES_PIX = TPIX / WPIX;
     static_assert((TCO / WCO) * WAVES_PIX == 4, "4 waves per workgroup");
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_v5_kernel(const IgemmArgs a
     auto issue_a = [&]() {
         if (la_t < nsteps) {
             const float* base = a.wp + (size_t)((la_r * KW + la_s) * a.CiR + la_c * BK + wave * NIA * RPI) * a.CoP;
-            const unsigned dst = lds_a + (unsigned)(((la_t & (SA - 1)) * A_STAGE + wave * NIA * 256) * 4);
+            const unsigned dst = lds_a + (unsigned)(((la_t % SA) * A_STAGE + wave * NIA * 256) * 4);
 #pragma unroll
             for (int i = 0; i < NIA; ++i) dma16(base + (size_t)(i * RPI) * a.CoP, a_voff, dst + i * 1024);
             ++la_t;
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_v5_kernel(const IgemmArgs a
     auto issue_b = [&]() {
         if (lb_t < nB) {
             const float* base = a.x + (size_t)(lb_c * BK) * HW;
-            const unsigned dst = lds_b + (unsigned)(((lb_t & (SB - 1)) * B_STAGE + wave * QPW * 4) * 4);
+            const unsigned dst = lds_b + (unsigned)(((lb_t % SB) * B_STAGE + wave * QPW * 4) * 4);
             const int shift = dh_of(lb_r) * a.W * 4;
 #pragma unroll
             for (int i = 0; i < NIB; ++i) {
@@ -178,8 +182,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_v5_kernel(const IgemmArgs a
     // fragments of step `tn` (tap row rn, tap column S) -> register set SET
     auto read_frags = [&](auto set_c, auto s_c, int tn, int btn, int rn) {
         constexpr int SET = decltype(set_c)::value, S = decltype(s_c)::value;
-        const float* Ap = As + (tn & (SA - 1)) * A_STAGE + a_frag;
-        const float* Bn = Bs + (btn & (SB - 1)) * B_STAGE + b_frag + (DW0 + S * DWS);
+        const float* Ap = As + (tn % SA) * A_STAGE + a_frag;
+        const float* Bn = Bs + (btn % SB) * B_STAGE + b_frag + (DW0 + S * DWS);
         const int bit = rn * KW + S;
         const float* Bp[MPIX];
 #pragma unroll
@@ -208,12 +212,24 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_v5_kernel(const IgemmArgs a
     // ---------------------------------------------------------------- prologue: fill the rings
     // Request order = the steady state's (weight stage t at "step" t - SA, activation stage b at the last step of stage
     // b - SB, after that step's weight request), so the loop's wait counts hold from its first iteration on.
+    // (weight stage j belongs to "step" j - SA, activation stage j to step j - SB (KW = 1) or 3j - 4 (KW = 3); within a
+    // step the weight request comes first)
+    constexpr int NEWER_A = (SA - 2) * NIA;
+    constexpr int NEWER_B1 = SB > SA ? (SA - 1) * NIB : ((SA < SB ? SA : SB) - 2) * NIB;     // KW = 1
+    constexpr int NEWER_A1 = SB < SA ? (SB - 2) * NIA : NEWER_A;                               // KW = 1
     if constexpr (KW == 3) {
-        issue_a(); issue_b(); issue_a(); issue_a(); issue_a(); issue_b();
-        wait_vm<3 * NIA + NIB>();
+        if constexpr (SA == 4) { issue_a(); issue_b(); issue_a(); issue_a(); issue_a(); issue_b(); }     // A0 B0 | A1 | A2 | A3 B1
+        else { issue_b(); issue_a(); issue_a(); issue_a(); issue_b(); }                                // B0 | A0 | A1 | A2 B1
+        wait_vm<(SA - 1) * NIA + NIB>();
+    } else if constexpr (SA == SB) {
+        for (int j = 0; j < SA; ++j) { issue_a(); issue_b(); }                                         // A0 B0 | A1 B1 | ...
+        wait_vm<(SA - 1) * (NIA + NIB)>();
+    } else if constexpr (SB > SA) {
+        issue_b(); issue_a(); issue_b(); issue_a(); issue_b(); issue_a(); issue_b();                   // B0 | A0 B1 | A1 B2 | A2 B3
+        wait_vm<2 * NIA + 3 * NIB>();
     } else {
-        issue_a(); issue_b(); issue_a(); issue_b(); issue_a(); issue_b(); issue_a(); issue_b();
-        wait_vm<3 * (NIA + NIB)>();
+        issue_a(); issue_a(); issue_b(); issue_a(); issue_b(); issue_a(); issue_b();                   // A0 | A1 B0 | A2 B1 | A3 B2
+        wait_vm<2 * (NIA + NIB)>();
     }
     __syncthreads();
     read_frags(ic<0>{}, ic<0>{}, 0, 0, 0);
@@ -228,19 +244,17 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_v5_kernel(const IgemmArgs a
         constexpr int SET = decltype(set_c)::value, S = decltype(s_c)::value;
         // loads newer than the ones step tcur+1 needs: weight stages tcur+2, tcur+3 and the activation stage(s)
         // requested together with them
-        if (tcur + 3 >= nsteps) {
+        if (tcur + SA >= nsteps) {
             wait_vm<0>();
-        } else if (KW == 3 && tcur + 8 >= nsteps) {
-            wait_vm<2 * NIA>();                  // the activation requests stop two stages before the weight requests do
         } else if constexpr (KW == 3) {
-            if constexpr (S == 2) wait_vm<2 * NIA>();
-            else wait_vm<2 * NIA + NIB>();
+            if (tcur + 8 >= nsteps) wait_vm<NEWER_A>();     // the activation requests stop two stages before the weight requests do
+            else wait_vm<NEWER_A + (S == 2 ? 0 : NIB)>();
         } else {
-            wait_vm<2 * (NIA + NIB)>();
+            wait_vm<NEWER_A1 + NEWER_B1>();
         }
         __syncthreads();
         issue_a();
-        if constexpr (S == KW - 1) issue_b();
+        if constexpr (KW == 1 || S == KW - 1) issue_b();
         // (unconditional: after the last step this reads a dead slot — branch-free, so the reads and the MFMAs below
         // stay in one scheduling region)
         if constexpr (S == KW - 1) {
@@ -386,9 +400,12 @@ static int env_int_v5(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// -1: follow DYNMM_IGEMM_V5 (default on); 0 / 1: forced by dynmm_debug_set_igemm_v5 (A/B inside one process: scratch/v5_ab.py)
+static int g_v5_override = -1;
+
 bool igemm_v5_eligible(const IgemmArgs& a, bool dgrad) {
     static const int on = env_int_v5("DYNMM_IGEMM_V5", 1);
-    if (!on) return false;
+    if (!(g_v5_override >= 0 ? g_v5_override : on)) return false;
     (void)dgrad;
     if (a.x2 || a.y2) return false;                                           // one input, one output tensor
     if (a.SH != 1 || a.SW != 1) return false;
@@ -412,25 +429,57 @@ bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st) {
     a.K = a.KH * a.KW * a.Ci;
     a.CoP = a.Co;
     a.subpix = 0;
+    static const int sa_env = env_int_v5("DYNMM_V5_SA", 3), sb_env = env_int_v5("DYNMM_V5_SB", 3);
+#define DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, KW_, DG_)                                                                    \
+    do {                                                                                                               \
+        if (KW_ == 3) {                                                                                                \
+            if (sa_env == 4) hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, KW_, DG_, 4, KW_ == 3 ? 2 : 4>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, KW_, DG_, 3, KW_ == 3 ? 2 : 4>), grid, dim3(256), 0, st, a); \
+        } else if (sa_env == 4) {                                                                                      \
+            if (sb_env == 3) hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, KW_, DG_, 4, KW_ == 3 ? 2 : 3>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, KW_, DG_, 4, KW_ == 3 ? 2 : 4>), grid, dim3(256), 0, st, a); \
+        } else {                                                                                                       \
+            if (sb_env == 3) hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, KW_, DG_, 3, KW_ == 3 ? 2 : 3>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, KW_, DG_, 3, KW_ == 3 ? 2 : 4>), grid, dim3(256), 0, st, a); \
+        }                                                                                                              \
+    } while (0)
 #define DYNMM_V5_LAUNCH(TCO, TPIX, WCO, WPIX)                                                                          \
     do {                                                                                                               \
         a.n_co_tiles = a.Co / TCO;                                                                                     \
         a.n_pix_tiles = ceil_div(a.M, TPIX);                                                                           \
         dim3 grid((unsigned)(a.n_co_tiles * a.n_pix_tiles));                                                           \
         if (a.KW == 3) {                                                                                               \
-            if (dgrad) hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, 3, true>), grid, dim3(256), 0, st, a);  \
-            else hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, 3, false>), grid, dim3(256), 0, st, a);      \
+            if (dgrad) DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 3, true);                                                     \
+            else DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 3, false);                                                          \
         } else {                                                                                                       \
-            if (dgrad) hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, 1, true>), grid, dim3(256), 0, st, a);  \
-            else hipLaunchKernelGGL((conv_igemm_v5_kernel<TCO, TPIX, WCO, WPIX, 1, false>), grid, dim3(256), 0, st, a);      \
+            if (dgrad) DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 1, true);                                                     \
+            else DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 1, false);                                                          \
         }                                                                                                              \
     } while (0)
     if (a.Co % 128 == 0)
         DYNMM_V5_LAUNCH(128, 64, 64, 32);
     else
         DYNMM_V5_LAUNCH(64, 128, 32, 64);
+#undef DYNMM_V5_GO
 #undef DYNMM_V5_LAUNCH
     return true;
 }
 
 }  // namespace dynmm
+
+extern "C" int dynmm_debug_set_igemm_v5(int mode) {
+    dynmm::g_v5_override = mode;
+    return 0;
+}
+
+// Geometry-only form of igemm_v5_eligible (pointer alignment aside) for profiling tools that label launches:
+// 1 if dynmm_conv2d_fwd (dgrad = 0) / dynmm_conv2d_dgrad (dgrad = 1) serve this convolution with the operand-ring kernels.
+extern "C" int dynmm_conv2d_uses_operand_ring(const dynmm_conv_geom* g, int dgrad) {
+    if (!g || g->c_split != g->Ci) return 0;
+    dynmm::IgemmArgs a{};
+    a.N = g->N; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    if (dgrad) { a.Ci = g->Co; a.H = g->Ho; a.W = g->Wo; a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W; }
+    else { a.Ci = g->Ci; a.H = g->H; a.W = g->W; a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo; }
+    a.c_out_split = a.Co;
+    return dynmm::igemm_v5_eligible(a, dgrad != 0) ? 1 : 0;
+}

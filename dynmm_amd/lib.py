@@ -33,6 +33,8 @@ _PP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     'dynmm_abi_version': (c_i, []),
     'dynmm_build_info': (C.c_char_p, []),
+    'dynmm_debug_set_igemm_v5': (c_i, [c_i]),
+    'dynmm_conv2d_uses_operand_ring': (c_i, [_GP, c_i]),
     'dynmm_packed_weight_floats': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'dynmm_pack_weight': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_pack_weight_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),

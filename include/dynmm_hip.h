@@ -39,6 +39,12 @@ extern "C" {
 int dynmm_abi_version(void);
 const char* dynmm_build_info(void);
 
+/* A/B switch for tests and measurement tools: which implicit-GEMM generation serves the stride-1 same-padded
+ * 1x1 / 3x1 / 1x3 / 3x3 convolutions (forward + input gradient).  mode 1 = the operand-ring kernels
+ * (csrc/conv_igemm_v5.hip), 0 = the register-staged kernels (csrc/conv_igemm.hip), -1 = follow the environment
+ * (DYNMM_IGEMM_V5, default 1).  Process-wide; not meant to be flipped while launches are being issued from other threads. */
+int dynmm_debug_set_igemm_v5(int mode);
+
 /* Geometry of one convolution, shared by fwd / dgrad / wgrad.
  * x:[N,Ci,H,W]  w:[Co,Ci,KH,KW]  y:[N,Co,Ho,Wo], Ho = (H+2PH-KH)/SH+1 (same for W). groups = 1.
  * If x2 != NULL the logical input is cat([x, x2], dim=1) with x holding the first `c_split`
@@ -49,6 +55,10 @@ typedef struct {
     int KH, KW, SH, SW, PH, PW;
     int c_split; /* == Ci when x2 is NULL */
 } dynmm_conv_geom;
+
+/* 1 if dynmm_conv2d_fwd (dgrad = 0) / dynmm_conv2d_dgrad (dgrad = 1) serve this geometry with the operand-ring kernels
+ * (csrc/conv_igemm_v5.hip; 16-byte aligned operands assumed) — for tools that label launches (bench.py's roofline leg). */
+int dynmm_conv2d_uses_operand_ring(const dynmm_conv_geom* g, int dgrad);
 
 /* Re-layout of a conv weight for the implicit-GEMM kernels (done per step; weights are small).
  *   wp_fwd  [(tap*CiR+ci)][CoP]  (tap = r*KW+s)   — operand of dynmm_conv2d_fwd
