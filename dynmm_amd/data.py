@@ -32,4 +32,29 @@ class SyntheticRGBD:
             yield {'image': rgb, 'depth': depth, 'label': label, 'label_down': down, 'label_orig': label}
 
     def compute_class_weights(self, weight_mode='median_frequency', c=1.02):
-        return torch.linspace(0.5, 2.0, self.n_classes_without_void).numpy()
+        """src/datasets/dataset_base.py:147-208 over this source's own label maps (void = class 0 removed):
+        median_frequency = median(f) / f with f = pixels of the class / pixels of the images containing it;
+        logarithmic = 1 / log(c + p); linear = pixel counts."""
+        import numpy as np
+        if weight_mode not in ('median_frequency', 'logarithmic', 'linear'):
+            raise ValueError(f'unknown class weighting {weight_mode!r}')
+        n_cls = self.n_classes_without_void + 1
+        per_class, with_class = np.zeros(n_cls), np.zeros(n_cls)
+        for i in range(len(self)):
+            n = min(self.bs, self.n - i * self.bs)
+            label = synth.synth_labels(n, self.h, self.w, seed=self.seed + 17 * i + 1, device='cpu')
+            for img in label.reshape(n, -1).to(torch.int64):
+                dist = np.bincount(img.numpy(), minlength=n_cls)[:n_cls]
+                per_class += dist
+                with_class += (dist > 0) * img.numel()
+        per_class, with_class = per_class[1:], with_class[1:]
+        if weight_mode == 'linear':
+            w = per_class
+        elif weight_mode == 'median_frequency':
+            freq = per_class / with_class
+            w = np.median(freq) / freq
+        else:
+            w = 1.0 / np.log(c + per_class / per_class.sum())
+        if np.isnan(np.sum(w)):
+            raise ValueError('class weighting contains NaNs')
+        return w

@@ -40,6 +40,16 @@ class FlatParameters:
                 off += n
 
 
+    def refresh(self):
+        """Assert that every parameter still is a view of the flat buffer (load_state_dict copies into the views; code
+        that REPLACES `.data` would silently detach a parameter from the fused optimizer)."""
+        base = self.flat.data_ptr()
+        for q in self.params:
+            lo, _ = self.span[id(q)]
+            if q.data_ptr() != base + 4 * lo:
+                raise RuntimeError('a parameter was re-homed outside the flat buffer; rebuild TrainStep after replacing parameters')
+
+
 def _merge(spans):
     out = []
     for lo, hi in sorted(spans):
@@ -107,6 +117,67 @@ class _FlatOptimizer:
             for lo, hi in ranges:
                 self._launch(lib, lo, hi, sp, lp, st)
 
+    # -- checkpoints: torch.optim's own state_dict layout (train.py:131-135 / src/utils.py:118-175), so that a run can be
+    # resumed by either implementation.  Parameter indices follow model.parameters() (what train.py hands to torch.optim);
+    # TrainStep sets `param_index` / `n_params`; per-parameter tensors are views of the flat state buffers.
+    param_index = None
+    n_params = None
+    STATE_KEYS = ()
+
+    def _index(self):
+        if self.param_index is not None:
+            return self.param_index, self.n_params
+        return {id(q): i for i, q in enumerate(self.fp.params)}, len(self.fp.params)
+
+    def _group_dict(self, n):
+        raise NotImplementedError
+
+    def state_dict(self):
+        index, n = self._index()
+        steps = self.steps.tolist()
+        state = {}
+        for q in self.fp.params:
+            if steps[self.group_of[id(q)]] == 0:
+                continue                                   # torch.optim keeps no state for a parameter it never stepped
+            lo, hi = self.fp.span[id(q)]
+            ent = {k: buf[lo:hi].view_as(q).clone() for k, buf in zip(self.STATE_KEYS, self.state_tensors()[:len(self.STATE_KEYS)])}
+            if 'exp_avg' in ent:
+                ent['step'] = torch.tensor(float(steps[self.group_of[id(q)]]))
+            state[index[id(q)]] = ent
+        return {'state': state, 'param_groups': [self._group_dict(n)],
+                'dynmm': {'steps': self.steps.clone(), 'hyper': self.hyper.clone(), 'groups': list(self.group_names)}}
+
+    def load_state_dict(self, sd):
+        index, _ = self._index()
+        if 'param_groups' not in sd:                       # rounds 1-2 layout: the flat buffers themselves
+            for key, buf in zip(('momentum_buffer', 'exp_avg', 'exp_avg_sq'), self.state_tensors()):
+                if key in sd:
+                    buf.copy_(sd[key])
+            if 'steps' in sd:
+                self.steps.copy_(sd['steps'])
+            return
+        state = sd['state']
+        seen = {}
+        with torch.no_grad():
+            for q in self.fp.params:
+                ent = state.get(index[id(q)])
+                if ent is None:
+                    continue
+                lo, hi = self.fp.span[id(q)]
+                for k, buf in zip(self.STATE_KEYS, self.state_tensors()[:len(self.STATE_KEYS)]):
+                    if ent.get(k) is not None:
+                        buf[lo:hi].copy_(ent[k].reshape(-1).to(buf.device))
+                seen[self.group_of[id(q)]] = int(float(ent['step'])) if 'step' in ent else 1
+        extra = sd.get('dynmm')
+        if extra is not None and list(extra.get('groups', [])) == list(self.group_names):
+            self.steps.copy_(extra['steps'].to(self.steps.device))
+        else:                                              # a torch.optim checkpoint: per-parameter step counters
+            for gi, n_ in seen.items():
+                self.steps[gi:gi + 1].fill_(n_)
+        grp = sd['param_groups'][0]
+        if 'lr' in grp:
+            self.set_lr(grp['lr'])
+
     def check_finite(self):
         """Raise the reference's error if any step since the last call saw a non-finite loss (one D2H read)."""
         v = int(self.nan_flag.item())
@@ -130,8 +201,17 @@ class SGDNesterov(_FlatOptimizer):
                                        C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), self.weight_decay,
                                        1.0, lp, self.nan_flag.data_ptr(), sp, st), 'sgd_nesterov')
 
-    def state_dict(self):
-        return {'kind': 'SGD', 'momentum_buffer': self.buf, 'hyper': self.hyper, 'steps': self.steps}
+    STATE_KEYS = ('momentum_buffer',)
+
+    def _group_dict(self, n):
+        h = self.hyper.tolist()
+        return {'lr': h[0], 'momentum': h[1], 'dampening': 0, 'weight_decay': self.weight_decay, 'nesterov': True,
+                'maximize': False, 'foreach': None, 'differentiable': False, 'fused': None, 'params': list(range(n))}
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        if 'param_groups' in sd and 'momentum' in sd['param_groups'][0]:
+            self.set_momentum(sd['param_groups'][0]['momentum'])
 
     def state_tensors(self):
         return [self.buf, self.steps]
@@ -158,8 +238,13 @@ class Adam(_FlatOptimizer):
                                lp, self.nan_flag.data_ptr(), int(self.decoupled),
                                None if self.grad_scale_dev is None else self.grad_scale_dev.data_ptr(), st), 'adam')
 
-    def state_dict(self):
-        return {'kind': 'Adam', 'exp_avg': self.m, 'exp_avg_sq': self.v, 'hyper': self.hyper, 'steps': self.steps}
+    STATE_KEYS = ('exp_avg', 'exp_avg_sq')
+
+    def _group_dict(self, n):
+        h = self.hyper.tolist()
+        return {'lr': h[0], 'betas': (h[1], h[2]), 'eps': h[3], 'weight_decay': self.weight_decay, 'amsgrad': False,
+                'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                'params': list(range(n))}
 
     def state_tensors(self):
         return [self.m, self.v, self.steps]
@@ -207,6 +292,8 @@ class TrainStep:
             self.opt = Adam(self.flatp, self.reducer.flat, lr, weight_decay=weight_decay, groups=groups)
         else:
             raise NotImplementedError(f'Currently only SGD and Adam as optimizers are supported. Got {optimizer}')
+        allp = list(model.parameters())                 # torch.optim's parameter numbering (train.py:557-570)
+        self.opt.param_index, self.opt.n_params = {id(q): i for i, q in enumerate(allp)}, len(allp)
         # 3-stream schedule: RGB encoder | depth encoder | conv weight gradients (see nn/net.py, ops.py)
         self.multi_stream = bool(multi_stream)
         # None: on unless DYNMM_NO_FUSED_TAIL is set (A/B switch for bench.py / tests)

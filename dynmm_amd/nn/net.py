@@ -106,14 +106,18 @@ class SkipGateESANet(nn.Module):
             raise NotImplementedError('Only encoder_decoder_fusion="add" is implemented')
         if fuse_depth_in_rgb_encoder not in ('add', 'SE-add'):
             raise NotImplementedError('fuse_depth_in_rgb_encoder must be "add" or "SE-add"')
-        if pretrained_on_imagenet:
-            warnings.warn('ImageNet weights are not available offline; load a checkpoint with load_state_dict')
         self.fuse_depth_in_rgb_encoder = fuse_depth_in_rgb_encoder
         self.block_rule = block_rule if block_rule else [1, 1, 1, 1]
         self.height, self.width = height, width
 
         self.encoder_rgb = ResNetEncoder(encoder_rgb, encoder_block, input_channels=3)
         self.encoder_depth = ResNetEncoder(encoder_depth, encoder_block, input_channels=1)
+        if pretrained_on_imagenet:
+            # resnet.py:395-509, from local files (raises FileNotFoundError when they are absent — never a silent
+            # random initialisation)
+            from ..src.pretrained import load_imagenet_encoder
+            load_imagenet_encoder(self.encoder_rgb, encoder_rgb, encoder_block, 3, pretrained_dir)
+            load_imagenet_encoder(self.encoder_depth, encoder_depth, encoder_block, 1, pretrained_dir)
         enc = self.encoder_rgb
         self.channels_decoder_in = enc.down_32_channels_out
 

@@ -42,14 +42,16 @@ class SkipESANet(nn.Module):
             raise NotImplementedError('Only learned-3x3-zeropad upsampling is implemented. Got {}'.format(upsampling))
         if encoder_decoder_fusion != 'add':
             raise NotImplementedError('Only encoder_decoder_fusion="add" is implemented')
-        if pretrained_on_imagenet:
-            warnings.warn('ImageNet weights are not available offline; load a checkpoint with load_state_dict')
         self.fuse_depth_in_rgb_encoder = fuse_depth_in_rgb_encoder
         self.block_rule = block_rule if block_rule else [1, 1, 1, 1]
         self.height, self.width = height, width
 
         self.encoder_rgb = ResNetEncoder(encoder_rgb, encoder_block, input_channels=3)
         self.encoder_depth = ResNetEncoder(encoder_depth, encoder_block, input_channels=1)
+        if pretrained_on_imagenet:                    # resnet.py:395-509, local files only (loud when absent)
+            from ..src.pretrained import load_imagenet_encoder
+            load_imagenet_encoder(self.encoder_rgb, encoder_rgb, encoder_block, 3, pretrained_dir)
+            load_imagenet_encoder(self.encoder_depth, encoder_depth, encoder_block, 1, pretrained_dir)
         enc = self.encoder_rgb
         self.channels_decoder_in = enc.down_32_channels_out
         stage_ch = (64, enc.down_4_channels_out, enc.down_8_channels_out, enc.down_16_channels_out,

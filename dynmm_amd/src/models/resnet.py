@@ -1,12 +1,15 @@
 """Counterpart of FusionDynMM/src/models/resnet.py (ResNet-18/34/50 trunks used by the hot path)."""
 from ...nn.blocks import BasicBlock, Bottleneck, NonBottleneck1D, ResNetEncoder as ResNet  # noqa: F401
+from ..pretrained import load_imagenet_encoder
 
 
-def _make(name, block='BasicBlock', pretrained_on_imagenet=False, pretrained_dir=None,
+def _make(name, block='BasicBlock', pretrained_on_imagenet=False, pretrained_dir='./trained_models/imagenet',
           input_channels=3, activation=None):
-    if pretrained_on_imagenet:
-        raise NotImplementedError('offline build: load weights with load_state_dict instead')
-    return ResNet(name, block if isinstance(block, str) else block.__name__, input_channels)
+    block = block if isinstance(block, str) else block.__name__
+    model = ResNet(name, block, input_channels)
+    if pretrained_on_imagenet:             # resnet.py:395-466 / :469-509, from local files
+        load_imagenet_encoder(model, name, 'Bottleneck' if name == 'resnet50' else block, input_channels, pretrained_dir)
+    return model
 
 
 def ResNet18(**kw):

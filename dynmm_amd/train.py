@@ -18,6 +18,7 @@ from . import dp, engine, schedules
 from .data import SyntheticRGBD
 from .src.args import ArgumentParserRGBDSegmentation
 from .src.build_model import build_model
+from .src.pretrained import load_ckpt
 
 
 def parse_args(argv=None):
@@ -31,10 +32,13 @@ def parse_args(argv=None):
     return args
 
 
-def save_ckpt(ckpt_dir, model, opt, epoch):
-    """Same keys as src/utils.py:118-127."""
+def save_ckpt(ckpt_dir, model, opt, epoch, best_miou=None, best_miou_epoch=None):
+    """Same keys as src/utils.py:118-127 (+ the best-mIoU bookkeeping load_ckpt looks for, :160-170)."""
     path = os.path.join(ckpt_dir, f'ckpt_epoch_{epoch}.pth')
-    torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': opt.state_dict()}, path)
+    state = {'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': opt.state_dict()}
+    if best_miou is not None:
+        state.update(best_miou=best_miou, best_miou_epoch=best_miou_epoch)
+    torch.save(state, path)
     return path
 
 
@@ -63,7 +67,7 @@ def train_main(argv=None):
 
 def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
     dp.broadcast_parameters(model)
-    cw = train_loader.compute_class_weights(args.class_weighting) if args.class_weighting != 'None' else np.ones(40)
+    cw = train_loader.compute_class_weights(args.class_weighting, c=args.c_for_logarithmic_weighting) if args.class_weighting != 'None' else np.ones(40)
     if args.freeze and args.dynamic:                      # train.py:139-141
         print('Freeze everything but the soft gates')
         model.freeze()
@@ -74,7 +78,12 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
     temp = schedules.ExpDecayTemp(args.temp, args.end_temp, args.epoch_hard)
     model.baseline = args.baseline
     best_miou, best_epoch, best_state, logs = 0.0, 0, None, []
-    for epoch in range(args.epochs):
+    start_epoch = 0
+    if args.last_ckpt:                                    # train.py:131-135: model + optimizer state + epoch counter
+        last, best_miou, best_epoch = load_ckpt(model, step.opt, args.last_ckpt)
+        start_epoch = last + 1
+        step.flatp.refresh()                              # load_state_dict copied INTO the flat views; nothing to re-home
+    for epoch in range(start_epoch, args.epochs):
         assert args.epoch_ini <= args.epoch_hard
         model.ini_stage = epoch < args.epoch_ini
         model.hard_gate = epoch >= args.epoch_hard
@@ -115,7 +124,7 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
             print(f"Epoch {epoch} | Train loss {row['loss_train_total']:.4f} | Flop loss {row['loss_flop']:.4f} "
                   f"Temperature {model.temp} | lr {lr}" + (f" | mIoU {row['mIoU_test']:.2f}" if 'mIoU_test' in row else ''))
             if epoch >= 10 and epoch % args.save_every == args.save_every - 1:
-                save_ckpt(ckpt_dir, model, step.opt, epoch)
+                save_ckpt(ckpt_dir, model, step.opt, epoch, best_miou, best_epoch)
         logs.append(row)
     if rank == 0:
         # train.py:250: the BEST model's weights under the best epoch's name

@@ -241,6 +241,13 @@ def forward(sd, rgb, depth, cfg: Config, training=False, test=False, return_weig
     return out, loss
 
 
+def forward_esanet(sd, rgb, depth, cfg: Config, training=False):
+    """ESANet.forward (src/models/model.py:189-241): the static network — depth fused into the RGB encoder at the stem and
+    after every stage, no gate, `out` only (a 4-tuple in training mode, model.py:306-308).  With weight = e_4 the blend of
+    `forward` above is w = 0 for stages 1-3 (fuse = fused, :282-301) and w = 1 in the swapped stage-4 rule (:309-310)."""
+    return forward(sd, rgb, depth, cfg, training=training, test=True, baseline=True)
+
+
 # --------------------------------------------------------------------------------------------
 # SkipESANet: per-stage Gumbel gates (SURVEY.md §8f-3)
 # --------------------------------------------------------------------------------------------

@@ -15,6 +15,8 @@ What is stored (data only: inputs are regenerated from dynmm_amd.synth on both s
   nyu8_P_se.npz            BASELINE config[0] restated on 8 synthetic NYUv2-like pairs, 480x640,
                            eval --baseline: strided logits, argmax histogram, CM and mIoU.
   ops.npz                  DiffSoftmax cases, Upsample fixed init, CE loss, temperature schedule.
+  esanet_P_se_96x128.npz   the STATIC model (src/models/model.py:19-241, what build_model returns without --dynamic):
+                           state_dict contract, eval logits, train outputs + gradient norms / samples.
   skip_P_96x128.npz        SkipESANet (per-stage Gumbel gates, model_skip_mod.py): per mode the Exp(1) draws
                            injected into F.gumbel_softmax (Tensor.exponential_ patched process-locally),
                            the four gate weights, strided logits and, for train modes, gradient norms.
@@ -36,7 +38,7 @@ warnings.filterwarnings('ignore')
 
 from src.models.model_skip_mod_globalgate import SkipGateESANet, DiffSoftmax  # noqa: E402
 from src.models.model_skip_mod import SkipESANet                               # noqa: E402
-from src.models.model import Upsample                                          # noqa: E402
+from src.models.model import Upsample, ESANet                                  # noqa: E402
 from src import utils as ref_utils                                             # noqa: E402
 
 from dynmm_amd import synth                                                    # noqa: E402
@@ -402,6 +404,47 @@ def skip_fixture():
     np.savez_compressed(os.path.join(HERE, 'skip_P_96x128.npz'), **blob)
 
 
+def esanet_fixture():
+    """ESANet (src/models/model.py:19-241): the static fuse-at-every-stage network `build_model` returns when --dynamic is
+    not given (src/build_model.py:93-113); config P (ResNet-34 / NonBottleneck1D / SE-add / 3 decoder blocks)."""
+    h, w, n = 96, 128, 2
+    blob = {'meta': np.array([h, w, n, STRIDE])}
+
+    def make():
+        m = ESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34', encoder_depth='resnet34',
+                   encoder_block='NonBottleneck1D', channels_decoder=[128, 128, 128], nr_decoder_blocks=[3, 3, 3],
+                   pretrained_on_imagenet=False, fuse_depth_in_rgb_encoder='SE-add', upsampling='learned-3x3-zeropad')
+        synth.fill_state_dict(m.state_dict(), seed=0)
+        return m
+    m = make()
+    sd = m.state_dict()
+    blob['keys'] = np.array(list(sd.keys()))
+    blob['shapes'] = np.array([','.join(map(str, v.shape)) for v in sd.values()])
+    blob['dtypes'] = np.array([str(v.dtype) for v in sd.values()])
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    m.eval()
+    with torch.no_grad():
+        out = m(rgb, depth)
+    for k, v in summarize_logits(out).items():
+        blob[f'eval/{k}'] = v
+    m = make()
+    m.train()
+    outs = m(rgb, depth)
+    loss = train_loss(outs, torch.zeros(()))
+    loss.backward()
+    for k, v in summarize_logits(outs[0]).items():
+        blob[f'train/{k}'] = v
+    for i, o in enumerate(outs[1:]):
+        blob[f'train/side{i}'] = o.detach().numpy()
+    blob['train/loss'] = np.float32(loss.item())
+    names = [k for k, _ in m.named_parameters()]
+    blob['train/grad_names'] = np.array(names)
+    blob['train/grad_norms'] = np.array([p.grad.norm().item() for _, p in m.named_parameters()], np.float64)
+    for name in ('encoder_depth.conv1.weight', 'decoder.conv_out.bias', 'se_layer2.se_rgb.fc.0.weight'):
+        blob['train/grad:' + name] = dict(m.named_parameters())[name].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'esanet_P_se_96x128.npz'), **blob)
+
+
 def contract_fixture():
     """state_dict keys / shapes / dtypes of the reference model (the strict-load contract, eval.py:61)."""
     blob = {}
@@ -422,6 +465,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'r50':
         model_fixture('R50_se', 96, 128, 2, ['eval_hard', 'train_soft'])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'esanet':
+        esanet_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'skip':
         skip_fixture()
@@ -444,5 +490,6 @@ if __name__ == '__main__':
     model_fixture('R50_se', 96, 128, 2, ['eval_hard', 'train_soft'])
     nyu8_fixture()
     skip_fixture()
+    esanet_fixture()
     train_n8_fixture()
     print('done')
