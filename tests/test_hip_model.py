@@ -15,8 +15,30 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-4        # eval-mode logits (fp32 oracle vs fp64 oracle differ by ~4e-5 themselves)
 TRAIN_OUT_TOL = 1e-3    # train-mode outputs incl. 3x4 side maps: batch-stat BN amplifies rounding; north_star bar
-GRAD_NORM_TOL = 0.2   # whole-model fp32 gradients are ill-conditioned (see test_model_vs_oracle_*)
+# Whole-model fp32 gradients are ill-conditioned (see test_model_vs_oracle_*).  The bars are CALIBRATED: tests/golden/
+# grad_noise.npz (tests/golden/make_grad_noise.py) holds, per fixture, how far the fp32 CPU oracle itself moves between
+# summation orders (thread counts 1 / 8, oneDNN / native convolutions) — the worst deviation of a per-parameter gradient
+# norm and of a stored full gradient tensor from the reference's fp32 values.  HIP is held to that range x 1.25 (floor
+# 0.05: a 4-draw maximum under-estimates the range of the well-conditioned fixtures); fixtures without a row keep the
+# round-2 constants.
+GRAD_NORM_TOL = 0.2
 GRAD_FULL_TOL = 0.25
+NOISE_MARGIN = 1.25
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def grad_noise():
+    return np.load(os.path.join(GOLDEN, 'grad_noise.npz'))
+
+
+def calibrated_tols(cfg, h, w, mode):
+    g = grad_noise()
+    tags = [str(t) for t in g['small_fixtures']]
+    tag = f'{cfg} {h}x{w} {mode}'
+    if tag not in tags:
+        return GRAD_NORM_TOL, GRAD_FULL_TOL
+    nrm, full = g['small'][tags.index(tag)]
+    return max(NOISE_MARGIN * float(nrm), 0.05), max(NOISE_MARGIN * float(full), 0.05)
 
 
 def hip_model(cfg_name, h, w, seed=0):
@@ -75,12 +97,15 @@ def test_model_matches_reference_goldens(golden_dir, cfg, h, w):
             names = [str(s) for s in g[f'{mode}/grad_names']]
             norms = np.array([0.0 if params[nm].grad is None else params[nm].grad.norm().item() for nm in names])
             ref = g[f'{mode}/grad_norms']
-            bad = np.abs(norms - ref) > GRAD_NORM_TOL * np.maximum(ref, 1e-2 * ref.max())
+            norm_tol, full_tol = calibrated_tols(cfg, hh, ww, mode)
+            dev = np.abs(norms - ref) / np.maximum(ref, 1e-2 * ref.max())
+            print(f'{cfg} {hh}x{ww} {mode}: worst gradient-norm deviation {dev.max():.4f} (bar {norm_tol:.4f})')
+            bad = dev > norm_tol
             assert not bad.any(), [(names[i], norms[i], ref[i]) for i in np.nonzero(bad)[0][:8]]
             sd = m.state_dict()
             for k in g.files:
                 if k.startswith(f'{mode}/grad:') and np.abs(g[k]).max() > 1e-6:   # skip analytically-zero grads
-                    assert Hh.rel_err(params[k.split('grad:')[1]].grad.cpu(), g[k]) < GRAD_FULL_TOL, k
+                    assert Hh.rel_err(params[k.split('grad:')[1]].grad.cpu(), g[k]) < full_tol, k
                 if k.startswith(f'{mode}/rm:'):
                     assert Hh.rel_err(sd[k.split('rm:')[1] + '.running_mean'].cpu(), g[k]) < 1e-4, k
                 if k.startswith(f'{mode}/rv:'):
@@ -389,16 +414,21 @@ def test_train_step_matches_reference_n8_fixture(golden_dir):
     # least as accurate against fp64 as the CPU's own fp32 conv (scratch/stem_acc.py: 2.2e-7 / 5.1e-7 rms) moved the
     # median over 2.27e-2 .. 2.80e-2, the p95 over 2.66e-2 .. 3.48e-2 and the max over 0.92e-1 .. 1.58e-1 (fp32 oracle:
     # 1.96e-2 / 2.22e-2 / 1.02e-1).  The bars sit at 2x / 2x / 3x of the oracle's own fp32 error.
-    assert np.median(e_hip) <= 2.0 * np.median(e_ref) + 1e-5, (np.median(e_hip), np.median(e_ref))
-    assert np.percentile(e_hip, 95) <= 2.0 * np.percentile(e_ref, 95) + 1e-5
-    assert e_hip.max() <= 3.0 * e_ref.max() + 1e-5, (e_hip.max(), e_ref.max())
+    # Round 3: the noise floor is CALIBRATED — the fp32 CPU oracle under 6 summation orders against the same fp64 truth at
+    # this very point (grad_noise.npz 'n8': median 1.20e-2..1.58e-2, p95 1.61e-2..2.08e-2, max 4.0e-2..6.3e-2) — and HIP must sit inside the observed range x 1.25
+    # (round 2: 2x / 2x / 3x of ONE draw).
+    bars = NOISE_MARGIN * grad_noise()['n8'].max(axis=0)
+    print(f'calibrated bars (median / p95 / max / cosine deficit): {bars[0]:.3e} {bars[1]:.3e} {bars[2]:.3e} {NOISE_MARGIN * bars[3]:.3e}')
+    assert np.median(e_hip) <= bars[0], (np.median(e_hip), bars[0])
+    assert np.percentile(e_hip, 95) <= bars[1], (np.percentile(e_hip, 95), bars[1])
+    assert e_hip.max() <= bars[2], (e_hip.max(), bars[2])
     A, B32, B64 = (torch.cat(cat[k]) for k in ('hip', 'f32', 'f64'))
     cos64 = torch.nn.functional.cosine_similarity(A, B64, dim=0).item()
     cos_ref = torch.nn.functional.cosine_similarity(B32, B64, dim=0).item()
     print(f'n8 fixture: grad err vs fp64 median {np.median(e_hip):.2e} (reference fp32: {np.median(e_ref):.2e}), '
           f'max {e_hip.max():.2e} ({e_ref.max():.2e}); vs fp32 reference median {np.median(e_h32):.2e}; '
           f'cosine {cos64:.6f} (reference fp32: {cos_ref:.6f})')
-    assert 1 - cos64 <= 2 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
+    assert 1 - cos64 <= NOISE_MARGIN * bars[3], (cos64, bars[3])          # (quadratic in the error: margin^2 on the deficit)
     # against the reference's fp32 gradients directly: both sides carry ~1e-2 of fp32 conditioning noise
     assert np.median(e_h32) < 2.5e-2 and e_h32.max() < 8e-2, (np.median(e_h32), e_h32.max())
 
@@ -456,9 +486,14 @@ def test_train_step_parity_at_benchmark_resolution():
     # least as accurate against fp64 as the CPU's own fp32 conv (scratch/stem_acc.py: 2.2e-7 / 5.1e-7 rms) moved the
     # median over 2.27e-2 .. 2.80e-2, the p95 over 2.66e-2 .. 3.48e-2 and the max over 0.92e-1 .. 1.58e-1 (fp32 oracle:
     # 1.96e-2 / 2.22e-2 / 1.02e-1).  The bars sit at 2x / 2x / 3x of the oracle's own fp32 error.
-    assert np.median(e_hip) <= 2.0 * np.median(e_ref) + 1e-5, (np.median(e_hip), np.median(e_ref))
-    assert np.percentile(e_hip, 95) <= 2.0 * np.percentile(e_ref, 95) + 1e-5
-    assert e_hip.max() <= 3.0 * e_ref.max() + 1e-5, (e_hip.max(), e_ref.max())
+    # Round 3: the noise floor is CALIBRATED — the fp32 CPU oracle under 6 summation orders against the same fp64 truth at
+    # this very point (grad_noise.npz 'b2_480x640': median 1.89e-2..2.71e-2, p95 2.23e-2..3.34e-2, max 6.8e-2..1.9e-1) — and HIP must sit inside the observed range x 1.25
+    # (round 2: 2x / 2x / 3x of ONE draw).
+    bars = NOISE_MARGIN * grad_noise()['b2_480x640'].max(axis=0)
+    print(f'calibrated bars (median / p95 / max / cosine deficit): {bars[0]:.3e} {bars[1]:.3e} {bars[2]:.3e} {NOISE_MARGIN * bars[3]:.3e}')
+    assert np.median(e_hip) <= bars[0], (np.median(e_hip), bars[0])
+    assert np.percentile(e_hip, 95) <= bars[1], (np.percentile(e_hip, 95), bars[1])
+    assert e_hip.max() <= bars[2], (e_hip.max(), bars[2])
     flat = lambda src: torch.cat([src(nm).double().flatten() for nm in names])   # noqa: E731
     A, B32, B64 = flat(lambda nm: grads[nm].cpu()), flat(lambda nm: r32['grads'][nm]), flat(lambda nm: r64['grads'][nm])
     cos64 = torch.nn.functional.cosine_similarity(A, B64, dim=0).item()
@@ -466,8 +501,7 @@ def test_train_step_parity_at_benchmark_resolution():
     print(f'480x640 batch 2: logits rel err {Hh.rel_err(outs[0].cpu(), r64["outs"][0]):.2e}; grad err vs fp64 median '
           f'{np.median(e_hip):.2e} (fp32 oracle {np.median(e_ref):.2e}), max {e_hip.max():.2e} ({e_ref.max():.2e}); '
           f'cosine {cos64:.6f} (fp32 oracle {cos_ref:.6f}); |g| ratio {(A.norm() / B64.norm()).item():.5f}')
-    # 1 - cosine is quadratic in the relative error: the 2x error bars above are 4x here
-    assert 1 - cos64 <= 4 * (1 - cos_ref) + 1e-6, (cos64, cos_ref)
+    assert 1 - cos64 <= NOISE_MARGIN * bars[3], (cos64, bars[3])          # (quadratic in the error: margin^2 on the deficit)
     assert _rl2(A, B64) <= 3 * _rl2(B32, B64) + 1e-5
 
 
