@@ -37,7 +37,7 @@ GFLOP_PER_IMG_FWD_BWD = {'P': 222.98, 'S': 300.8}   # BASELINE.md §2 (conv MACs
 GFLOP_PER_IMG_FWD = {'P': 74.67, 'S': 100.62}
 TRAFFIC_NOTE = ('HBM bytes per launch from profiles/pmc_dominant_kernel.json (separate rocprofv3 --pmc passes for FETCH_SIZE '
                 'and WRITE_SIZE): fetch_factor x FETCH_SIZE + WRITE_SIZE, fetch_factor = 2 (the guide\'s gfx950 correction) '
-                'for kernels that stream 16 B/lane (conv_wgrad_v4), 1 = raw for the 4 B/lane gathers of the implicit-GEMM '
+                'for kernels that stream 16 B/lane (conv_wgrad_v4, conv_igemm_v5), 1 = raw for the 4 B/lane gathers of the implicit-GEMM '
                 'kernels (uncalibrated width: lower bound).  For the split weight gradient the figure includes its slab '
                 'writes; the slab reduction kernel that follows is listed separately in the JSON.')
 
@@ -291,16 +291,26 @@ def roofline_of(agg):
         return None
     name, (launches, ms, flops, abytes) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None
+    # HBM traffic per launch: rocprofv3 PMC record of the SAME step (profiles/pmc_dominant_kernel.json, written by
+    # profiles/r03_recipe.sh).  It is a like-for-like figure only if it was taken over the same launch set: same kernel
+    # label, same number of launches per step as this run's instrumented step — otherwise it is withheld.
+    traffic, traffic_why = None, None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
+            rec = json.load(open(pmc)).get(name)
+            if rec is None:
+                traffic_why = f'no PMC record for {name}'
+            elif abs(rec.get('launches_per_step', -1) - launches) > 0.01:
+                traffic_why = (f"PMC record covers {rec.get('launches_per_step')} launches per step, this step has {launches}: "
+                               'not the same launch set')
+            else:
+                traffic = rec.get('hbm_bytes_per_launch')
+        except Exception as e:
+            traffic_why = f'unreadable PMC record: {e}'
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-            'traffic_note': TRAFFIC_NOTE if traffic is not None else None,
+            'traffic_note': TRAFFIC_NOTE if traffic is not None else traffic_why,
             'kernel': name, 'launches_per_step': launches,
             'avg_launch_us': round(1000.0 * ms / launches, 2),
             'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
