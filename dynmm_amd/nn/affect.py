@@ -125,13 +125,15 @@ class _GatedMixture(nn.Module):
         return S.linear_bdt(self.gate[0]([x, inputs[1][0]]), self.gate[1].weight, self.gate[1].bias)
 
     def _mix(self, logits, preds):
+        # affect_dyn.py:152-165: the gate's own DiffSoftmax weight is computed and RECORDED first, whatever infer_mode then
+        # does with the prediction (cal_flop / weight_stat read weight_list after every evaluation mode)
+        out, aux, weight = S.moe_blend(logits, preds, self.temp, self.hard_gate)
+        if self.store_weight:
+            self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
         if self.infer_mode > 0:
             return preds[self.infer_mode - 1], 0
         if self.infer_mode == -1:                       # uniform weights (affect_dyn.py:161-162)
-            logits = torch.zeros_like(logits)
-        out, aux, weight = S.moe_blend(logits, preds, self.temp, self.hard_gate and self.infer_mode != -1)
-        if self.store_weight:
-            self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
+            out, aux, _ = S.moe_blend(torch.zeros_like(logits), preds, self.temp, False)
         return out, aux
 
 
@@ -207,16 +209,26 @@ class AffectTrainStep:
         # the batch shape are frozen into a capture, which is re-made when they change).
         self.use_graph = bool(use_graph)
         self._graphs = {}
+        # every Linear / Conv1d weight of the step re-laid for the MFMA kernels by ONE launch (ops.PackedWeights) instead of
+        # one pack launch per layer call (r2 profile: 2 310 of 14 525 dispatches were pack_weight_kernel)
+        from .. import ops
+        self.prepack = ops.PackedWeights()
 
     def _body(self, inputs, target):
         from .. import engine, ops
         m = self.model
         self.flat_g.zero_()
-        with engine.direct_gradients(False):         # kernels write parameter gradients straight into flat_g
-            ops.touched_reset()
-            logits = m.gate_logits(inputs)
-            preds = m.experts(inputs)
-            self.last = S.moe_loss_backward(logits, preds, target, m.temp, m.hard_gate, self.lossw)
+        prev, ops.PREPACK = ops.PREPACK, self.prepack
+        self.prepack.pack()
+        try:
+            with engine.direct_gradients(False):     # kernels write parameter gradients straight into flat_g
+                ops.touched_reset()
+                logits = m.gate_logits(inputs)
+                preds = m.experts(inputs)
+                self.last = S.moe_loss_backward(logits, preds, target, m.temp, m.hard_gate, self.lossw)
+        finally:
+            self.prepack.invalidate()                # the optimizer below rewrites the weights
+            ops.PREPACK = prev
         nc = S.clip_grad_norm(self.flat_g, self.clip_val)
         self.opt.grad_scale_dev = nc[1:2]
         self.opt.step(None, self.last['total'])
@@ -241,6 +253,8 @@ class AffectTrainStep:
             self.flatp.flat.copy_(snap[0])                   # undo the warm-up's parameter update
             for t, c in zip(self.opt.state_tensors(), snap[1:]):
                 t.copy_(c)
+            if self.prepack.reg and self.prepack.dirty:
+                self.prepack._layout()                       # the warm-up registered the weights: lay the arena out before capturing
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._body(static_in, static_y)

@@ -428,7 +428,9 @@ class _Conv2d(Function):
                     'pack_weight_bf16')
             if bf_d:
                 wpd = wsd
-        pre = PREPACK.lookup(weight, need_dx) if (PREPACK is not None and not bf_f and not bf_d) else None
+        # (a Linear / Conv1d weight arrives as a [Co, Ci, 1, 1] alias of its parameter: same memory, so the parameter keys the pack)
+        wkey = w_owner if w_owner is not None else weight
+        pre = PREPACK.lookup(wkey, need_dx) if (PREPACK is not None and not bf_f and not bf_d) else None
         if pre is not None:
             wp, wpd32 = pre                      # packed by the step's single multi-tensor launch
             if need_dx:
@@ -442,7 +444,7 @@ class _Conv2d(Function):
             if wpd32 is not None:
                 wpd = wpd32
             if PREPACK is not None and not bf_f and not bf_d:
-                PREPACK.register(weight, g, need_dx)
+                PREPACK.register(wkey, g, need_dx)
         if bf_f:
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_bf16(_p(x), _p(wsf), ns, None, _p(bias), None, _p(y),
                                                                        C.byref(g), act, st)), 'conv2d_fwd_bf16')

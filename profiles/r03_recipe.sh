@@ -1,0 +1,23 @@
+# Round-3 profiling recipe (run on the GPU box through gpurun): rocprofv3 kernel traces of the bench command in the
+# roofline-leg configuration (single stream) and the default 3-stream schedule, then three separate --pmc passes.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r03
+rm -rf $O; mkdir -p $O
+B="--no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats -d $O/single -o bench -- python $R/bench.py --steps 3 --warmup 1 $B --single-stream > $O/single_stdout.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/multi -o bench -- python $R/bench.py --steps 3 --warmup 1 $B > $O/multi_stdout.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/affect -o aff -- python $R/scratch/affect_bench.py 5 > $O/affect_stdout.log 2>&1
+cd $R
+python profiles/summarize_rocpd.py $O/single/bench_results.db $O/single.md > /dev/null
+python profiles/summarize_rocpd.py $O/multi/bench_results.db $O/multi.md > /dev/null
+python profiles/summarize_rocpd.py $O/affect/aff_results.db $O/affect.md > /dev/null
+python profiles/summarize_pmc.py $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv $O/pmc_sq/p_counter_collection.csv $O/pmc.md $O/pmc.json conv_igemm 4 > $O/pmc_summary.log 2>&1
+rm -rf $O/*/*.db $O/pmc_*/p_*.csv    # keep the merge-back small: summaries only
+tail -1 $O/single_stdout.log | cut -c1-300
+head -30 $O/single.md | cut -c1-160
+head -14 $O/pmc.md | cut -c1-200
+tail -5 $O/pmc_summary.log

@@ -132,3 +132,30 @@ def test_affect_train_step_matches_torch_adamw():
             n_far = int((d > 0.2 * 2 * 1e-3).sum().item())
             assert n_far <= max(1, int(2e-3 * d.numel())) and d.max().item() < 2.2 * 2 * 1e-3, (freeze, k, n_far)
         step.opt.check_finite()
+
+
+@pytest.mark.gpu
+def test_infer_modes_record_the_gate_weights():
+    """affect_dyn.py:152-165: the gate's DiffSoftmax weight is stored BEFORE infer_mode is looked at — cal_flop / weight_stat
+    read weight_list after single-branch (infer_mode > 0) and uniform (infer_mode = -1) evaluations too."""
+    from dynmm_amd.nn import affect as A
+    torch.manual_seed(1)
+    m = A.DynMMNetV2(1.0, True).cuda().eval()
+    B, T = 6, 50
+    xs = [torch.randn(B, T, f).cuda() for f in (35, 74, 300)]
+    inputs = [xs, [torch.full((B,), T, dtype=torch.long)] * 3]
+    with torch.no_grad():
+        m.infer_mode = 0
+        m.reset_weight()
+        out0, _ = m(inputs)
+        w0 = m.weight_list.clone()
+        preds = m.experts(inputs)
+        for mode in (1, 2, -1):
+            m.infer_mode = mode
+            m.reset_weight()
+            out, _ = m(inputs)
+            assert torch.equal(m.weight_list, w0), mode                   # the gate's real (hard) decisions, every mode
+            want = preds[mode - 1] if mode > 0 else 0.5 * (preds[0] + preds[1])
+            assert _rel(out, want) < 1e-5, mode
+    assert w0.shape == (B, 2) and bool(((w0 == 0) | (w0 == 1)).all())
+    assert np.isfinite(m.cal_flop())
