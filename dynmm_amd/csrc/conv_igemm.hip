@@ -908,6 +908,10 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
+#ifdef DYNMM_TRACE
+    const size_t trace_row = (size_t)blockIdx.x * 6;
+    if (g_trace && threadIdx.x == 0) { g_trace[trace_row] = wall_clock64(); g_trace[trace_row + 1] = g_trace[trace_row]; g_trace[trace_row + 4] = clock64(); }
+#endif
     const int wave_co = wave / WAVES_K, wave_k = wave % WAVES_K;
     const int khalf = lane >> 5, l31 = lane & 31;
     const int n_tiles = a.n_co_tiles * a.n_k_tiles;          // XCD-aware order, see conv_wgrad_kernel
@@ -1069,6 +1073,9 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
         __syncthreads();
     }
 
+#ifdef DYNMM_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[trace_row + 2] = wall_clock64();
+#endif
     if (do_bias && t < TCO && co0 + t < a.Co) a.out_bias[(size_t)split * a.Co + co0 + t] = bsum;
     const int KHKW = a.KH * a.KW;
     float* out = a.out + (size_t)split * a.Co * a.K;
@@ -1088,6 +1095,10 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_v4_kernel(const WgradArgs a
                 if (co < a.Co) out[(size_t)co * rowlen + col] = acc[mi][j];
             }
     }
+#ifdef DYNMM_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+    if (g_trace && threadIdx.x == 0) { g_trace[trace_row + 3] = wall_clock64(); g_trace[trace_row + 5] = clock64(); }
+#endif
 }
 
 // out[(co*Ci + ci)*KHKW + tap] = sum_s slabs[s][co*K + tap*Ci + ci], fixed order (4 slab groups in flight per

@@ -52,3 +52,13 @@ for (Cc, H, W, KH, KW) in ((128, 60, 80, 3, 1), (256, 30, 40, 3, 1), (64, 120, 1
     dc_ = (t[:, 5] - t[:, 4]).astype(np.float64)
     print('   clock64 ticks per us (MHz): mean %.1f min %.1f max %.1f' % ((dc_ / dw_).mean(), (dc_ / dw_).min(), (dc_ / dw_).max()))
     print('   start times: p50 %.1f p95 %.1f max %.1f' % (np.median(rel[:, 0]), np.percentile(rel[:, 0], 95), rel[:, 0].max()))
+    # MFMA throughput over time (uniform progress inside each workgroup's loop)
+    T = rel[:, 3].max(); bins = np.arange(0, T + 5, 5.0); prog = np.zeros(len(bins) - 1)
+    for a_, b_ in zip(rel[:, 0], rel[:, 2]):
+        lo = np.clip(bins[:-1], a_, b_); hi = np.clip(bins[1:], a_, b_); prog += (hi - lo) / max(b_ - a_, 1e-9)
+    print('   TF/s per 5 us:', ' '.join(f'{v:.0f}' for v in prog * (fl / len(t)) / 5e-6 / 1e12))
+    d = rel[:, 2] - rel[:, 0]
+    nb = len(t)
+    print('   loop us by blockIdx class: [0,256) mean %.1f | [256,512) mean %.1f | even %.1f odd %.1f | by xcd %s' % (
+        d[:256].mean(), d[256:].mean(), d[0::2].mean(), d[1::2].mean(), ' '.join('%.0f' % d[i::8].mean() for i in range(8))))
+    print('   quartiles of loop us over blockIdx ranges of 64:', ' '.join('%.0f' % d[i:i + 64].mean() for i in range(0, nb, 64)))
