@@ -589,3 +589,42 @@ def test_benchmark_config_train_step_invariants():
           f'{cos:.6f}, |g| ratio {(shuffled[2].norm() / base[2].norm()).item():.5f}')
     assert cos > 0.999, cos
     assert abs((shuffled[2].norm() / base[2].norm()).item() - 1) < 2e-2
+
+
+def test_configs1_forward_only_batch16_properties():
+    """BASELINE configs[1] at its OWN size — fwd-only eval, batch 16, 480x640, gate forced on (static fuse), both encoder
+    streams, BatchNorm folded into the convolutions — where the oracle is too slow to run: size-independent properties.
+      * eval mode is per-sample: the batch-16 forward equals two batch-8 forwards of its halves, sample by sample;
+      * a batch permutation permutes the output rows and nothing else;
+      * static fuse == the dynamic model with every gate decision "fuse" (ESANet.forward vs SkipGateESANet.baseline);
+      * the first two samples agree with the CPU oracle (2e-4, the eval-logit bar)."""
+    from dynmm_amd.nn.esanet import ESANet
+    from oracle import dynmm_oracle as O
+    h, w, n = 480, 640, 16
+    rgb, depth = synth.synth_inputs(n, h, w, seed=2468, device='cuda')
+    m = hip_model('P_se', h, w, seed=0)
+    m.eval()
+    m.baseline = True
+    m.dual_stream = True
+    with torch.no_grad():
+        out = m(rgb, depth, test=True)
+        halves = torch.cat([m(rgb[:8], depth[:8], test=True), m(rgb[8:], depth[8:], test=True)])
+        perm = torch.tensor([5, 0, 11, 3, 15, 8, 1, 12, 7, 2, 14, 9, 4, 13, 6, 10], device='cuda')
+        out_p = m(rgb[perm].contiguous(), depth[perm].contiguous(), test=True)
+    assert out.shape == (n, 40, h, w) and bool(torch.isfinite(out).all())
+    scale = out.abs().max().item()
+    # (tile boundaries move with the batch size: the same sums in the same order per pixel, so these are exact or 1 ulp)
+    assert (out - halves).abs().max().item() <= 2e-6 * scale
+    assert (out_p - out[perm]).abs().max().item() <= 2e-6 * scale
+    e = ESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34', encoder_depth='resnet34',
+               encoder_block='NonBottleneck1D', channels_decoder=[128, 128, 128], nr_decoder_blocks=[3, 3, 3],
+               pretrained_on_imagenet=False, fuse_depth_in_rgb_encoder='SE-add', upsampling='learned-3x3-zeropad')
+    e.load_state_dict({k: v for k, v in m.state_dict().items() if 'gate' not in k})
+    e = e.cuda().eval()
+    with torch.no_grad():
+        out_e = e(rgb, depth)
+    assert (out_e - out).abs().max().item() <= 2e-6 * scale
+    sd = Hh.filled_state_dict(Hh.CFGS['P_se'], seed=0)
+    with torch.no_grad():
+        ref = O.forward(sd, rgb[:2].cpu(), depth[:2].cpu(), Hh.CFGS['P_se'], test=True, baseline=True)
+    assert Hh.rel_err(out[:2].cpu(), ref) < LOGIT_TOL
