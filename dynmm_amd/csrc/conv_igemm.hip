@@ -502,7 +502,7 @@ static int env_int(const char* name) {
 }
 
 template <bool DGRAD>
-static int launch_igemm(IgemmArgs& a, hipStream_t st) {
+static int launch_igemm(IgemmArgs& a, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0) {
     static const int force_tpix = env_int("DYNMM_IGEMM_TPIX");
     static const int force_tpix64 = env_int("DYNMM_IGEMM_TPIX_C64");
     const bool dual_in = a.x2 != nullptr;
@@ -514,7 +514,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     a.CoP = (a.Co + 3) & ~3;
     static const int no_subpix = env_int("DYNMM_NO_SUBPIX");
     a.subpix = (DGRAD && !generic && !no_subpix && a.SH * a.SW > 1 && a.Ho % a.SH == 0 && a.Wo % a.SW == 0) ? 1 : 0;
-    if (!generic && launch_igemm_v5(a, DGRAD, st)) {      // stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3: the operand-ring kernels
+    if (!generic && launch_igemm_v5(a, DGRAD, st, workspace, workspace_bytes)) {      // stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3: the operand-ring kernels
         DYNMM_LAUNCH_CHECK();
         return DYNMM_OK;
     }
@@ -1407,6 +1407,13 @@ extern "C" int dynmm_pack_weight_multi(const float* src_base, float* dst_base, c
 extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
                                 const float* scale, const float* shift, const float* residual,
                                 float* y, const dynmm_conv_geom* g, int act, void* stream) {
+    return dynmm_conv2d_fwd_ws(x, x2, wp_fwd, scale, shift, residual, y, g, act, nullptr, 0, stream);
+}
+
+extern "C" int dynmm_conv2d_fwd_ws(const float* x, const float* x2, const float* wp_fwd,
+                                   const float* scale, const float* shift, const float* residual,
+                                   float* y, const dynmm_conv_geom* g, int act, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !wp_fwd || !y || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (x2 != nullptr)) return DYNMM_EINVAL;
@@ -1423,12 +1430,18 @@ extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp
         if (small_conv_fwd_eligible(s, residual)) return launch_small_conv_fwd(s, (hipStream_t)stream);
         if (stem_conv_fwd_eligible(s, residual)) return launch_stem_conv_fwd(s, (hipStream_t)stream);
     }
-    return launch_igemm<false>(a, (hipStream_t)stream);
+    return launch_igemm<false>(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
                                   const float* accum, float* dx, float* dx2,
                                   const dynmm_conv_geom* g, void* stream) {
+    return dynmm_conv2d_dgrad_ws(dy, wp_dgrad, mask, accum, dx, dx2, g, nullptr, 0, stream);
+}
+
+extern "C" int dynmm_conv2d_dgrad_ws(const float* dy, const float* wp_dgrad, const float* mask,
+                                     const float* accum, float* dx, float* dx2,
+                                     const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!dy || !wp_dgrad || !dx || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (dx2 != nullptr)) return DYNMM_EINVAL;
@@ -1440,7 +1453,7 @@ extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const 
     a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
     a.c_in_split = g->Co; a.c_out_split = g->c_split; a.act = DYNMM_ACT_NONE;
-    return launch_igemm<true>(a, (hipStream_t)stream);
+    return launch_igemm<true>(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 static void launch_wgrad_generic(const WgradArgs& a, const WgradGroup& grp, const WgradPlan& p, dim3 grid, bool dual,

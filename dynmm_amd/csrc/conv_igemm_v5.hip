@@ -79,12 +79,18 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     const int wave_co = wave / WAVES_PIX, wave_pix = wave % WAVES_PIX;
     const int khalf = lane >> 5, l31 = lane & 31;
 
+    // K split (a.ksplit > 1, grids that would leave most CUs with less than three workgroups): workgroups
+    // [s * nblk, (s + 1) * nblk) handle channel chunks [s, s + 1) * NC of every tile; split s is dispatched before split s + 1,
+    // which is what makes the partial-sum hand-off below deadlock-free
     const int nblk = a.n_co_tiles * a.n_pix_tiles;
-    const int lin = xcd_remap(blockIdx.x, nblk);
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    const int split = ksplit > 1 ? (int)blockIdx.x / nblk : 0;
+    const int lin = xcd_remap((int)blockIdx.x - split * nblk, nblk);
     const int co0 = (lin % a.n_co_tiles) * TCO;
     const int pix0 = (lin / a.n_co_tiles) * TPIX;
     const int HW = a.H * a.W;
-    const int NC = a.Ci / BK;                    // channel chunks
+    const int NC = a.Ci / BK / ksplit;           // channel chunks of this workgroup
+    const int cbase = split * NC;                //   ... starting at this chunk
     const int nB = a.KH * NC;                    // activation stages (vertical tap, chunk)
     const int nsteps = nB * KW;                  // K-steps (one weight stage each)
 
@@ -121,7 +127,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     int lb_t = 0, lb_r = 0, lb_c = 0;             // next activation stage to request
     auto issue_a = [&]() {
         if (la_t < nsteps) {
-            const float* base = a.wp + (size_t)((la_r * KW + la_s) * a.CiR + la_c * BK + wave * NIA * RPI) * a.CoP;
+            const float* base = a.wp + (size_t)((la_r * KW + la_s) * a.CiR + (cbase + la_c) * BK + wave * NIA * RPI) * a.CoP;
             const unsigned dst = lds_a + (unsigned)(((la_t % SA) * A_STAGE + wave * NIA * 256) * 4);
 #pragma unroll
             for (int i = 0; i < NIA; ++i) dma16(base + (size_t)(i * RPI) * a.CoP, a_voff, dst + i * 1024);
@@ -134,7 +140,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     };
     auto issue_b = [&]() {
         if (lb_t < nB) {
-            const float* base = a.x + (size_t)(lb_c * BK) * HW;
+            const float* base = a.x + (size_t)((cbase + lb_c) * BK) * HW;
             const unsigned dst = lds_b + (unsigned)(((lb_t % SB) * B_STAGE + wave * QPW * 4) * 4);
             const int shift = dh_of(lb_r) * a.W * 4;
 #pragma unroll
@@ -290,6 +296,57 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     __syncthreads();                               // every wave is done with the operand rings: As is reused below
     DYNMM_TRACE_MARK(2);
 
+    // ---------------------------------------------------------------- K split: ordered partial-sum hand-off
+    // Split s waits until the tile's counter reads s, adds the running sum of splits < s (a fixed order: the result does not
+    // depend on timing), then either publishes the new running sum (s < ksplit - 1) or runs the epilogue.  Publication:
+    // plain 16-byte stores -> barrier -> lane 0: agent-scope release fence, vmcnt(0), relaxed agent store of the counter;
+    // consumption: lane 0 polls with relaxed agent loads, agent-scope acquire fence, barrier, plain loads (the cross-CU
+    // visibility recipe of the CDNA4 guide: per-XCD L2s are not coherent with each other).
+    if (ksplit > 1) {
+        float4* slot = reinterpret_cast<float4*>(a.ws) + ((size_t)lin * 256 + t) * (MCO * MPIX * 4);
+        unsigned* flag = a.flags + lin;
+        if (split > 0) {
+            if (t == 0) {
+                // bounded: the producer is always resident or finished when workgroups start in blockIdx order; if that ever
+                // failed, abort the launch (an error the caller sees) rather than hang the device
+                unsigned spins = 0;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)split) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 26)) __builtin_trap();
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();                       // (the acquire invalidated this CU's L1: one fence serves the workgroup)
+#pragma unroll
+            for (int mi = 0; mi < MCO; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < MPIX; ++ni)
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const float4 p = slot[(mi * MPIX + ni) * 4 + j4];
+                        acc[mi][ni][4 * j4 + 0] += p.x; acc[mi][ni][4 * j4 + 1] += p.y;
+                        acc[mi][ni][4 * j4 + 2] += p.z; acc[mi][ni][4 * j4 + 3] += p.w;
+                    }
+        }
+        if (split < ksplit - 1) {
+#pragma unroll
+            for (int mi = 0; mi < MCO; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < MPIX; ++ni)
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4)
+                        slot[(mi * MPIX + ni) * 4 + j4] = make_float4(acc[mi][ni][4 * j4 + 0], acc[mi][ni][4 * j4 + 1],
+                                                                      acc[mi][ni][4 * j4 + 2], acc[mi][ni][4 * j4 + 3]);
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(flag, (unsigned)(split + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
+
     // ---------------------------------------------------------------- epilogue (as conv_igemm.hip)
     // scale/shift (bias or folded BN), residual, activation, ReLU-mask; NCHW store.  No memory wait sits between two
     // stores: per-channel scale/shift come from LDS, residual / mask values of half an accumulator tile are loaded as one
@@ -422,13 +479,65 @@ bool igemm_v5_eligible(const IgemmArgs& a, bool dgrad) {
     return true;
 }
 
-bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st) {
+// Tile shape the launcher picks (TCO x TPIX) and the K split it would use with a workspace.
+static void v5_tiles(const IgemmArgs& a, int& tco, int& tpix, int& tiles) {
+    tco = (a.Co % 128 == 0) ? 128 : 64;
+    tpix = tco == 128 ? 64 : 128;
+    tiles = (a.Co / tco) * ceil_div(a.N * a.Ho * a.Wo, tpix);
+}
+
+// Long reductions on grids that leave most CUs with fewer than three workgroups (C = 512 at 15x20, compacted depth stages)
+// split K: 2 or 4 workgroups per tile, each over a contiguous range of channel chunks (an even number of 16-channel chunks
+// per workgroup: the two-stage unroll of the K loop).
+int igemm_v5_ksplit(const IgemmArgs& a, bool dgrad) {
+    // Opt-in (DYNMM_V5_SPLITK=1).  Measured ("Round 3"): +7 % on the isolated C = 512 launches, +1.7 % on the batch-16
+    // forward-only line, nothing on the multi-stream training step — not enough to put a cross-workgroup hand-off (which
+    // relies on workgroups being dispatched in blockIdx order) on the default path.
+    static const int on = env_int_v5("DYNMM_V5_SPLITK", 0);
+    if (!on || !igemm_v5_eligible(a, dgrad)) return 1;
+    int tco, tpix, tiles;
+    v5_tiles(a, tco, tpix, tiles);
+    const int nc = a.Ci / 16;
+    const int steps = a.KH * a.KW * nc;
+    // The hand-off costs 10-20 us per launch (partial tile out through an agent-scope release, back in behind an acquire),
+    // measured on MI355X (scratch/splitk_check.py): it pays for long reductions only — 2 ways when a workgroup keeps >= 48
+    // K-steps (C = 512, three taps: 178 -> 166 us, 166 -> 154 us), 4 ways when the grid is below half a workgroup per CU
+    // (compacted depth stages: 63.5 -> 56.9 us); K = 384 / 768 tiles lose 10-45 % and stay un-split.
+    int best = 1;
+    if (nc % 4 == 0 && tiles < 768 && steps / 2 >= 48) best = 2;
+    if (nc % 8 == 0 && tiles < 192 && steps / 4 >= 24) best = 4;
+    return best;
+}
+
+size_t igemm_v5_workspace_bytes(const IgemmArgs& a, bool dgrad) {
+    const int s = igemm_v5_ksplit(a, dgrad);
+    if (s <= 1) return 0;
+    int tco, tpix, tiles;
+    v5_tiles(a, tco, tpix, tiles);
+    return (size_t)tiles * tco * tpix * sizeof(float) + (((size_t)tiles * sizeof(unsigned) + 15) & ~(size_t)15);
+}
+
+bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st, void* workspace, size_t workspace_bytes) {
     if (!igemm_v5_eligible(a, dgrad)) return false;
     a.CiR = a.Ci;
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Ci;
     a.CoP = a.Co;
     a.subpix = 0;
+    a.ksplit = 1;
+    a.ws = nullptr;
+    a.flags = nullptr;
+    {
+        const size_t need = igemm_v5_workspace_bytes(a, dgrad);
+        if (need > 0 && workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) {
+            int tco, tpix, tiles;
+            v5_tiles(a, tco, tpix, tiles);
+            a.ksplit = igemm_v5_ksplit(a, dgrad);
+            a.ws = reinterpret_cast<float*>(workspace);
+            a.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + (size_t)tiles * tco * tpix * sizeof(float));
+            if (hipMemsetAsync(a.flags, 0, (size_t)tiles * sizeof(unsigned), st) != hipSuccess) return false;
+        }
+    }
     static const int sa_env = env_int_v5("DYNMM_V5_SA", 3), sb_env = env_int_v5("DYNMM_V5_SB", 3);
 #define DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, KW_, DG_)                                                                    \
     do {                                                                                                               \
@@ -447,7 +556,7 @@ bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st) {
     do {                                                                                                               \
         a.n_co_tiles = a.Co / TCO;                                                                                     \
         a.n_pix_tiles = ceil_div(a.M, TPIX);                                                                           \
-        dim3 grid((unsigned)(a.n_co_tiles * a.n_pix_tiles));                                                           \
+        dim3 grid((unsigned)(a.n_co_tiles * a.n_pix_tiles * a.ksplit));                                                \
         if (a.KW == 3) {                                                                                               \
             if (dgrad) DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 3, true);                                                     \
             else DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 3, false);                                                          \
@@ -470,6 +579,21 @@ bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st) {
 extern "C" int dynmm_debug_set_igemm_v5(int mode) {
     dynmm::g_v5_override = mode;
     return 0;
+}
+
+static void geom_to_args(const dynmm_conv_geom* g, int dgrad, dynmm::IgemmArgs& a) {
+    a.N = g->N; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    if (dgrad) { a.Ci = g->Co; a.H = g->Ho; a.W = g->Wo; a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W; }
+    else { a.Ci = g->Ci; a.H = g->H; a.W = g->W; a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo; }
+    a.c_out_split = a.Co;
+}
+
+// Bytes of scratch dynmm_conv2d_fwd_ws / dynmm_conv2d_dgrad_ws can use for this geometry (0: the launch is not K-split).
+extern "C" size_t dynmm_conv2d_workspace_bytes(const dynmm_conv_geom* g, int dgrad) {
+    if (!g || g->c_split != g->Ci) return 0;
+    dynmm::IgemmArgs a{};
+    geom_to_args(g, dgrad, a);
+    return dynmm::igemm_v5_workspace_bytes(a, dgrad != 0);
 }
 
 // Geometry-only form of igemm_v5_eligible (pointer alignment aside) for profiling tools that label launches:

@@ -41,6 +41,9 @@ SIGNATURES = {
     'dynmm_pack_weight_multi_blocks': (c_i, [c_i] * 5),
     'dynmm_conv2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
+    'dynmm_conv2d_workspace_bytes': (c_sz, [_GP, c_i]),
+    'dynmm_conv2d_fwd_ws': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f, c_sz, c_f]),
+    'dynmm_conv2d_dgrad_ws': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f, c_sz, c_f]),
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),
     'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv2d_wgrad_groupable': (c_i, [_GP]),

@@ -404,6 +404,22 @@ class PackedWeights:
 PREPACK = None
 
 
+_SCRATCH_BYTES = {}
+
+
+def _conv_scratch(g, dgrad, device):
+    """(tensor or None, bytes): scratch for a K-split forward / input-gradient launch (dynmm_conv2d_workspace_bytes:
+    small grids only — C = 512 at 15x20, the decoder's small maps, compacted depth stages).  Allocated per call from
+    torch's caching allocator (stream-ordered, capture-safe); the byte count is cached per geometry."""
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split, dgrad)
+    n = _SCRATCH_BYTES.get(key)
+    if n is None:
+        n = _SCRATCH_BYTES[key] = int(_lib().dynmm_conv2d_workspace_bytes(C.byref(g), dgrad))
+    if n == 0:
+        return None, 0
+    return torch.empty(n // 4, device=device, dtype=torch.float32), n
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, split_fwd, w_owner=None):
@@ -449,8 +465,9 @@ class _Conv2d(Function):
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_bf16(_p(x), _p(wsf), ns, None, _p(bias), None, _p(y),
                                                                        C.byref(g), act, st)), 'conv2d_fwd_bf16')
         else:
-            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
-                                                                  C.byref(g), act, st)), 'conv2d_fwd')
+            ws, nws = _conv_scratch(g, 0, x.device)
+            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_ws(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
+                                                                     C.byref(g), act, _p(ws), nws, st)), 'conv2d_fwd')
         ctx.bf_d, ctx.ns = bf_d, ns
         ctx.geom = g
         ctx.act = act
@@ -507,8 +524,9 @@ class _Conv2d(Function):
                 L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad_bf16(_p(gy), _p(wpd), ctx.ns, _p(mask), _p(accum),
                                                                                _p(dx), C.byref(g), st)), 'conv2d_dgrad_bf16')
             else:
-                L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
-                                                                          _p(dx2), C.byref(g), st)), 'conv2d_dgrad')
+                ws, nws = _conv_scratch(g, 1, gy.device)
+                L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad_ws(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
+                                                                             _p(dx2), C.byref(g), _p(ws), nws, st)), 'conv2d_dgrad')
         dw_ret = None
         ws_stream = None
         if DIRECT_GRAD and WGRAD_GROUP > 1:
@@ -643,8 +661,9 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
         L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_bf16(_p(x), _p(wsf), ns, _p(scale), _p(shift), _p(residual),
                                                                    _p(y), C.byref(g), ACT[act], st)), 'conv2d_fwd_bf16')
     else:
-        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
-                                                              _p(y), C.byref(g), ACT[act], st)), 'conv2d_fwd')
+        ws, nws = _conv_scratch(g, 0, x.device)
+        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_ws(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
+                                                                 _p(y), C.byref(g), ACT[act], _p(ws), nws, st)), 'conv2d_fwd')
     return y
 
 

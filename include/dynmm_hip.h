@@ -100,6 +100,20 @@ int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
 int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
                        float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
 
+/* The same two calls with caller-owned scratch.  For long reductions on grids that would leave most CUs with fewer than
+ * three workgroups (C = 512 at 15x20, compacted depth stages) the operand-ring kernels split the reduction over 2 or 4
+ * workgroups per tile; the partial accumulator tiles travel through `workspace` in a fixed order
+ * (split s adds the running sum of the splits before it: the result does not depend on timing).
+ * dynmm_conv2d_workspace_bytes(g, dgrad) = bytes that enable the split for this geometry (0: never split); a smaller or
+ * NULL workspace simply runs the un-split launch.  The arrival counters inside it are zeroed on the stream by the callee. */
+size_t dynmm_conv2d_workspace_bytes(const dynmm_conv_geom* g, int dgrad);
+int dynmm_conv2d_fwd_ws(const float* x, const float* x2, const float* wp_fwd,
+                        const float* scale, const float* shift, const float* residual,
+                        float* y, const dynmm_conv_geom* g, int act, void* workspace, size_t workspace_bytes, void* stream);
+int dynmm_conv2d_dgrad_ws(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
+                          float* dx, float* dx2, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* dw[Co,Ci,KH,KW] = sum_{n,oh,ow} dy * x(window).  Split over the pixel range into partial slabs in
  * `workspace` (>= dynmm_conv2d_wgrad_workspace_bytes), reduced deterministically.
  * dbias (optional, [Co]) = sum_{n,oh,ow} dy: the bias gradient of the same conv, produced from the dy tiles

@@ -1,5 +1,7 @@
 """GPU: each HIP op (through the C ABI, via dynmm_amd.ops) against a plain PyTorch fp32 CPU reference
 of the same op, forward and backward, on the shape classes of the hot path."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -63,7 +65,33 @@ CONV_CASES = [
     (2, 64, 12, 16, 128, (1, 1), (1, 1), (0, 0), False, None),       # 1x1: no padding at all, 4 K-steps (ring depth)
     (2, 512, 15, 20, 512, (3, 1), (1, 1), (1, 0), True, None),       # K = 1536: 96 K-steps
     (1, 96, 8, 16, 192, (3, 3), (1, 1), (1, 1), True, None),         # Ci = 6 chunks, Co = 3 x 64
+    (4, 512, 15, 20, 512, (1, 3), (1, 1), (0, 1), True, 'relu'),     # 76 tiles, 96 K-steps (K split 4 ways under DYNMM_V5_SPLITK=1)
+    (2, 256, 30, 40, 256, (3, 3), (1, 1), (1, 1), False, None),      # 76 tiles, K = 2304
 ]
+
+
+def test_conv2d_k_split_is_exact_and_reproducible():
+    """Opt-in K split of the operand-ring kernels (DYNMM_V5_SPLITK=1: ordered partial-sum hand-off between the 2 or 4
+    workgroups of a tile).  The switch is read once per process, so the check runs in a child: split vs un-split launch of the
+    same kernel (<= 2e-6: one more fp32 addition per element), bit-identical across runs, and the whole conv test list."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DYNMM_V5_SPLITK='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'scratch', 'splitk_check.py')], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith('(')]
+    assert len(rows) >= 4
+    split_rows = [ln for ln in rows if 'ws MB 0.0' not in ln]
+    assert len(split_rows) >= 3, rows                     # the C = 512 shapes and the 6-sample compacted stage really split
+    for ln in split_rows:
+        rel = float(ln.split('split-vs-unsplit rel ')[1].split()[0])
+        assert rel < 2e-6 and 'reproducible True' in ln, ln
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_hip_ops.py'), '-q', '-m', 'gpu', '-k',
+                        'test_conv2d_fwd_bwd', '-x'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:]
+
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
