@@ -564,36 +564,6 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, void* workspace = nullptr,
 // ------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* x;
-    const float* x2;
-    const float* dy;
-    float* out;            // slabs [splits][Co*K] in the layout of w: [Co][Ci][KH][KW]
-    float* out_bias;       // optional bias-gradient slabs [splits][Co] (sum over pixels of dy), or nullptr
-    int N, Ci, H, W;
-    int Co, Ho, Wo;
-    int KH, KW, SH, SW, PH, PW;
-    int c_split;
-    int M, K;
-    int n_co_tiles, n_k_tiles;
-    int steps_per_split;   // 32-pixel steps handled by one workgroup
-    unsigned magic_wo;     // floor(2^32 / Wo) + 1 when Ho*Wo*Wo < 2^32 (exact rem / Wo by mulhi), else 0
-    int k_major_out;       // v4 slabs: out[co][k] with k = tap*Ci + ci (128-byte store runs); permuted by the slab reduction
-};
-
-// Up to 8 weight gradients of identical geometry in ONE launch (dynmm_conv2d_wgrad_group): the workgroups of problem p are
-// [p*per, (p+1)*per).  A launch holds one residency round whatever the number of problems, so each workgroup walks a
-// nprob-times longer pixel range of its problem: the fixed costs of a launch (cold prologue, slab burst, tail) and the slab
-// traffic are paid once per group instead of once per convolution.
-constexpr int kWgradGroupMax = 8;
-struct WgradGroup {
-    const float* x[kWgradGroupMax];
-    const float* dy[kWgradGroupMax];
-    float* out[kWgradGroupMax];
-    float* out_bias[kWgradGroupMax];
-    int nprob, per;
-};
-
 template <int TCO, int TK, int WCO, int WK, bool DUAL, bool FAST>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs a_in, const WgradGroup grp) {
     WgradArgs a = a_in;
@@ -1160,10 +1130,45 @@ __global__ void __launch_bounds__(256) reduce_slabs_perm_kernel(const float* __r
 
 struct WgradPlan {
     int tco, tk, n_co_tiles, n_k_tiles, splits, steps_per_split;
+    int v6;        // conv_wgrad_v6.hip: tile tco x (3 taps x 64 ci), 16-pixel steps
+    int bp;        // pixels per step
+    int target;    // workgroups of one residency round
 };
 
-static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
+// (conv_wgrad_v6.hip)
+bool wgrad_v6_shape_ok(const dynmm_conv_geom* g);
+int wgrad_v6_tco(const dynmm_conv_geom* g);
+int wgrad_v6_occupancy(const dynmm_conv_geom* g);
+void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int occ, hipStream_t st);
+
+static void plan_splits(WgradPlan& p, const dynmm_conv_geom* g, int nprob) {
+    const int total_steps = ceil_div(g->N * g->Ho * g->Wo, p.bp);
+    const int tiles = p.n_co_tiles * p.n_k_tiles * nprob;
+    int splits = p.target / tiles;
+    if (splits < 1) splits = 1;
+    const int max_splits = ceil_div(total_steps, 256 / p.bp);   // >= 256 pixels per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = ceil_div(total_steps, splits);
+    p.splits = ceil_div(total_steps, p.steps_per_split);
+}
+
+static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
     WgradPlan p;
+    p.v6 = 0;
+    p.bp = 32;
+    if (allow_v6 && wgrad_v6_shape_ok(g)) {
+        static const int target6 = env_int("DYNMM_WGRAD_V6_BLOCKS");
+        p.v6 = 1;
+        p.bp = 16;
+        p.tco = wgrad_v6_tco(g);
+        p.tk = 192;
+        p.n_co_tiles = g->Co / p.tco;
+        p.n_k_tiles = g->Ci / 64;
+        p.target = target6 ? target6 : 256 * wgrad_v6_occupancy(g);
+        plan_splits(p, g, 1);
+        return p;
+    }
     p.tco = g->Co > 64 ? 128 : (g->Co > 32 ? 64 : 32);
     const int K = g->KH * g->KW * g->Ci;
     // k-tile width for the 64-row configuration: 192 for the C=64 three-tap convs (K = 192: one tile instead
@@ -1175,18 +1180,9 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g) {
     }
     p.n_co_tiles = ceil_div(g->Co, p.tco);
     p.n_k_tiles = ceil_div(K, p.tk);
-    const int M = g->N * g->Ho * g->Wo;
-    const int total_steps = ceil_div(M, 32);
-    const int tiles = p.n_co_tiles * p.n_k_tiles;
     static const int target_env = env_int("DYNMM_WGRAD_BLOCKS");
-    const int target = target_env ? target_env : 512;  // ONE residency round: 256 CUs x 2 workgroups (180 VGPRs)
-    int splits = target / tiles;
-    if (splits < 1) splits = 1;
-    const int max_splits = ceil_div(total_steps, 8);   // >= 256 pixels per workgroup
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    p.steps_per_split = ceil_div(total_steps, splits);
-    p.splits = ceil_div(total_steps, p.steps_per_split);
+    p.target = target_env ? target_env : 512;          // ONE residency round: 256 CUs x 2 workgroups (180 VGPRs)
+    plan_splits(p, g, 1);
     return p;
 }
 
@@ -1491,12 +1487,17 @@ extern "C" size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
     return stem > gen ? stem : gen;
 }
 
-static size_t generic_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
-    const WgradPlan p = plan_wgrad(g);
+static size_t plan_workspace_bytes(const dynmm_conv_geom* g, const WgradPlan& p) {
     if (p.splits <= 1) return 0;
     // [splits][Co*K] weight-gradient slabs, then [splits][Co] bias-gradient slabs (16-byte aligned start)
     const size_t wslab = ((size_t)p.splits * g->Co * g->Ci * g->KH * g->KW + 3) & ~(size_t)3;
     return (wslab + (size_t)p.splits * g->Co) * sizeof(float);
+}
+
+// (the three-tap kernel needs 16-byte aligned tensors, known only at the call: room for either plan)
+static size_t generic_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
+    const size_t a = plan_workspace_bytes(g, plan_wgrad(g)), b = plan_workspace_bytes(g, plan_wgrad(g, false));
+    return a > b ? a : b;
 }
 
 extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias,
@@ -1511,7 +1512,8 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
         if (!workspace || workspace_bytes < need_s) return DYNMM_EWORKSPACE;
         return launch_stem_conv_wgrad(x, dy, dw, (float*)workspace, g->N, g->Ci, g->H, g->W, g->Ho, g->Wo, (hipStream_t)stream);
     }
-    const WgradPlan p = plan_wgrad(g);
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15u) == 0;
+    const WgradPlan p = plan_wgrad(g, aligned16 && !x2);
     const size_t need = generic_wgrad_workspace_bytes(g);
     if (need > 0 && (!workspace || workspace_bytes < need)) return DYNMM_EWORKSPACE;
     WgradArgs a{};
@@ -1534,17 +1536,19 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     const bool fast = !dual && (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
     a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
     static const int no_v4 = env_int("DYNMM_WGRAD_NO_V4");
-    const bool v4 = !no_v4 && !dual && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
+    const bool v4 = !p.v6 && !no_v4 && !dual && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
                     (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
                     ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH &&
                     ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15u) == 0);
     const bool bias_ok4 = !dbias || ((g->Co % 4 == 0) && ((reinterpret_cast<uintptr_t>(bias_slabs) & 15u) == 0) &&
                                      ((reinterpret_cast<uintptr_t>(dbias) & 15u) == 0));
-    const bool perm = v4 && p.splits > 1 && ((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) && bias_ok4;
+    const bool perm = (v4 || p.v6) && p.splits > 1 && ((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) && bias_ok4;
     a.k_major_out = perm ? 1 : 0;
-    if (v4) {
+    if (p.v6 || v4) {
         static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
-        if (v4_nbuf == 2)
+        if (p.v6)
+            launch_wgrad_v6(a, WgradGroup{}, grid, wgrad_v6_occupancy(g), st);
+        else if (v4_nbuf == 2)
             hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, WgradGroup{});
         else
             hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a, WgradGroup{});
@@ -1571,6 +1575,7 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
 // ---- grouped weight gradients --------------------------------------------------------------------------------------
 static bool wgrad_v4_shape_ok(const dynmm_conv_geom* g, const WgradPlan& p) {
     static const int no_v4 = env_int("DYNMM_WGRAD_NO_V4");
+    if (p.v6) return (g->Co % 4 == 0);
     return !no_v4 && g->c_split == g->Ci && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
            (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
            ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH && (g->Co % 4 == 0);
@@ -1579,14 +1584,8 @@ static bool wgrad_v4_shape_ok(const dynmm_conv_geom* g, const WgradPlan& p) {
 // the plan of n same-shape problems sharing one residency round
 static WgradPlan plan_wgrad_group(const dynmm_conv_geom* g, int n) {
     WgradPlan p = plan_wgrad(g);
-    const int total_steps = ceil_div(g->N * g->Ho * g->Wo, 32);
-    const int tiles = p.n_co_tiles * p.n_k_tiles * n;
-    int splits = 512 / tiles;
-    if (splits < 1) splits = 1;
-    const int max_splits = ceil_div(total_steps, 8);
-    if (splits > max_splits) splits = max_splits;
-    p.steps_per_split = ceil_div(total_steps, splits);
-    p.splits = ceil_div(total_steps, p.steps_per_split);
+    if (!p.v6) p.target = 512;
+    plan_splits(p, g, n);
     return p;
 }
 
@@ -1604,6 +1603,14 @@ extern "C" int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g) {
     if (p.splits <= 1) return 0;
     static const int no_generic = env_int("DYNMM_NO_WGRAD_GROUP_GENERIC");
     return wgrad_v4_shape_ok(g, p) ? 2 : (no_generic ? 0 : 1);
+}
+
+extern "C" int dynmm_conv2d_wgrad_variant(const dynmm_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    if (stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split < g->Ci, false)) return 0;
+    const WgradPlan p = plan_wgrad(g);
+    if (p.v6) return 6;
+    return wgrad_v4_shape_ok(g, p) ? 4 : 0;
 }
 
 extern "C" size_t dynmm_conv2d_wgrad_group_workspace_bytes(const dynmm_conv_geom* g, int n) {
@@ -1676,7 +1683,9 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
     }
     a.k_major_out = 1;
     static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
-    if (v4_nbuf == 2)
+    if (p.v6)
+        launch_wgrad_v6(a, grp, grid, wgrad_v6_occupancy(g), st);
+    else if (v4_nbuf == 2)
         hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, grp);
     else
         hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a, grp);

@@ -28,23 +28,6 @@
 
 namespace dynmm {
 
-// s_waitcnt vmcnt(N) lgkmcnt(0)   (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4] = 7 (no wait), lgkmcnt [11:8])
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4));
-}
-
-// One wave instruction: lane l copies the 16 bytes at sbase + voff[l] to LDS byte address lds + 16*l.
-__device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_addr) {
-    // (an SALU write of M0 needs one wait state before an LDS-DMA instruction reads it — ISA "manually inserted wait states";
-    // the compiler pads its own code, not inline assembly)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :
-                 : "s"(lds_addr), "v"(voff_bytes), "s"(sbase)
-                 : "memory", "m0");
-}
-
 template <int I>
 using ic = std::integral_constant<int, I>;
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),
     'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv2d_wgrad_groupable': (c_i, [_GP]),
+    'dynmm_conv2d_wgrad_variant': (c_i, [_GP]),
     'dynmm_conv2d_wgrad_group_workspace_bytes': (c_sz, [_GP, c_i]),
     'dynmm_conv2d_wgrad_group': (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv_bf16x3_eligible': (c_i, [_GP, c_i]),

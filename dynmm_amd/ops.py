@@ -260,8 +260,12 @@ def _timed(kind, g, call, nprob=1):
             generic = ',padded'
     m = g.N * (g.H * g.W if kind == 'dgrad' else g.Ho * g.Wo)
     name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co, m)}{generic}>'
-    if kind == 'wgrad' and _lib().dynmm_conv2d_wgrad_groupable(C.byref(g)) == 2:
-        name = 'conv_wgrad_v4<co128>'                       # the vectorised 128x128 kernel (conv_igemm.hip: wgrad_v4_shape_ok)
+    if kind == 'wgrad':
+        variant = _lib().dynmm_conv2d_wgrad_variant(C.byref(g))
+        if variant == 6:                                    # conv_wgrad_v6.hip: one template instance per tile height and tap axis
+            name = f'conv_wgrad_v6<co{128 if g.Co % 128 == 0 else 64},{g.KH}x{g.KW}>'
+        elif variant == 4:
+            name = 'conv_wgrad_v4<co128>'                   # the vectorised 128x128 kernel (conv_igemm.hip: wgrad_v4_shape_ok)
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
     if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)

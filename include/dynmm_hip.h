@@ -129,6 +129,9 @@ int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* 
  * of n device pointers (dbiases NULL, or all entries set / all NULL).  Falls back to n ordinary launches when the
  * geometry is not groupable (dynmm_conv2d_wgrad_groupable: the vectorised 128x128 kernel, single input). */
 int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g);
+/* Which weight-gradient kernel serves this geometry when the tensors are 16-byte aligned (launch labels of bench.py):
+ * 6 = the three-tap kernel (conv_wgrad_v6.hip), 4 = the vectorised 128x128 kernel, 0 = the generic tiles / stem kernel. */
+int dynmm_conv2d_wgrad_variant(const dynmm_conv_geom* g);
 size_t dynmm_conv2d_wgrad_group_workspace_bytes(const dynmm_conv_geom* g, int n);
 int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const float* const* dys, float* const* dws,
                              float* const* dbiases, void* workspace, size_t workspace_bytes,

@@ -67,6 +67,11 @@ CONV_CASES = [
     (1, 96, 8, 16, 192, (3, 3), (1, 1), (1, 1), True, None),         # Ci = 6 chunks, Co = 3 x 64
     (4, 512, 15, 20, 512, (1, 3), (1, 1), (0, 1), True, 'relu'),     # 76 tiles, 96 K-steps (K split 4 ways under DYNMM_V5_SPLITK=1)
     (2, 256, 30, 40, 256, (3, 3), (1, 1), (1, 1), False, None),      # 76 tiles, K = 2304
+    # three-tap weight-gradient kernel (conv_wgrad_v6.hip): stride 1, same padding, W % 4 == 0 >= 16, Ci, Co % 64 == 0
+    (3, 128, 15, 20, 128, (1, 3), (1, 1), (0, 1), True, None),       # M = 900: last step has one live quad; rows of 20 pixels
+    (5, 64, 17, 20, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),       # vertical taps, 64-row tile, M = 1700, odd H
+    (2, 128, 9, 16, 256, (3, 1), (1, 1), (1, 0), True, None),        # narrowest rows (one step = one row), 2 co tiles x 2 ci tiles
+    (1, 192, 8, 24, 64, (1, 3), (1, 1), (0, 1), False, None),        # 3 ci tiles, no bias, a step straddles rows
 ]
 
 
@@ -619,8 +624,10 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
         assert rel(x, y) < 2e-4, i
 
 
-@pytest.mark.parametrize('case', [(4, 128, 24, 32, 128, (3, 1), (1, 0), True),      # vectorised 128x128 kernel
-                                  (4, 64, 24, 32, 64, (1, 3), (0, 1), True),        # generic 64co x 192k tiles
+@pytest.mark.parametrize('case', [(4, 128, 24, 32, 128, (3, 1), (1, 0), True),      # three-tap kernel, vertical taps
+                                  (4, 64, 24, 32, 64, (1, 3), (0, 1), True),        # three-tap kernel, 64-row tile
+                                  (3, 128, 15, 20, 256, (1, 3), (0, 1), True),      # ... horizontal taps, M = 900 (ragged)
+                                  (2, 128, 12, 16, 128, (1, 1), (0, 0), True),      # vectorised 128x128 kernel
                                   (4, 128, 24, 32, 128, (3, 3), (1, 1), False)])
 def test_grouped_weight_gradients(ops, case):
     """dynmm_conv2d_wgrad_group through the C ABI: 3 same-geometry convolutions in one launch against fp64 torch (and
