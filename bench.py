@@ -449,7 +449,11 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     y = torch.randn(batch, 1, generator=g).to(device)
     step = A.AffectTrainStep(model, lr=1e-5, weight_decay=1e-4, lossw=0.1, use_graph=True)
     res = {}
-    for name, fn in (('train_step', lambda: step(inputs, y)), ('forward', None)):
+    model.train()                                     # dropout p = 0.1 at the 100 sites, as the reference trains
+    for name, fn in (('train_step', lambda: step(inputs, y)), ('train_step_no_dropout', lambda: step(inputs, y)),
+                     ('forward', None)):
+        if name == 'train_step_no_dropout':
+            model.eval()                                  # same step with the eval-mode arithmetic (what rounds 1-2 measured)
         if fn is None:
             model.eval()
 
@@ -464,6 +468,8 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     res['forward']['model_tflops'] = round(res['forward']['value'] * 2 * mmac * 1e6 / 1e12, 2)
     res['train_step']['model_tflops'] = round(res['train_step']['value'] * 6 * mmac * 1e6 / 1e12, 2)
     res['train_step']['launch'] = 'hipGraph replay'
+    res['train_step']['dropout'] = 'p = 0.1, Philox masks regenerated in the backward, new masks every replay'
+    res['train_step_no_dropout']['model_tflops'] = round(res['train_step_no_dropout']['value'] * 6 * mmac * 1e6 / 1e12, 2)
     res['workload'] = ('configs[4] per GPU: ModalityDynMM DynMMNetV2 on CMU-MOSEI-shaped synthetic features '
                        f'(T={T}: visual 35, audio 74, text 300), batch {batch}; experts trainable (freeze=False); '
                        'PARITY UNPINNED (MultiBench not vendored)')

@@ -17,6 +17,59 @@ constexpr int kSeqMaxT = 64;
 constexpr int kSeqMaxDh = 32;
 
 // ---------------------------------------------------------------------------------------------------------------
+// Dropout (nn.TransformerEncoderLayer trains with p = 0.1 at four places: the attention probabilities, the attention
+// block's output, the feed-forward hidden layer and the feed-forward output).  An element survives with probability
+// 1 - p and is scaled by 1/(1 - p).  The decision for element `idx` of a site is a pure function of
+// (seed, offset + *step, idx) through Philox-4x32-10, so the backward pass regenerates it instead of storing masks and a
+// captured hipGraph draws new masks at every replay (`step` is a device counter the training step advances).
+// `mask` (tests): explicit keep flags, one byte per element, instead of the generator.
+// ---------------------------------------------------------------------------------------------------------------
+struct DropSpec {
+    const unsigned char* mask;
+    const unsigned long long* step;
+    unsigned long long seed, offset;
+    float p;
+};
+
+__device__ __forceinline__ void seq_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                  uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 0 (dropped) or 1/(1-p) (kept); 1 when the site has no dropout
+struct DropState {
+    const unsigned char* mask;
+    unsigned long long off;
+    uint32_t k0, k1;
+    float p, inv;
+    __device__ __forceinline__ explicit DropState(const DropSpec& d)
+        : mask(d.mask), off(d.offset + (d.step ? *d.step : 0ull)), k0((uint32_t)d.seed), k1((uint32_t)(d.seed >> 32)),
+          p(d.p), inv(d.p > 0.f ? 1.f / (1.f - d.p) : 1.f) {}
+    __device__ __forceinline__ float operator()(size_t idx) const {
+        if (!(p > 0.f)) return 1.f;
+        if (mask) return mask[idx] ? inv : 0.f;
+        uint32_t r[4];
+        seq_philox4x32_10((uint32_t)idx, (uint32_t)((unsigned long long)idx >> 32), (uint32_t)off, (uint32_t)(off >> 32), k0, k1, r);
+        const float u = (float)(r[0] >> 8) * (1.f / 16777216.f);        // [0, 1)
+        return u >= p ? inv : 0.f;
+    }
+};
+
+__global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                      const DropSpec spec) {
+    const DropState ds(spec);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i] * ds(i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over D for every token (b, t) of x[B, D, T]; lanes walk consecutive t (coalesced), D is strided.
 // ---------------------------------------------------------------------------------------------------------------
 // `res` (optional): the layer normalises x + res (the residual connection of the encoder layer) without a
@@ -38,8 +91,9 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int B, int D,
-                                                     int T, float eps) {
+                                                     int T, float eps, const DropSpec spec) {
     __shared__ float sh[kLnGrp][kLnTok];
+    const DropState ds(spec);
     const int tl = threadIdx.x & (kLnTok - 1), grp = threadIdx.x / kLnTok;
     const int tok = blockIdx.x * kLnTok + tl;
     const bool ok = tok < B * T;
@@ -47,12 +101,16 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
     const size_t base = (size_t)b * D * T + t;
     float s = 0.f;
     if (ok)
-        for (int c = grp; c < D; c += kLnGrp) s += x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
+        for (int c = grp; c < D; c += kLnGrp) {
+            const size_t i = base + (size_t)c * T;
+            s += x[i] * ds(i) + (res ? res[i] : 0.f);
+        }
     const float mu = ln_group_sum(s, sh, tl, grp) / (float)D;
     float v = 0.f;
     if (ok)
         for (int c = grp; c < D; c += kLnGrp) {
-            const float d = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu;
+            const size_t i = base + (size_t)c * T;
+            const float d = x[i] * ds(i) + (res ? res[i] : 0.f) - mu;
             v += d * d;
         }
     const float rs = rsqrtf(ln_group_sum(v, sh, tl, grp) / (float)D + eps);
@@ -62,8 +120,9 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
         if (rstd) rstd[tok] = rs;
     }
     for (int c = grp; c < D; c += kLnGrp) {
-        const float sv = x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f);
-        y[base + (size_t)c * T] = (sv - mu) * rs * gamma[c] + beta[c];
+        const size_t i = base + (size_t)c * T;
+        const float sv = x[i] * ds(i) + (res ? res[i] : 0.f);
+        y[i] = (sv - mu) * rs * gamma[c] + beta[c];
     }
 }
 
@@ -71,9 +130,11 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 __global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                         const float* __restrict__ res,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, float* __restrict__ dx, int B,
-                                                        int D, int T) {
+                                                        const float* __restrict__ rstd, float* __restrict__ dx,
+                                                        float* __restrict__ dres, int B, int D, int T,
+                                                        const DropSpec spec) {
     __shared__ float sh[kLnGrp][kLnTok];
+    const DropState ds(spec);
     const int tl = threadIdx.x & (kLnTok - 1), grp = threadIdx.x / kLnTok;
     const int tok = blockIdx.x * kLnTok + tl;
     const bool ok = tok < B * T;
@@ -83,18 +144,24 @@ __global__ void __launch_bounds__(256) ln_bwd_dx_kernel(const float* __restrict_
     float s1 = 0.f, s2 = 0.f;
     if (ok)
         for (int c = grp; c < D; c += kLnGrp) {
-            const float gg = g[base + (size_t)c * T] * gamma[c];
-            const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
+            const size_t i = base + (size_t)c * T;
+            const float gg = g[i] * gamma[c];
+            const float xh = (x[i] * ds(i) + (res ? res[i] : 0.f) - mu) * rs;
             s1 += gg;
             s2 += gg * xh;
         }
     s1 = ln_group_sum(s1, sh, tl, grp) / (float)D;
     s2 = ln_group_sum(s2, sh, tl, grp) / (float)D;
     if (!ok) return;
+    // d(x*keep + res): the residual branch receives it as is (dres), x through its keep factor (dx)
     for (int c = grp; c < D; c += kLnGrp) {
-        const float gg = g[base + (size_t)c * T] * gamma[c];
-        const float xh = (x[base + (size_t)c * T] + (res ? res[base + (size_t)c * T] : 0.f) - mu) * rs;
-        dx[base + (size_t)c * T] = rs * (gg - s1 - xh * s2);
+        const size_t i = base + (size_t)c * T;
+        const float gg = g[i] * gamma[c];
+        const float k = ds(i);
+        const float xh = (x[i] * k + (res ? res[i] : 0.f) - mu) * rs;
+        const float dv = rs * (gg - s1 - xh * s2);
+        if (dres) dres[i] = dv;
+        if (dx) dx[i] = dv * k;
     }
 }
 
@@ -103,15 +170,17 @@ __global__ void __launch_bounds__(256) ln_bwd_param_kernel(const float* __restri
                                                            const float* __restrict__ res,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int B, int D, int T) {
+                                                           float* __restrict__ dbeta, int B, int D, int T,
+                                                           const DropSpec spec) {
     __shared__ float red[4];
+    const DropState ds(spec);
     const int c = blockIdx.x;
     float a = 0.f, bsum = 0.f;
     for (int tok = threadIdx.x; tok < B * T; tok += 256) {
         const int b = tok / T, t = tok - b * T;
         const size_t i = ((size_t)b * D + c) * T + t;
         const float gv = g[i];
-        a += gv * (x[i] + (res ? res[i] : 0.f) - mean[tok]) * rstd[tok];
+        a += gv * (x[i] * ds(i) + (res ? res[i] : 0.f) - mean[tok]) * rstd[tok];
         bsum += gv;
     }
     const float ta = block_reduce_sum_256<float>(a, red);
@@ -136,9 +205,10 @@ __global__ void __launch_bounds__(256) ln_bwd_param_kernel(const float* __restri
 // scalar branch and the kernel runs 3x slower); the non-exact instantiation serves any dh <= DH.
 template <int DH, bool EXACT>
 __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                     float* __restrict__ probs, int D, int T, int H) {
+                                                     float* __restrict__ probs, int D, int T, int H, const DropSpec spec) {
     __shared__ float ks[DH][kSeqMaxT], vs[DH][kSeqMaxT];
     __shared__ float ps[kSeqMaxT][kSeqMaxT + 1];
+    const DropState drop(spec);
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int dh = D / H;
     const int i = threadIdx.x;
@@ -168,17 +238,19 @@ __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ q
         mx = fmaxf(mx, s);
     }
     float den = 0.f;
+    const size_t prow = ((size_t)blockIdx.x * T + i) * T;      // probs (and their keep flags) are [B*H][T][T]
     for (int j = 0; j < T; ++j) {
         const float e = expf(ps[i][j] - mx);
         ps[i][j] = e;
         den += e;
+        const float ek = e * drop(prow + j);                     // dropout acts on the normalised probabilities: linear in e
 #pragma unroll
         for (int c = 0; c < DH; ++c)
-            if (EXACT || c < dh) o[c] += e * vs[c][j];
+            if (EXACT || c < dh) o[c] += ek * vs[c][j];
     }
     const float inv = 1.f / den;
-    float* pg = probs + ((size_t)blockIdx.x * T + i) * T;
-    for (int j = 0; j < T; ++j) pg[j] = ps[i][j] * inv;
+    float* pg = probs + prow;
+    for (int j = 0; j < T; ++j) pg[j] = ps[i][j] * inv;        // saved for the backward: the probabilities BEFORE dropout
     float* ob = out + (size_t)b * D * T;
 #pragma unroll
     for (int c = 0; c < DH; ++c)
@@ -188,7 +260,8 @@ __global__ void __launch_bounds__(64) mha_fwd_kernel(const float* __restrict__ q
 template <int DH, bool EXACT>
 __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g, const float* __restrict__ qkv,
                                                      const float* __restrict__ probs, float* __restrict__ dqkv, int D,
-                                                     int T, int H) {
+                                                     int T, int H, const DropSpec spec) {
+    const DropState drop(spec);
     __shared__ float qs[DH][kSeqMaxT], ks[DH][kSeqMaxT], vs[DH][kSeqMaxT], gs[DH][kSeqMaxT];
     __shared__ float ps[kSeqMaxT][kSeqMaxT + 1], ds[kSeqMaxT][kSeqMaxT + 1];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -215,17 +288,23 @@ __global__ void __launch_bounds__(64) mha_bwd_kernel(const float* __restrict__ g
     }
     __syncthreads();
     if (act) {
-        // dP[i][j] = sum_c g[c][i] v[c][j];  dS = P * (dP - sum_j P dP)
+        // P' = P * keep (what multiplied V);  dP'[i][j] = sum_c g[c][i] v[c][j];  dP = dP' * keep;
+        // dS = P * (dP - sum_j P dP).  Row i then keeps P' in ps (dV needs it), P is not used again.
+        const size_t prow = ((size_t)blockIdx.x * T + i) * T;
         float dot = 0.f;
         for (int j = 0; j < T; ++j) {
             float sacc = 0.f;
 #pragma unroll
             for (int c = 0; c < DH; ++c)
                 if (EXACT || c < dh) sacc += gq[c] * vs[c][j];
+            sacc *= drop(prow + j);
             ds[i][j] = sacc;
             dot += ps[i][j] * sacc;
         }
-        for (int j = 0; j < T; ++j) ds[i][j] = ps[i][j] * (ds[i][j] - dot);
+        for (int j = 0; j < T; ++j) {
+            ds[i][j] = ps[i][j] * (ds[i][j] - dot);
+            ps[i][j] *= drop(prow + j);
+        }
     }
     __syncthreads();
     if (!act) return;
@@ -372,39 +451,72 @@ using namespace dynmm;
 
 #define ST ((hipStream_t)stream)
 
+static DropSpec drop_spec(const dynmm_dropout* d) {
+    DropSpec s{};
+    if (d && d->p > 0.f) {
+        s.mask = d->mask; s.step = d->step; s.seed = d->seed; s.offset = d->offset; s.p = d->p;
+    }
+    return s;
+}
+static bool drop_ok(const dynmm_dropout* d) { return !d || (d->p >= 0.f && d->p < 1.f); }
+
+extern "C" int dynmm_dropout_apply(const float* x, float* y, size_t n, const dynmm_dropout* drop, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !y || n == 0 || !drop_ok(drop)) return DYNMM_EINVAL;
+    const size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, ST, x, y, n, drop_spec(drop));
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_layernorm_drop_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                        float* mean, float* rstd, int B, int D, int T, float eps,
+                                        const dynmm_dropout* drop, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !gamma || !beta || !y || B <= 0 || D <= 0 || T <= 0 || !drop_ok(drop)) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, x, res, gamma, beta, y, mean, rstd,
+                       B, D, T, eps, drop_spec(drop));
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
 extern "C" int dynmm_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                    float* mean, float* rstd, int B, int D, int T, float eps, void* stream) {
+    return dynmm_layernorm_drop_fwd(x, res, gamma, beta, y, mean, rstd, B, D, T, eps, nullptr, stream);
+}
+
+extern "C" int dynmm_layernorm_drop_bwd(const float* g, const float* x, const float* res, const float* gamma,
+                                        const float* mean, const float* rstd, float* dx, float* dres, float* dgamma,
+                                        float* dbeta, int B, int D, int T, const dynmm_dropout* drop, void* stream) {
     (void)hipGetLastError();
-    if (!x || !gamma || !beta || !y || B <= 0 || D <= 0 || T <= 0) return DYNMM_EINVAL;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, x, res, gamma, beta, y, mean, rstd,
-                       B, D, T, eps);
-    DYNMM_LAUNCH_CHECK();
+    if (!g || !x || !gamma || !mean || !rstd || B <= 0 || D <= 0 || T <= 0 || !drop_ok(drop)) return DYNMM_EINVAL;
+    if (dx || dres) {
+        hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, g, x, res, gamma, mean, rstd,
+                           dx, dres, B, D, T, drop_spec(drop));
+        DYNMM_LAUNCH_CHECK();
+    }
+    if (dgamma && dbeta) {
+        hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(D), dim3(256), 0, ST, g, x, res, mean, rstd, dgamma, dbeta, B, D, T,
+                           drop_spec(drop));
+        DYNMM_LAUNCH_CHECK();
+    }
     return DYNMM_OK;
 }
 
 extern "C" int dynmm_layernorm_bwd(const float* g, const float* x, const float* res, const float* gamma,
                                    const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, int B,
                                    int D, int T, void* stream) {
-    (void)hipGetLastError();
-    if (!g || !x || !gamma || !mean || !rstd || B <= 0 || D <= 0 || T <= 0) return DYNMM_EINVAL;
-    if (dx) {
-        hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, g, x, res, gamma, mean, rstd,
-                           dx, B, D, T);
-        DYNMM_LAUNCH_CHECK();
-    }
-    if (dgamma && dbeta) {
-        hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(D), dim3(256), 0, ST, g, x, res, mean, rstd, dgamma, dbeta, B, D, T);
-        DYNMM_LAUNCH_CHECK();
-    }
-    return DYNMM_OK;
+    return dynmm_layernorm_drop_bwd(g, x, res, gamma, mean, rstd, dx, nullptr, dgamma, dbeta, B, D, T, nullptr, stream);
 }
 
-extern "C" int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads, void* stream) {
+extern "C" int dynmm_mha_drop_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads,
+                                  const dynmm_dropout* drop, void* stream) {
     (void)hipGetLastError();
-    if (!qkv || !out || !probs || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
+    if (!qkv || !out || !probs || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0 || !drop_ok(drop)) return DYNMM_EINVAL;
+    const DropSpec spec = drop_spec(drop);
     if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
     const int dh = D / heads;
-#define DYNMM_MHA_F(DH, EX) hipLaunchKernelGGL((mha_fwd_kernel<DH, EX>), dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads)
+#define DYNMM_MHA_F(DH, EX) hipLaunchKernelGGL((mha_fwd_kernel<DH, EX>), dim3(B * heads), dim3(64), 0, ST, qkv, out, probs, D, T, heads, spec)
     if (dh == 24) DYNMM_MHA_F(24, true);
     else if (dh == 12) DYNMM_MHA_F(12, true);
     else if (dh == 2) DYNMM_MHA_F(2, true);
@@ -414,13 +526,18 @@ extern "C" int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, 
     return DYNMM_OK;
 }
 
-extern "C" int dynmm_mha_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T,
-                             int heads, void* stream) {
+extern "C" int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads, void* stream) {
+    return dynmm_mha_drop_fwd(qkv, out, probs, B, D, T, heads, nullptr, stream);
+}
+
+extern "C" int dynmm_mha_drop_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T,
+                                  int heads, const dynmm_dropout* drop, void* stream) {
     (void)hipGetLastError();
-    if (!g || !qkv || !probs || !dqkv || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0) return DYNMM_EINVAL;
+    if (!g || !qkv || !probs || !dqkv || B <= 0 || D <= 0 || T <= 0 || heads <= 0 || D % heads != 0 || !drop_ok(drop)) return DYNMM_EINVAL;
+    const DropSpec spec = drop_spec(drop);
     if (T > kSeqMaxT || D / heads > kSeqMaxDh) return DYNMM_EUNSUPPORTED;
     const int dh = D / heads;
-#define DYNMM_MHA_B(DH, EX) hipLaunchKernelGGL((mha_bwd_kernel<DH, EX>), dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads)
+#define DYNMM_MHA_B(DH, EX) hipLaunchKernelGGL((mha_bwd_kernel<DH, EX>), dim3(B * heads), dim3(64), 0, ST, g, qkv, probs, dqkv, D, T, heads, spec)
     if (dh == 24) DYNMM_MHA_B(24, true);
     else if (dh == 12) DYNMM_MHA_B(12, true);
     else if (dh == 2) DYNMM_MHA_B(2, true);
@@ -428,6 +545,11 @@ extern "C" int dynmm_mha_bwd(const float* g, const float* qkv, const float* prob
 #undef DYNMM_MHA_B
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
+}
+
+extern "C" int dynmm_mha_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T,
+                             int heads, void* stream) {
+    return dynmm_mha_drop_bwd(g, qkv, probs, dqkv, B, D, T, heads, nullptr, stream);
 }
 
 extern "C" int dynmm_moe_head(const float* logits, const float* const* preds, int K, const float* target, float temp,

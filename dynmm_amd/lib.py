@@ -26,7 +26,14 @@ class ConvGeom(C.Structure):
                                        'KH', 'KW', 'SH', 'SW', 'PH', 'PW', 'c_split')]
 
 
+class Dropout(C.Structure):
+    """dynmm_dropout (include/dynmm_hip.h)."""
+    _fields_ = [('mask', C.c_void_p), ('step', C.c_void_p), ('seed', C.c_ulonglong), ('offset', C.c_ulonglong),
+                ('p', C.c_float)]
+
+
 _GP = C.POINTER(ConvGeom)
+_DP = C.POINTER(Dropout)
 _PP = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/dynmm_hip.h one to one
@@ -111,6 +118,11 @@ SIGNATURES = {
     'dynmm_moe_blend_bwd': (c_i, [c_f, c_f, c_f, _PP, c_i, c_f, c_fl, _PP, c_f, c_i, c_f]),
     'dynmm_mha_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_mha_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_dropout_apply': (c_i, [c_f, c_f, c_sz, _DP, c_f]),
+    'dynmm_layernorm_drop_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_i, c_fl, _DP, c_f]),
+    'dynmm_layernorm_drop_bwd': (c_i, [c_f] * 10 + [c_i, c_i, c_i, _DP, c_f]),
+    'dynmm_mha_drop_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, _DP, c_f]),
+    'dynmm_mha_drop_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, _DP, c_f]),
     'dynmm_moe_head': (c_i, [c_f, _PP, c_i, c_f, c_fl, c_i, c_fl, c_f, c_f, c_f, _PP, c_f, c_i, c_f]),
     'dynmm_clip_grad_norm_workspace_bytes': (c_sz, []),
     'dynmm_clip_grad_norm': (c_i, [c_f, c_sz, c_fl, c_f, c_f, c_f]),

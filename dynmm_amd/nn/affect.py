@@ -19,8 +19,9 @@ regulariser mean(w[:, 1])) and DynMMNet (affect_dyn.py:31-104: three uni-modal e
 
 Modules are parameter containers with torch's own state_dict keys (`conv.weight`, `transformer.layers.N.self_attn.
 in_proj_weight`, ...), so `expert.state_dict()` of a trained MultiBench module loads with load_state_dict.  Dropout
-(p = 0.1 inside nn.TransformerEncoderLayer while training) is NOT applied by the HIP path: outputs equal the
-reference's eval-mode arithmetic, in training as well.
+(p = 0.1 inside nn.TransformerEncoderLayer) is applied in training mode at torch's four sites per layer, with a Philox
+stream of its own (ops.manual_seed; torch's generator cannot be reproduced bit for bit, the tests inject the keep flags
+on both sides); `.eval()` switches it off as in torch.
 """
 import torch
 import torch.nn as nn
@@ -31,16 +32,30 @@ FEATURES = {'visual': 35, 'audio': 74, 'text': 300}      # CMU-MOSEI (affect/cou
 
 
 def encoder_layer(h, layer, heads):
-    """nn.TransformerEncoderLayer.forward (post-norm): h [B, D, T]."""
+    """nn.TransformerEncoderLayer.forward (post-norm): h [B, D, T].  In training mode the layer's four dropouts act where
+    torch applies them: on the attention probabilities (MultiheadAttention.dropout), on the attention block's output
+    (dropout1, fused into norm1's kernel), on the feed-forward hidden layer (dropout) and on the feed-forward output
+    (dropout2, fused into norm2's kernel)."""
     sa = layer.self_attn
+    train = layer.training
+    site = getattr(layer, '_dynmm_sites', None)
+    if site is None:
+        site = layer._dynmm_sites = S.new_sites(4)
+    p_att = float(sa.dropout) if train else 0.0
+    p1, pf, p2 = ((float(m.p) if train else 0.0) for m in (layer.dropout1, layer.dropout, layer.dropout2))
     qkv = S.linear_bdt(h, sa.in_proj_weight, sa.in_proj_bias)
-    a = S.mha_core(qkv, heads)
+    a = S.mha_core(qkv, heads, drop=(p_att, site, 'attn'))
     o = S.linear_bdt(a, sa.out_proj.weight, sa.out_proj.bias)
-    h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h)
-    # the ReLU backward of linear1 is applied in the input-gradient epilogue of linear2 (its only consumer)
-    f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu', defer_mask=True)
-    f = S.linear_bdt(f, layer.linear2.weight, layer.linear2.bias, mask_input=True)
-    return S.layernorm_bdt(f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, residual=h1)
+    h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h, drop=(p1, site + 1, 'dropout1'))
+    if pf > 0:
+        f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu')
+        f = S.dropout_bdt(f, pf, site + 2, 'dropout')
+        f = S.linear_bdt(f, layer.linear2.weight, layer.linear2.bias)
+    else:
+        # the ReLU backward of linear1 is applied in the input-gradient epilogue of linear2 (its only consumer)
+        f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu', defer_mask=True)
+        f = S.linear_bdt(f, layer.linear2.weight, layer.linear2.bias, mask_input=True)
+    return S.layernorm_bdt(f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, residual=h1, drop=(p2, site + 3, 'dropout2'))
 
 
 class Transformer(nn.Module):
@@ -218,6 +233,7 @@ class AffectTrainStep:
         from .. import engine, ops
         m = self.model
         self.flat_g.zero_()
+        S.advance_dropout_step(self.flat_g.device)   # new dropout masks every step (also under hipGraph replay)
         prev, ops.PREPACK = ops.PREPACK, self.prepack
         self.prepack.pack()
         try:
@@ -239,7 +255,7 @@ class AffectTrainStep:
             self._body(inputs, target)
             return self.last
         m = self.model
-        key = (tuple(tuple(x.shape) for x in inputs[0]), float(m.temp), bool(m.hard_gate))
+        key = (tuple(tuple(x.shape) for x in inputs[0]), float(m.temp), bool(m.hard_gate), bool(m.training))
         entry = self._graphs.get(key)
         if entry is None:
             static_in = [[x.clone() for x in inputs[0]], inputs[1]]

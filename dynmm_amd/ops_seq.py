@@ -5,6 +5,7 @@ Activations are [B, D, T] fp32 (the layout the reference feeds its Conv1d after 
 added for this path live in csrc/seq.hip.  As everywhere in dynmm_amd there is no CPU / eager fallback.
 """
 import ctypes as C
+import itertools
 
 import torch
 from torch.autograd import Function
@@ -31,6 +32,82 @@ def linear_bdt(x, weight, bias=None, act=None, defer_mask=False, mask_input=Fals
     return y.reshape(y.shape[0], y.shape[1]) if squeeze else y.reshape(y.shape[0], y.shape[1], -1)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# dropout (nn.TransformerEncoderLayer trains with p = 0.1 at four sites per layer)
+# ---------------------------------------------------------------------------------------------------------------
+# A site is an integer; its keep decisions are Philox(seed, (site << 32) + device step counter, element index)
+# (csrc/seq.hip): nothing is stored for the backward, and a captured step draws new masks at every replay because the
+# counter lives on the device (advance_dropout_step(), called once per training step).
+MASKS = None            # tests: callable(site_name, shape) -> uint8 keep flags (device tensor) or None
+_SITE_IDS = itertools.count(1)
+_STEP = {}
+
+
+def new_sites(n):
+    """n consecutive site ids (one encoder layer takes 4)."""
+    first = next(_SITE_IDS)
+    for _ in range(n - 1):
+        next(_SITE_IDS)
+    return first
+
+
+def dropout_step(device):
+    t = _STEP.get(device)
+    if t is None:
+        t = _STEP[device] = torch.zeros(1, device=device, dtype=torch.int64)
+    return t
+
+
+def advance_dropout_step(device):
+    dropout_step(device).add_(1)
+
+
+class Drop:
+    """One dropout site of one call: probability, site id and (tests) the injected keep flags."""
+
+    def __init__(self, p, site, name, shape, device):
+        self.p, self.site = float(p), int(site)
+        self.mask = None
+        if MASKS is not None and self.p > 0:
+            m = MASKS(name, tuple(shape))
+            if m is not None:
+                if m.dtype != torch.uint8 or tuple(m.shape) != tuple(shape) or not m.is_cuda:
+                    raise L.DynmmHipError(f'dropout mask for {name}: expected uint8 {tuple(shape)} on the device')
+                self.mask = m.contiguous()
+        self.step = dropout_step(device) if self.p > 0 else None
+
+    def desc(self):
+        return L.Dropout(_p(self.mask), _p(self.step), ops._PHILOX_SEED, self.site << 32, self.p)
+
+
+def _drop_arg(d):
+    return C.byref(d.desc()) if d is not None and d.p > 0 else None
+
+
+class _DropoutBDT(Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        x = _chk(x, 'x')
+        y = torch.empty_like(x)
+        L.check(_lib().dynmm_dropout_apply(_p(x), _p(y), C.c_size_t(x.numel()), _drop_arg(drop), _stream()), 'dropout')
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g, 'grad')
+        dx = torch.empty_like(g)
+        L.check(_lib().dynmm_dropout_apply(_p(g), _p(dx), C.c_size_t(g.numel()), _drop_arg(ctx.drop), _stream()), 'dropout')
+        return dx, None
+
+
+def dropout_bdt(x, p, site, name='dropout'):
+    """x * keep / (1 - p) (nn.Dropout in training mode); identity when p == 0."""
+    if not p > 0:
+        return x
+    return _DropoutBDT.apply(x, Drop(p, site, name, x.shape, x.device))
+
+
 class _Alias(Function):
     """weight viewed as [Co, Ci, 1, 1]; the gradient comes back in the same memory layout."""
 
@@ -46,15 +123,16 @@ class _Alias(Function):
 
 class _LayerNormBDT(Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, drop=None):
         lib = _lib()
         x, res, gamma, beta = _chk(x, 'x'), _chk(res, 'res'), _chk(gamma, 'gamma'), _chk(beta, 'beta')
         B, D, T = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(B * T, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        L.check(lib.dynmm_layernorm_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), B, D, T,
-                                        float(eps), _stream()), 'layernorm_fwd')
+        L.check(lib.dynmm_layernorm_drop_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), B, D, T,
+                                             float(eps), _drop_arg(drop), _stream()), 'layernorm_fwd')
+        ctx.drop = drop
         ctx.save_for_backward(x, res, gamma, mean, rstd)
         ctx.g_param, ctx.b_param = gamma, beta
         return y
@@ -65,34 +143,39 @@ class _LayerNormBDT(Function):
         x, res, gamma, mean, rstd = ctx.saved_tensors
         g = _chk(g, 'grad')
         B, D, T = x.shape
-        need_dx = ctx.needs_input_grad[0] or (res is not None and ctx.needs_input_grad[1])
-        dx = torch.empty_like(x) if need_dx else None
+        need_x = ctx.needs_input_grad[0]
+        need_res = res is not None and ctx.needs_input_grad[1]
+        dropping = ctx.drop is not None and ctx.drop.p > 0
+        # without dropout the two branches of the sum receive the same tensor; with it x gets its keep factor on top
+        dres = torch.empty_like(x) if (need_res or (need_x and not dropping)) else None
+        dx = torch.empty_like(x) if (need_x and dropping) else None
         dg = dg_ret = db = db_ret = None
         if ctx.needs_input_grad[2]:
             dg, dg_ret = _grad_dst(ctx.g_param)
             db, db_ret = _grad_dst(ctx.b_param)
-        L.check(lib.dynmm_layernorm_bwd(_p(g), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db),
-                                        B, D, T, _stream()), 'layernorm_bwd')
+        L.check(lib.dynmm_layernorm_drop_bwd(_p(g), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres), _p(dg),
+                                             _p(db), B, D, T, _drop_arg(ctx.drop), _stream()), 'layernorm_bwd')
         _grads_enqueued()
-        return (dx if ctx.needs_input_grad[0] else None), (dx if (res is not None and ctx.needs_input_grad[1]) else None), \
-            dg_ret, db_ret, None
+        return ((dx if dropping else dres) if need_x else None), (dres if need_res else None), dg_ret, db_ret, None, None
 
 
-def layernorm_bdt(x, gamma, beta, eps=1e-5, residual=None):
-    """LayerNorm over D of (x + residual), x [B, D, T]."""
-    return _LayerNormBDT.apply(x, residual, gamma, beta, eps)
+def layernorm_bdt(x, gamma, beta, eps=1e-5, residual=None, drop=None):
+    """LayerNorm over D of (dropout(x) + residual), x [B, D, T]; drop = (p, site, name) or None."""
+    d = Drop(drop[0], drop[1], drop[2], x.shape, x.device) if drop is not None and drop[0] > 0 else None
+    return _LayerNormBDT.apply(x, residual, gamma, beta, eps, d)
 
 
 class _MHACore(Function):
     @staticmethod
-    def forward(ctx, qkv, heads):
+    def forward(ctx, qkv, heads, drop=None):
         lib = _lib()
         qkv = _chk(qkv, 'qkv')
         B, D3, T = qkv.shape
         D = D3 // 3
         out = torch.empty((B, D, T), device=qkv.device, dtype=torch.float32)
         probs = torch.empty((B * heads, T, T), device=qkv.device, dtype=torch.float32)
-        L.check(lib.dynmm_mha_fwd(_p(qkv), _p(out), _p(probs), B, D, T, heads, _stream()), 'mha_fwd')
+        L.check(lib.dynmm_mha_drop_fwd(_p(qkv), _p(out), _p(probs), B, D, T, heads, _drop_arg(drop), _stream()), 'mha_fwd')
+        ctx.drop = drop
         ctx.save_for_backward(qkv, probs)
         ctx.heads = heads
         return out
@@ -104,13 +187,17 @@ class _MHACore(Function):
         g = _chk(g, 'grad')
         B, D3, T = qkv.shape
         dqkv = torch.empty_like(qkv)
-        L.check(lib.dynmm_mha_bwd(_p(g), _p(qkv), _p(probs), _p(dqkv), B, D3 // 3, T, ctx.heads, _stream()), 'mha_bwd')
-        return dqkv, None
+        L.check(lib.dynmm_mha_drop_bwd(_p(g), _p(qkv), _p(probs), _p(dqkv), B, D3 // 3, T, ctx.heads, _drop_arg(ctx.drop),
+                                       _stream()), 'mha_bwd')
+        return dqkv, None, None
 
 
-def mha_core(qkv, heads):
-    """softmax(q k^T / sqrt(dh)) v per head for qkv [B, 3D, T] (q | k | v along channels) -> [B, D, T]."""
-    return _MHACore.apply(qkv, heads)
+def mha_core(qkv, heads, drop=None):
+    """dropout(softmax(q k^T / sqrt(dh))) v per head for qkv [B, 3D, T] (q | k | v along channels) -> [B, D, T];
+    drop = (p, site, name) or None: dropout on the [B*heads, T, T] probabilities."""
+    B, D3, T = qkv.shape
+    d = Drop(drop[0], drop[1], drop[2], (B * heads, T, T), qkv.device) if drop is not None and drop[0] > 0 else None
+    return _MHACore.apply(qkv, heads, d)
 
 
 class _MoEBlend(Function):

@@ -425,6 +425,34 @@ int dynmm_layernorm_bwd(const float* g, const float* x, const float* res, const 
 int dynmm_mha_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads, void* stream);
 int dynmm_mha_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T, int heads,
                   void* stream);
+/* Dropout as nn.TransformerEncoderLayer applies it while training (p = 0.1: attention probabilities, attention-block output,
+ * feed-forward hidden layer, feed-forward output): an element survives with probability 1-p and is scaled by 1/(1-p).
+ * The decision for element i is Philox-4x32-10(counter = i, offset + *step; key = seed) >= p, a pure function of its
+ * arguments: the backward pass regenerates it (no stored masks) and a captured hipGraph draws new masks at every replay
+ * because `step` (optional) is a DEVICE counter the training step advances.  `mask` (optional, tests): explicit keep
+ * flags, one byte per element, instead of the generator.  p == 0 or a NULL descriptor: no dropout. */
+typedef struct dynmm_dropout {
+    const unsigned char* mask;
+    const unsigned long long* step;
+    unsigned long long seed, offset;
+    float p;
+} dynmm_dropout;
+/* y[i] = x[i] * keep_i / (1-p)  (forward and, with the same descriptor, backward); in place allowed. */
+int dynmm_dropout_apply(const float* x, float* y, size_t n, const dynmm_dropout* drop, void* stream);
+/* LayerNorm(dropout(x) + res): indices of the dropout site run over x's [B, D, T] layout.  Backward: dres = gradient of the
+ * normalised sum (what the residual branch receives), dx = dres * keep/(1-p); either may be NULL. */
+int dynmm_layernorm_drop_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                             float* mean, float* rstd, int B, int D, int T, float eps, const dynmm_dropout* drop,
+                             void* stream);
+int dynmm_layernorm_drop_bwd(const float* g, const float* x, const float* res, const float* gamma, const float* mean,
+                             const float* rstd, float* dx, float* dres, float* dgamma, float* dbeta, int B, int D, int T,
+                             const dynmm_dropout* drop, void* stream);
+/* attention with dropout on the probabilities (indices over probs' [B*heads, T, T] layout); probs holds the
+ * probabilities BEFORE dropout, which is what the backward needs together with the regenerated keep flags. */
+int dynmm_mha_drop_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads,
+                       const dynmm_dropout* drop, void* stream);
+int dynmm_mha_drop_bwd(const float* g, const float* qkv, const float* probs, float* dqkv, int B, int D, int T, int heads,
+                       const dynmm_dropout* drop, void* stream);
 /* Mixture head (affect_dyn.py:152-165) + loss (Supervised_Learning.py:135-136): w = DiffSoftmax(logits[B,K]/temp),
  * out = sum_k w_k pred_k, aux = mean w[:,K-1], loss1 = mean |out - target|, scalars = {loss1, aux, loss1 + reg*aux};
  * with target != NULL also the backward seeds d_preds[k][B] (optional per k) and d_logits[B,K]. K <= 4. */

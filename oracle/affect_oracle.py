@@ -5,13 +5,36 @@ PARITY UNPINNED.  The arithmetic of the reference's experts lives in MultiBench 
 `fusions.common_fusions`), which /root/reference neither vendors nor pins to a commit (ModalityDynMM README;
 affect_dyn.py:12-15), and the reference holds no golden vector, known-answer test or fixture for this path.  This
 file restates MultiBench's published module definitions with the real torch.nn layers they wrap (dropout set to 0:
-the deterministic, eval-mode arithmetic) and the reference's own DynMMNetV2 / DynMMNet / DiffSoftmax
+the deterministic, eval-mode arithmetic; the training-mode arithmetic with EXPLICIT keep flags is `encoder_layer_dropout`,
+pinned to torch's own layer in tests/test_affect.py) and the reference's own DynMMNetV2 / DynMMNet / DiffSoftmax
 (affect_dyn.py:18-28, 31-104, 107-175) and training objective (Supervised_Learning.py:120-144).  State-dict keys
 equal those of dynmm_amd.nn.affect, so one deterministic fill drives both sides.
 """
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+def encoder_layer_dropout(layer, x, p, next_mask):
+    """nn.TransformerEncoderLayer.forward (post-norm, ReLU; torch/nn/modules/transformer.py) in training mode, with the four
+    dropout decisions supplied by the caller instead of drawn: x [T, B, D]; next_mask(name, shape) -> keep flags in the
+    HIP path's layouts — 'attn' [B*heads, T, T], 'dropout1' / 'dropout2' [B, D, T], 'dropout' [B, dim_feedforward, T]."""
+    T, B, D = x.shape
+    sa = layer.self_attn
+    H = sa.num_heads
+    dh = D // H
+    keep = lambda name, shape: next_mask(name, shape).to(x.dtype) / (1.0 - p)
+    q, k, v = F.linear(x, sa.in_proj_weight, sa.in_proj_bias).chunk(3, dim=-1)
+    q, k, v = (t.reshape(T, B * H, dh).transpose(0, 1) for t in (q, k, v))          # [B*H, T, dh], batch index b*H + h
+    att = torch.softmax((q / math.sqrt(dh)) @ k.transpose(1, 2), dim=-1) * keep('attn', (B * H, T, T))
+    o = (att @ v).transpose(0, 1).reshape(T, B, D)
+    o = F.linear(o, sa.out_proj.weight, sa.out_proj.bias)
+    x = layer.norm1(x + o * keep('dropout1', (B, D, T)).permute(2, 0, 1))
+    f = F.relu(layer.linear1(x))
+    f = layer.linear2(f * keep('dropout', (B, f.shape[-1], T)).permute(2, 0, 1))
+    return layer.norm2(x + f * keep('dropout2', (B, D, T)).permute(2, 0, 1))
 
 
 class Transformer(nn.Module):
@@ -23,11 +46,18 @@ class Transformer(nn.Module):
         layer = nn.TransformerEncoderLayer(d_model=dim, nhead=nhead, dropout=0.0)
         self.transformer = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
 
+    dropout_masks = None      # (p, next_mask): training-mode arithmetic with injected keep flags (see encoder_layer_dropout)
+
     def forward(self, x):
         if isinstance(x, (list, tuple)):
             x = x[0]
         x = self.conv(x.permute([0, 2, 1]))
         x = x.permute([2, 0, 1])
+        if Transformer.dropout_masks is not None:
+            p, next_mask = Transformer.dropout_masks
+            for layer in self.transformer.layers:
+                x = encoder_layer_dropout(layer, x, p, next_mask)
+            return x[-1]
         return self.transformer(x)[-1]
 
 

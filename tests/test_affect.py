@@ -20,6 +20,55 @@ def test_state_dict_layout_matches_oracle():
         A.DynMMNetV2(model_name_list=['b1.pt', 'b2.pt'])
 
 
+class _Masks:
+    """The n-th dropout site of a forward pass keeps element e iff rand_n(e) >= p: one deterministic stream both sides
+    walk in the same order (gate, experts; per layer: attn, dropout1, dropout, dropout2)."""
+
+    def __init__(self, p, seed, device='cpu'):
+        self.p, self.seed, self.n, self.device = p, seed, 0, device
+        self.names = []
+
+    def __call__(self, name, shape):
+        g = torch.Generator().manual_seed(self.seed * 100003 + self.n)
+        self.n += 1
+        self.names.append(name)
+        m = (torch.rand(shape, generator=g) >= self.p).to(torch.uint8)
+        return m.to(self.device)
+
+
+def test_oracle_dropout_layer_is_torchs_layer():
+    """oracle.encoder_layer_dropout against torch.nn.TransformerEncoderLayer itself: identical without dropout, and — with
+    nn.Dropout.forward replaced by the same injected keep flags — identical at the three nn.Dropout sites (dropout1,
+    dropout, dropout2).  (The fourth site sits inside scaled_dot_product_attention and cannot be injected into torch; its
+    position — on the softmax output, before the product with V — is torch/nn/functional.py's.)"""
+    from oracle import affect_oracle as O
+    torch.manual_seed(0)
+    T, B, D, p = 7, 3, 20, 0.25
+    layer = torch.nn.TransformerEncoderLayer(d_model=D, nhead=5, dim_feedforward=48, dropout=p)
+    x = torch.randn(T, B, D)
+    ones = lambda name, shape: torch.full(shape, 1.0)
+    layer.eval()
+    assert _rel(O.encoder_layer_dropout(layer, x, 0.0, ones), layer(x)) < 1e-6
+    layer.train()
+    layer.self_attn.dropout = 0.0
+    mk = _Masks(p, 5)
+    served = []
+
+    def patched(self, inp):                                    # inp [T, B, C]; the masks are kept in the HIP layout [B, C, T]
+        m = mk('nn.Dropout', (inp.shape[1], inp.shape[2], inp.shape[0]))
+        served.append(m)
+        return inp * m.permute(2, 0, 1).to(inp.dtype) / (1.0 - p)
+    orig = torch.nn.Dropout.forward
+    torch.nn.Dropout.forward = patched
+    try:
+        want = layer(x)
+    finally:
+        torch.nn.Dropout.forward = orig
+    it = iter(served)
+    got = O.encoder_layer_dropout(layer, x, p, lambda name, shape: torch.full(shape, 1.0 - p) if name == 'attn' else next(it))
+    assert len(served) == 3 and _rel(got, want) < 1e-6
+
+
 def _rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
@@ -56,6 +105,158 @@ def test_layernorm_and_attention_kernels(B, D, T):
 
 
 @pytest.mark.gpu
+def test_dropout_kernels_with_injected_masks():
+    """LayerNorm(dropout(x) + r), attention with dropout on the probabilities and the plain dropout op, forward and
+    backward, against the same arithmetic in torch with the same keep flags."""
+    from dynmm_amd import ops_seq as S
+    torch.manual_seed(0)
+    B, D, T, H, p = 3, 60, 50, 5, 0.2
+    x = torch.randn(B, D, T, requires_grad=True)
+    r = torch.randn(B, D, T, requires_grad=True)
+    gamma = (torch.rand(D) + 0.5).requires_grad_(True)
+    beta = torch.randn(D).requires_grad_(True)
+    g = torch.randn(B, D, T)
+    mk = _Masks(p, 11, 'cuda')
+    S.MASKS = mk
+    try:
+        xc, rc, gc, bc = (t.detach().cuda().requires_grad_(True) for t in (x, r, gamma, beta))
+        y = S.layernorm_bdt(xc, gc, bc, 1e-5, residual=rc, drop=(p, 7, 'dropout1'))
+        y.backward(g.cuda())
+        m = _Masks(p, 11)('dropout1', (B, D, T)).float() / (1 - p)
+        y_ref = torch.nn.functional.layer_norm((x * m + r).permute(0, 2, 1), (D,), gamma, beta, 1e-5).permute(0, 2, 1)
+        y_ref.backward(g)
+        assert _rel(y, y_ref) < 1e-5
+        for a, b in ((xc, x), (rc, r), (gc, gamma), (bc, beta)):
+            assert _rel(a.grad, b.grad) < 2e-5
+        assert float((xc.grad == 0).float().mean()) > 0.5 * p           # dropped elements receive no gradient
+        # attention
+        qkv = torch.randn(B, 3 * D, T, requires_grad=True)
+        qc = qkv.detach().cuda().requires_grad_(True)
+        mk.n = 1
+        out = S.mha_core(qc, H, drop=(p, 8, 'attn'))
+        out.backward(g.cuda())
+        mg = _Masks(p, 11); mg.n = 1
+        ma = mg('attn', (B * H, T, T)).float() / (1 - p)
+        q, k, v = (t.reshape(B * H, D // H, T).transpose(1, 2) for t in qkv.split(D, dim=1))       # [B*H, T, dh]
+        att = torch.softmax(q @ k.transpose(1, 2) / (D // H) ** 0.5, dim=-1) * ma
+        ref = (att @ v).transpose(1, 2).reshape(B, D, T)
+        ref.backward(g)
+        assert _rel(out, ref) < 1e-5 and _rel(qc.grad, qkv.grad) < 2e-5
+        # plain op
+        x2 = x.detach().cuda().requires_grad_(True)
+        mk.n = 2
+        y2 = S.dropout_bdt(x2, p, 9, 'dropout')
+        y2.backward(g.cuda())
+        mg.n = 2
+        m2 = mg('dropout', (B, D, T)).float() / (1 - p)
+        assert _rel(y2, x.detach() * m2) < 1e-6 and _rel(x2.grad, g * m2) < 1e-6
+    finally:
+        S.MASKS = None
+
+
+@pytest.mark.gpu
+def test_dropout_generator_statistics_and_replay():
+    """The Philox path: keep rate, forward/backward consistency (the backward regenerates the forward's decisions), new
+    decisions after advance_dropout_step, identical decisions for identical (seed, site, step), different sites differ."""
+    from dynmm_amd import ops, ops_seq as S
+    ops.manual_seed(1234)
+    p = 0.1
+    x = torch.randn(8, 120, 50, device='cuda').abs() + 0.1
+
+    def keep(site):
+        xi = x.clone().requires_grad_(True)
+        y = S.dropout_bdt(xi, p, site, 'dropout')
+        y.backward(torch.ones_like(y))
+        k = (y.detach() != 0)
+        assert torch.equal(xi.grad != 0, k)                                     # same decisions in the backward
+        assert _rel(y.detach()[k], (x / (1 - p))[k]) < 1e-6
+        return k
+    k0 = keep(3)
+    assert abs(k0.float().mean().item() - (1 - p)) < 0.005                      # 48 000 draws: sigma = 0.0014
+    assert torch.equal(keep(3), k0)
+    k1 = keep(4)
+    assert 0.7 < (k1 == k0).float().mean().item() < 0.9                         # independent: agree on 0.82 of the elements
+    S.advance_dropout_step(x.device)
+    k2 = keep(3)
+    assert 0.7 < (k2 == k0).float().mean().item() < 0.9
+    # along each axis the decisions are not constant (a wrong index would repeat rows or columns)
+    assert k0.float().mean((0, 1)).std().item() > 0 and k0.float().mean((1, 2)).std().item() > 0
+    # attention and LayerNorm sites draw from the same generator
+    qkv = torch.randn(4, 180, 50, device='cuda')
+    o_eval = S.mha_core(qkv, 5)
+    o_drop = S.mha_core(qkv, 5, drop=(p, 5, 'attn'))
+    assert 0.01 < _rel(o_drop, o_eval) < 2.0
+    g = torch.ones(120, device='cuda')
+    y_a = S.layernorm_bdt(x, g, g, 1e-5, residual=x, drop=(p, 6, 'dropout1'))
+    y_b = S.layernorm_bdt(x, g, g, 1e-5, residual=x, drop=(p, 6, 'dropout1'))
+    assert torch.equal(y_a, y_b) and not torch.equal(y_a, S.layernorm_bdt(x, g, g, 1e-5, residual=x))
+
+
+@pytest.mark.gpu
+def test_dynmm_affect_training_mode_matches_oracle_with_injected_dropout():
+    """DynMMNetV2 in training mode (p = 0.1 at 4 sites x 5 layers x 5 transformers = 100 dropout sites), keep flags injected on
+    both sides: forward, objective and every gradient."""
+    from dynmm_amd import ops_seq as S
+    from dynmm_amd.nn import affect as A
+    from oracle import affect_oracle as O
+    ref = O.fill_(O.DynMMNetV2(0.7, False), seed=1)
+    mine = A.DynMMNetV2(0.7, False)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda().train()
+    inputs, y = O.synth_batch(4, seed=3)
+    mr, mh = _Masks(0.1, 21), _Masks(0.1, 21, 'cuda')
+    O.Transformer.dropout_masks = (0.1, mr)
+    S.MASKS = mh
+    try:
+        out_r, aux_r, _ = ref(inputs)
+        tot_r, _ = O.train_objective(out_r, aux_r, y, 0.3)
+        tot_r.backward()
+        out, aux = mine([[x.cuda() for x in inputs[0]], inputs[1]])
+        tot = (out - y.cuda()).abs().mean() + 0.3 * aux
+        tot.backward()
+        torch.cuda.synchronize()
+    finally:
+        O.Transformer.dropout_masks = None
+        S.MASKS = None
+    assert mr.n == mh.n == 100 and mr.names == mh.names
+    assert _rel(out, out_r) < 2e-4 and abs(tot.item() - tot_r.item()) < 1e-5
+    gr = dict(ref.named_parameters())
+    errs = {}
+    for n, p_ in mine.named_parameters():
+        if gr[n].grad is None or gr[n].grad.abs().max() < 1e-9:
+            continue
+        errs[n] = ((p_.grad.cpu().double() - gr[n].grad.double()).norm() / gr[n].grad.double().norm()).item()
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 2e-3, (worst, errs[worst])
+    assert np.median(list(errs.values())) < 2e-4
+    # and it differs from the eval-mode arithmetic (dropout really acted)
+    mine.eval()
+    with torch.no_grad():
+        out_e, _ = mine([[x.cuda() for x in inputs[0]], inputs[1]])
+    assert _rel(out_e, out_r) > 1e-3
+
+
+@pytest.mark.gpu
+def test_affect_train_step_draws_new_masks_every_replay():
+    """AffectTrainStep in training mode under hipGraph replay: the captured step must not reuse its dropout decisions —
+    with lr = 0 (weights frozen) two replays on the same batch give different losses, and re-seeding reproduces the first."""
+    from dynmm_amd import ops, ops_seq as S
+    from dynmm_amd.nn import affect as A
+    from oracle import affect_oracle as O
+    mine = A.DynMMNetV2(1.0, False)
+    mine.load_state_dict(O.fill_(O.DynMMNetV2(1.0, False), seed=2).state_dict())
+    mine = mine.cuda().train()
+    inputs, y = O.synth_batch(5, seed=10)
+    inputs = [[x.cuda() for x in inputs[0]], inputs[1]]
+    step = A.AffectTrainStep(mine, lr=0.0, weight_decay=0.0, lossw=0.2, use_graph=True)
+    ops.manual_seed(77)
+    S.dropout_step(inputs[0][0].device).zero_()
+    losses = [step(inputs, y.cuda())['total'].item() for _ in range(3)]
+    assert len({round(v, 7) for v in losses}) == 3, losses
+    step.opt.check_finite()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kind,hard', [('v2', False), ('v2', True), ('v1', False)])
 def test_dynmm_affect_model_matches_oracle(kind, hard):
     """Whole model, eval-mode arithmetic (dropout = 0), forward and every trainable gradient, HIP vs oracle."""
@@ -64,7 +265,7 @@ def test_dynmm_affect_model_matches_oracle(kind, hard):
     ref = O.fill_(O.DynMMNetV2(0.7, hard) if kind == 'v2' else O.DynMMNet(0.7, hard), seed=1)
     mine = (A.DynMMNetV2(0.7, hard) if kind == 'v2' else A.DynMMNet(0.7, hard, freeze=False))
     mine.load_state_dict(ref.state_dict())
-    mine = mine.cuda()
+    mine = mine.cuda().eval()                # eval(): no dropout, like the oracle's dropout=0 layers
     inputs, y = O.synth_batch(6, seed=3)
     out_r, aux_r, w_r = ref(inputs)
     tot_r, _ = O.train_objective(out_r, aux_r, y, 0.3)
@@ -96,7 +297,7 @@ def test_affect_train_step_matches_torch_adamw():
         ref = O.fill_(O.DynMMNetV2(1.0, False), seed=2)
         mine = A.DynMMNetV2(1.0, False, freeze=freeze)
         mine.load_state_dict(ref.state_dict())
-        mine = mine.cuda()
+        mine = mine.cuda().eval()            # the optimiser arithmetic is what is compared here: dropout off on both sides
         if freeze:
             for n, p in ref.named_parameters():
                 p.requires_grad = n.startswith('gate')
