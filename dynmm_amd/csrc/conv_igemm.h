@@ -28,6 +28,8 @@ struct IgemmArgs {
     float* ws;             // operand-ring kernels, K split over `ksplit` workgroups per tile: partial accumulator tiles
     unsigned* flags;       //   [tiles][256 threads][accumulators] and one arrival counter per tile (zeroed by the launcher)
     int ksplit;            // 1: no split
+    float* stats;          // operand-ring forward kernels: per pixel tile and channel, sum and sum of squares of the OUTPUT
+                           //   [n_pix_tiles][2][Co] (BatchNorm batch statistics without a pass over y), or nullptr
     int subpix;            // DGRAD with stride > 1 and Ho % SH == Wo % SW == 0: output pixels are enumerated
                            // parity class by parity class (see pix_decode), so a tile is (mostly) class-pure
 };
@@ -101,5 +103,7 @@ bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st, void* workspace =
 // K-split the launcher would use for this geometry given a workspace (1 = none) and the bytes it needs
 int igemm_v5_ksplit(const IgemmArgs& a, bool dgrad);
 size_t igemm_v5_workspace_bytes(const IgemmArgs& a, bool dgrad);
+// pixel tiles of the launch = rows of the [tiles][2][Co] statistics partials (IgemmArgs::stats)
+int igemm_v5_pix_tiles(const IgemmArgs& a);
 
 }  // namespace dynmm

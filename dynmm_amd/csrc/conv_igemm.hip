@@ -1429,6 +1429,38 @@ extern "C" int dynmm_conv2d_fwd_ws(const float* x, const float* x2, const float*
     return launch_igemm<false>(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+static void stats_args(IgemmArgs& a, const dynmm_conv_geom* g) {
+    a.N = g->N; a.Ci = g->Ci; a.H = g->H; a.W = g->W;
+    a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo;
+    a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    a.c_in_split = g->c_split; a.c_out_split = g->Co; a.act = DYNMM_ACT_NONE;
+}
+
+extern "C" int dynmm_conv2d_stats_tiles(const dynmm_conv_geom* g) {
+    if (!geom_ok(g) || g->c_split < g->Ci) return 0;
+    IgemmArgs a{};
+    stats_args(a, g);
+    a.x = a.wp = reinterpret_cast<const float*>(uintptr_t(4096));       // (alignment is checked again at the call)
+    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, false)) return 0;
+    return igemm_v5_pix_tiles(a);
+}
+
+extern "C" int dynmm_conv2d_fwd_stats(const float* x, const float* wp_fwd, const float* bias, float* y, float* stats,
+                                      size_t stats_floats, const dynmm_conv_geom* g, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !wp_fwd || !y || !stats || !geom_ok(g) || g->c_split < g->Ci) return DYNMM_EINVAL;
+    IgemmArgs a{};
+    stats_args(a, g);
+    a.x = x; a.wp = wp_fwd; a.shift = bias; a.y = y;
+    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, false)) return DYNMM_EUNSUPPORTED;
+    if (stats_floats < (size_t)igemm_v5_pix_tiles(a) * 2 * (size_t)g->Co) return DYNMM_EWORKSPACE;
+    a.stats = stats;
+    if (!launch_igemm_v5(a, false, (hipStream_t)stream, workspace, workspace_bytes)) return DYNMM_EUNSUPPORTED;
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
 extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
                                   const float* accum, float* dx, float* dx2,
                                   const dynmm_conv_geom* g, void* stream) {

@@ -31,6 +31,19 @@ namespace dynmm {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with it): quad butterflies, then the two mirrors
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_row_sum16(float v) {
+    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);      // row_half_mirror
+    v = dpp_add<0x140>(v);      // row_mirror
+    return v;
+}
+
 template <int TCO, int TPIX, int WCO, int WPIX, int KW, bool DGRAD, int SA, int SB>
 __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a) {
     // ring depths: SA weight stages; SB activation stages (KW = 3: two stages of three K-steps each; KW = 1: one per step)
@@ -390,12 +403,20 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
             v[4 * q + 3] = acc[mi][ni][4 * j4 + 3] * sc.w + sh.w;
         }
     };
+    // BatchNorm statistics of the output (forward, a.stats): every 8-value group is summed over the 16 lanes (= pixels) of its
+    // DPP row right after it is final, the row sums meet in the (dead) activation ring, 128 | 64 threads add the rows of the
+    // tile and write one partial per channel — the finalise kernel (norm.hip) adds the tiles in a fixed order.
+    const bool want_stats = !DGRAD && a.stats != nullptr;
+    constexpr int STAT_PARTS = WAVES_PIX * MPIX * 2;
+    float* const st_lds = Bs;                                   // [2][STAT_PARTS][TCO]
+    static_assert(2 * STAT_PARTS * TCO <= SB * B_STAGE, "statistics staging fits the activation ring");
 #pragma unroll
     for (int ni = 0; ni < MPIX; ++ni) {
         const int m = pix0 + wave_pix * WPIX + ni * 32 + l31;
-        if (m >= a.M) continue;
-        const unsigned n = (unsigned)(m / HoWo);
-        const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
+        const bool valid = m < a.M;
+        if (!valid && !want_stats) continue;
+        const unsigned n = (unsigned)((valid ? m : 0) / HoWo);
+        const unsigned rem = (unsigned)(valid ? m : 0) - n * (unsigned)HoWo;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
             const int cl0 = wave_co * WCO + mi * 32 + 4 * khalf;          // tile-local channel of j = 0
@@ -404,27 +425,56 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
             for (int h = 0; h < 2; ++h) {
                 float v[8], rv[8], mv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { mv[e] = 1.f; rv[e] = 0.f; }
-                if (has_mask) {
+                for (int e = 0; e < 8; ++e) { mv[e] = 1.f; rv[e] = 0.f; v[e] = 0.f; }
+                if (valid) {
+                    if (has_mask) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            mv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) +
+                                                                    (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            rv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) +
+                                                                    (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
+                    }
+                    scaled(v, mi, ni, cl0, h);
+                    finish(v, rv, mv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        mv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) +
-                                                                (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
+                                                  (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
                 }
-                if (has_res) {
+                if (want_stats) {
+                    const int part = ((wave_pix * MPIX + ni) * 2 + (l31 >> 4));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        rv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) +
-                                                                (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
+                    for (int e = 0; e < 8; ++e) {
+                        const float r1 = dpp_row_sum16(v[e]);
+                        const float r2 = dpp_row_sum16(v[e] * v[e]);
+                        if ((l31 & 15) == 0) {
+                            const int ch = cl0 + (e & 3) + 8 * (2 * h + (e >> 2));
+                            st_lds[part * TCO + ch] = r1;
+                            st_lds[(STAT_PARTS + part) * TCO + ch] = r2;
+                        }
+                    }
                 }
-                scaled(v, mi, ni, cl0, h);
-                finish(v, rv, mv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
-                                              (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (t < TCO) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int pt = 0; pt < STAT_PARTS; ++pt) {
+                s1 += st_lds[pt * TCO + t];
+                s2 += st_lds[(STAT_PARTS + pt) * TCO + t];
+            }
+            float* dst = a.stats + (size_t)(pix0 / TPIX) * 2 * a.Co + co0 + t;
+            dst[0] = s1;
+            dst[a.Co] = s2;
         }
     }
 #ifdef DYNMM_TRACE
@@ -467,6 +517,12 @@ static void v5_tiles(const IgemmArgs& a, int& tco, int& tpix, int& tiles) {
     tco = (a.Co % 128 == 0) ? 128 : 64;
     tpix = tco == 128 ? 64 : 128;
     tiles = (a.Co / tco) * ceil_div(a.N * a.Ho * a.Wo, tpix);
+}
+
+int igemm_v5_pix_tiles(const IgemmArgs& a) {
+    int tco, tpix, tiles;
+    v5_tiles(a, tco, tpix, tiles);
+    return ceil_div(a.N * a.Ho * a.Wo, tpix);
 }
 
 // Long reductions on grids that leave most CUs with fewer than three workgroups (C = 512 at 15x20, compacted depth stages)

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libdynmm_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+DYNMM_OK, DYNMM_EINVAL, DYNMM_EUNSUPPORTED, DYNMM_EWORKSPACE = 0, -1, -2, -3
 ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2}
 
 c_f = C.c_void_p       # device pointers travel as void* (tensor.data_ptr() or None)
@@ -55,6 +56,9 @@ SIGNATURES = {
     'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv2d_wgrad_groupable': (c_i, [_GP]),
     'dynmm_conv2d_wgrad_variant': (c_i, [_GP]),
+    'dynmm_conv2d_stats_tiles': (c_i, [_GP]),
+    'dynmm_conv2d_fwd_stats': (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f, c_sz, c_f]),
+    'dynmm_bn_stats_from_partials': (c_i, [c_f, c_i, c_i, c_f, c_i, c_f]),
     'dynmm_conv2d_wgrad_group_workspace_bytes': (c_sz, [_GP, c_i]),
     'dynmm_conv2d_wgrad_group': (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv_bf16x3_eligible': (c_i, [_GP, c_i]),

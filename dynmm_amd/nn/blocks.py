@@ -13,13 +13,14 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False,
     """act(BN(conv(x|x2)) + residual).
 
     inference (eval, no grad): ONE kernel — BN folded into the implicit-GEMM epilogue.
-    training: conv(+bias) kernel, batch statistics pass, normalise(+residual+act) pass.
+    training: conv(+bias) kernel — which also leaves the per-channel sums of its output behind where it is one of the
+    operand-ring kernels, else a batch statistics pass follows —, normalise(+residual+act) pass.
     """
     if not bn.training and not torch.is_grad_enabled():
         return ops.conv2d_fused_eval(x, conv.weight, conv.bias, bn, act, residual,
                                      conv.stride, conv.padding, x2)
     y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input,
-                   link=conv_link)
+                   link=conv_link, bn_stats=bn.training)
     return ops.batch_norm_act(y, bn, act, residual, link=res_link)
 
 

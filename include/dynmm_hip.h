@@ -168,6 +168,17 @@ int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbia
  * hands in a buffer that is already zero (e.g. a slice of an arena cleared once per step) and the memset
  * launch is skipped. */
 int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, int sums_are_zero, void* stream);
+/* BatchNorm batch statistics WITHOUT a pass over the convolution's output (training, conv -> BN): the operand-ring forward
+ * kernel sums its output tile per channel in the epilogue (y = conv + bias, no activation) and leaves
+ * stats[tile][0][c] = sum, stats[tile][1][c] = sum of squares; dynmm_bn_stats_from_partials adds the tiles (fp64 atomics per
+ * 64-tile group, like dynmm_bn_stats) into the `sums` array dynmm_bn_apply reads — in place of dynmm_bn_stats.  dynmm_conv2d_stats_tiles: rows of
+ * `stats` for this geometry, 0 when the geometry is not served by the operand-ring kernels (then: dynmm_conv2d_fwd +
+ * dynmm_bn_stats); dynmm_conv2d_fwd_stats returns DYNMM_EUNSUPPORTED when the tensors' alignment rules it out at the call. */
+int dynmm_conv2d_stats_tiles(const dynmm_conv_geom* g);
+int dynmm_conv2d_fwd_stats(const float* x, const float* wp_fwd, const float* bias, float* y, float* stats,
+                           size_t stats_floats, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int dynmm_bn_stats_from_partials(const float* partials, int tiles, int C, double* sums, int sums_are_zero, void* stream);
 /* y = act( (x-mean)*invstd*gamma + beta + residual ).
  * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
  *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and

@@ -102,7 +102,8 @@ def test_two_train_steps_match_reference(golden_dir, use_graph):
     # two ill-conditioned updates + momentum; the SE excitation biases are the most sensitive tensors
     # (fp32-vs-fp64 oracle gradient error ~1e-1 on them) and get a wider band
     tol = np.array([6e-2 if 'se_layer' in nm else 1e-2 for nm in names])
-    assert (rel < tol).all(), [(names[i], norms[i], g['param_norms'][i]) for i in worst]
+    bad = np.nonzero(rel >= tol)[0]
+    assert bad.size == 0, [(names[i], norms[i], g['param_norms'][i], rel[i]) for i in list(bad) + list(worst)]
 
 
 @pytest.mark.gpu
