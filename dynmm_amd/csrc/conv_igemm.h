@@ -28,8 +28,13 @@ struct IgemmArgs {
     float* ws;             // operand-ring kernels, K split over `ksplit` workgroups per tile: partial accumulator tiles
     unsigned* flags;       //   [tiles][256 threads][accumulators] and one arrival counter per tile (zeroed by the launcher)
     int ksplit;            // 1: no split
-    float* stats;          // operand-ring forward kernels: per pixel tile and channel, sum and sum of squares of the OUTPUT
-                           //   [n_pix_tiles][2][Co] (BatchNorm batch statistics without a pass over y), or nullptr
+    float* stats;          // operand-ring kernels, [n_pix_tiles][2][Co] per pixel tile and channel, or nullptr.  Forward: sum and
+                           //   sum of squares of the OUTPUT (BatchNorm batch statistics without a pass over y).  Input gradient:
+                           //   sum of the OUTPUT g and of g * xhat, xhat = (bn_x - bn_mean[c]) * bn_invstd[c] (the two reductions
+                           //   of the BatchNorm backward whose output this convolution consumes, without a pass over g and x)
+    const float* bn_x;     //   like y: the BatchNorm's input
+    const float* bn_mean;  //   [Co]
+    const float* bn_invstd;
     int subpix;            // DGRAD with stride > 1 and Ho % SH == Wo % SW == 0: output pixels are enumerated
                            // parity class by parity class (see pix_decode), so a tile is (mostly) class-pure
 };

@@ -1484,6 +1484,41 @@ extern "C" int dynmm_conv2d_dgrad_ws(const float* dy, const float* wp_dgrad, con
     return launch_igemm<true>(a, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+static void dgrad_args(IgemmArgs& a, const dynmm_conv_geom* g) {
+    // the GEMM's input is dy [N,Co,Ho,Wo], its output dx [N,Ci,H,W]
+    a.N = g->N; a.Ci = g->Co; a.H = g->Ho; a.W = g->Wo;
+    a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W;
+    a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
+    a.c_in_split = g->Co; a.c_out_split = g->c_split; a.act = DYNMM_ACT_NONE;
+}
+
+extern "C" int dynmm_conv2d_dgrad_stats_tiles(const dynmm_conv_geom* g) {
+    if (!geom_ok(g) || g->c_split < g->Ci) return 0;
+    IgemmArgs a{};
+    dgrad_args(a, g);
+    a.x = a.wp = reinterpret_cast<const float*>(uintptr_t(4096));       // (alignment is checked again at the call)
+    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, true)) return 0;
+    return igemm_v5_pix_tiles(a);
+}
+
+extern "C" int dynmm_conv2d_dgrad_bnstats(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
+                                          float* dx, const float* bn_x, const float* bn_mean, const float* bn_invstd,
+                                          float* stats, size_t stats_floats, const dynmm_conv_geom* g, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!dy || !wp_dgrad || !dx || !bn_x || !bn_mean || !bn_invstd || !stats || !geom_ok(g) || g->c_split < g->Ci)
+        return DYNMM_EINVAL;
+    IgemmArgs a{};
+    dgrad_args(a, g);
+    a.x = dy; a.wp = wp_dgrad; a.mask = mask; a.residual = accum; a.y = dx;
+    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, true)) return DYNMM_EUNSUPPORTED;
+    if (stats_floats < (size_t)igemm_v5_pix_tiles(a) * 2 * (size_t)g->Ci) return DYNMM_EWORKSPACE;
+    a.stats = stats; a.bn_x = bn_x; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+    if (!launch_igemm_v5(a, true, (hipStream_t)stream, workspace, workspace_bytes)) return DYNMM_EUNSUPPORTED;
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
 static void launch_wgrad_generic(const WgradArgs& a, const WgradGroup& grp, const WgradPlan& p, dim3 grid, bool dual,
                                  bool fast, hipStream_t st) {
 #define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \

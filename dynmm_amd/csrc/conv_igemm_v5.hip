@@ -406,7 +406,17 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     // BatchNorm statistics of the output (forward, a.stats): every 8-value group is summed over the 16 lanes (= pixels) of its
     // DPP row right after it is final, the row sums meet in the (dead) activation ring, 128 | 64 threads add the rows of the
     // tile and write one partial per channel — the finalise kernel (norm.hip) adds the tiles in a fixed order.
-    const bool want_stats = !DGRAD && a.stats != nullptr;
+    const bool want_stats = a.stats != nullptr;
+    float* const mu_lds = As + 2 * TCO;                         // input gradient: BatchNorm mean / invstd of the tile's channels
+    float* const is_lds = As + 3 * TCO;
+    const float* __restrict__ bnx_p = a.bn_x;
+    if (DGRAD && want_stats) {
+        for (int i = t; i < TCO; i += 256) {
+            mu_lds[i] = a.bn_mean[co0 + i];
+            is_lds[i] = a.bn_invstd[co0 + i];
+        }
+        __syncthreads();
+    }
     constexpr int STAT_PARTS = WAVES_PIX * MPIX * 2;
     float* const st_lds = Bs;                                   // [2][STAT_PARTS][TCO]
     static_assert(2 * STAT_PARTS * TCO <= SB * B_STAGE, "statistics staging fits the activation ring");
@@ -448,10 +458,22 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
                 }
                 if (want_stats) {
                     const int part = ((wave_pix * MPIX + ni) * 2 + (l31 >> 4));
+                    float w[8];                                  // second factor: the value itself, or xhat of the BatchNorm input
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = v[e];
+                    if (DGRAD) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int ch = cl0 + (e & 3) + 8 * (2 * h + (e >> 2));
+                            const float xv = valid ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bnx_p) +
+                                                         (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) : 0.f;
+                            w[e] = (xv - mu_lds[ch]) * is_lds[ch];
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float r1 = dpp_row_sum16(v[e]);
-                        const float r2 = dpp_row_sum16(v[e] * v[e]);
+                        const float r2 = dpp_row_sum16(v[e] * w[e]);
                         if ((l31 & 15) == 0) {
                             const int ch = cl0 + (e & 3) + 8 * (2 * h + (e >> 2));
                             st_lds[part * TCO + ch] = r1;

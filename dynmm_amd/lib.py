@@ -58,6 +58,8 @@ SIGNATURES = {
     'dynmm_conv2d_wgrad_variant': (c_i, [_GP]),
     'dynmm_conv2d_stats_tiles': (c_i, [_GP]),
     'dynmm_conv2d_fwd_stats': (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f, c_sz, c_f]),
+    'dynmm_conv2d_dgrad_stats_tiles': (c_i, [_GP]),
+    'dynmm_conv2d_dgrad_bnstats': (c_i, [c_f] * 9 + [c_sz, _GP, c_f, c_sz, c_f]),
     'dynmm_bn_stats_from_partials': (c_i, [c_f, c_i, c_i, c_f, c_i, c_f]),
     'dynmm_conv2d_wgrad_group_workspace_bytes': (c_sz, [_GP, c_i]),
     'dynmm_conv2d_wgrad_group': (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),

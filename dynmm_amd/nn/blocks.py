@@ -63,8 +63,8 @@ class NonBottleneck1D(nn.Module):
         c = self.conv3x1_1
         y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link)
         y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd)
-        c = self.conv3x1_2
-        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd)
+        c = self.conv3x1_2            # the only consumer of relu(bn1(.)): its dgrad also does bn1's backward reductions
+        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, bn_consumer=fuse_bwd)
         idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
         return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link)
 

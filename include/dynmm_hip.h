@@ -179,6 +179,15 @@ int dynmm_conv2d_fwd_stats(const float* x, const float* wp_fwd, const float* bia
                            size_t stats_floats, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
                            void* stream);
 int dynmm_bn_stats_from_partials(const float* partials, int tiles, int C, double* sums, int sums_are_zero, void* stream);
+/* The same for the BatchNorm BACKWARD (training, BN+ReLU -> conv with the ReLU mask applied in that conv's input-gradient
+ * epilogue): the input-gradient kernel produces g = d(loss)/d(BN pre-activation) and, per pixel tile and channel,
+ * stats[tile][0][c] = sum g, stats[tile][1][c] = sum g * (bn_x - bn_mean[c]) * bn_invstd[c]; dynmm_bn_stats_from_partials turns
+ * them into the `sums` dynmm_bn_bwd_apply reads — in place of dynmm_bn_bwd_reduce's pass over g and x. */
+int dynmm_conv2d_dgrad_stats_tiles(const dynmm_conv_geom* g);
+int dynmm_conv2d_dgrad_bnstats(const float* dy, const float* wp_dgrad, const float* mask, const float* accum, float* dx,
+                               const float* bn_x, const float* bn_mean, const float* bn_invstd, float* stats,
+                               size_t stats_floats, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
+                               void* stream);
 /* y = act( (x-mean)*invstd*gamma + beta + residual ).
  * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
  *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and

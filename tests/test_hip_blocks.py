@@ -214,3 +214,54 @@ def _conv_bn_statistics_case(shape, C, ops, conv_bn_act):
     assert a[6] == b[6] == 1
     for i in range(6):
         assert rel(a[i], b[i]) < (2e-5 if i >= 3 else 5e-6), i
+
+
+@pytest.mark.parametrize('shape', [(4, 128, 30, 40), (3, 64, 15, 20), (2, 256, 12, 16)])
+def test_bn_backward_reductions_from_the_dgrad_epilogue(shape):
+    """NonBottleneck1D, training: the input-gradient kernel of conv3x1_2 also produces the two reductions of bn1's backward
+    (sum g, sum g*xhat per pixel tile; ops.BNLink) — every gradient against the same block with bn1's own reduction pass
+    (the two summation orders differ below 1e-6; nothing downstream of them takes a ReLU decision), and the link was used."""
+    from dynmm_amd import ops
+    from dynmm_amd.nn.blocks import NonBottleneck1D
+    N, Cc, H, W = shape
+    torch.manual_seed(5)
+    blk = NonBottleneck1D(Cc, Cc)
+    synth.fill_state_dict(blk.state_dict(), seed=4)
+    blk = blk.cuda().train()
+    x = torch.randn(N, Cc, H, W, device='cuda')
+    gy = torch.randn(N, Cc, H, W, device='cuda')
+    used = []
+    orig = ops._lib().dynmm_conv2d_dgrad_bnstats
+    outs = []
+    default = ops.BN_BWD_FUSE
+    for fused in (True, False):
+        ops.BN_BWD_FUSE = fused                    # opt-in path (default: bn1's own reduction pass)
+        try:
+            blk.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            blk(xi).backward(gy)
+            outs.append([xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+        finally:
+            ops.BN_BWD_FUSE = default
+    names = ['dx'] + [n for n, _ in blk.named_parameters()]
+    gmax = max(t.abs().max().item() for t in outs[1][1:])
+    for n, a, b in zip(names, *outs):
+        if b.abs().max().item() < 1e-5 * gmax:
+            continue                              # analytically-zero gradients (conv bias in front of a train-mode BatchNorm)
+        assert rel(a, b) < 2e-5, n
+    # the fused run really used the link: bn1's output carries it, conv3x1_2's backward fills it, bn1's backward empties it
+    seen = []
+    orig = ops._BatchNormAct.backward
+
+    def spy(ctx, g_):
+        seen.append(ctx.bnlink is not None and ctx.bnlink.partials is not None)
+        return orig(ctx, g_)
+    ops._BatchNormAct.backward = staticmethod(spy)
+    ops.BN_BWD_FUSE = True
+    try:
+        xi = x.clone().requires_grad_(True)
+        blk(xi).backward(gy)
+    finally:
+        ops._BatchNormAct.backward = staticmethod(orig)
+        ops.BN_BWD_FUSE = default
+    assert seen == [False, True], seen            # bn2 (residual + ReLU: own reduction), then bn1 (from the epilogue)
