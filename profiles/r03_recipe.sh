@@ -15,7 +15,7 @@ cd $R
 python profiles/summarize_rocpd.py $O/single/bench_results.db $O/single.md > /dev/null
 python profiles/summarize_rocpd.py $O/multi/bench_results.db $O/multi.md > /dev/null
 python profiles/summarize_rocpd.py $O/affect/aff_results.db $O/affect.md > /dev/null
-python profiles/summarize_pmc.py $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv $O/pmc_sq/p_counter_collection.csv $O/pmc.md $O/pmc.json conv_igemm 4 > $O/pmc_summary.log 2>&1
+python profiles/summarize_pmc.py $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv $O/pmc_sq/p_counter_collection.csv $O/pmc.md $O/pmc.json conv_ 4 > $O/pmc_summary.log 2>&1
 rm -rf $O/*/*.db $O/pmc_*/p_*.csv    # keep the merge-back small: summaries only
 tail -1 $O/single_stdout.log | cut -c1-300
 head -30 $O/single.md | cut -c1-160
