@@ -6,6 +6,12 @@
 
 #include "dynmm_hip.h"
 
+// These kernels are written for one target: 160 KB of LDS per workgroup (mha_bwd_kernel<32,false> alone declares 66 KB),
+// global_load_lds_dwordx4, the gfx950 MFMA set.  Fail at compile time, not at the first launch, on anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdynmm_hip is gfx950 (MI355X) code: build with --offload-arch=gfx950"
+#endif
+
 #define DYNMM_LAUNCH_CHECK()                                   \
     do {                                                       \
         hipError_t e__ = hipGetLastError();                    \

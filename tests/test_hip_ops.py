@@ -128,6 +128,32 @@ def test_conv2d_fwd_bwd(ops, case):
         assert rel(xg.grad, xr.grad) < GTOL
 
 
+@pytest.mark.parametrize('k,p', [((1, 3), (0, 1)), ((3, 1), (1, 0))])
+def test_conv2d_tensors_off_the_16_byte_grid(ops, k, p):
+    """The operand-ring kernels and the three-tap weight-gradient kernel move 16 bytes per lane; a contiguous tensor that starts
+    4 bytes into its storage (a view of a larger buffer) must take the kernels that do not, with the same results — forward,
+    input gradient (gy misaligned), weight / bias gradient (x and gy misaligned)."""
+    N, Ci, H, W, Co = 2, 128, 12, 32, 128
+    x, w, b = rnd(N, Ci, H, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * 3) ** -0.5), rnd(Co, seed=3, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.conv2d(xr, wr, br, 1, p)
+    gy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+
+    def off_grid(t):
+        buf = torch.empty(t.numel() + 1, device='cuda')
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.is_contiguous() and v.data_ptr() % 16 == 4
+        return v
+    xg = off_grid(x).requires_grad_(True)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, 1, p)
+    assert rel(y, y_ref) < TOL
+    y.backward(off_grid(gy))
+    assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL and rel(xg.grad, xr.grad) < GTOL
+
+
 def test_conv2d_dual_input(ops):
     """GlobalGate's first conv: cat(rgb, depth) is never materialised."""
     a, b2 = rnd(2, 64, 24, 32, seed=5), rnd(2, 64, 24, 32, seed=6)
