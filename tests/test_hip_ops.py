@@ -154,6 +154,45 @@ def test_conv2d_tensors_off_the_16_byte_grid(ops, k, p):
     assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL and rel(xg.grad, xr.grad) < GTOL
 
 
+def test_conv2d_random_shapes_across_kernel_families(ops):
+    """40 seeded random geometries around the eligibility edges of the kernel families (operand-ring forward / input gradient:
+    stride 1, same padding, Ci % 32 == 0 >= 64, Co % 64 == 0, W % 4 == 0; three-tap weight gradient: W >= 16, Ci, Co % 64 == 0;
+    everything else: the round-2 tiles), each against torch in fp64: forward, input, weight and bias gradients."""
+    rng = np.random.default_rng(20260928)
+    done = set()
+    for it in range(40):
+        k = [(1, 3), (3, 1), (3, 3), (1, 1)][int(rng.integers(4))]
+        ci = int(rng.choice([32, 64, 96, 128, 192]))
+        co = int(rng.choice([40, 64, 72, 128, 192]))
+        n = int(rng.integers(1, 5))
+        h = int(rng.integers(3, 14))
+        w_ = int(rng.choice([8, 12, 16, 20, 22, 24, 36]))
+        stride = (1, 1) if rng.random() < 0.8 else ((2, 1) if k[0] == 3 else (1, 2) if k[1] == 3 else (2, 2))
+        pad = (k[0] // 2, k[1] // 2)
+        bias = bool(rng.integers(2))
+        x = torch.from_numpy(rng.standard_normal((n, ci, h, w_)).astype(np.float32))
+        w = torch.from_numpy((rng.standard_normal((co, ci, *k)) * (ci * k[0] * k[1]) ** -0.5).astype(np.float32))
+        b = torch.from_numpy((0.1 * rng.standard_normal(co)).astype(np.float32)) if bias else None
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if bias else None
+        y_ref = F.conv2d(xr, wr, br, stride, pad)
+        gy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)).astype(np.float32))
+        y_ref.backward(gy.double())
+        xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+        bg = b.cuda().requires_grad_(True) if bias else None
+        y = ops.conv2d(xg, wg, bg, stride, pad)
+        y.backward(gy.cuda())
+        tag = (n, ci, h, w_, co, k, stride, bias)
+        assert rel(y, y_ref) < TOL, tag
+        assert rel(xg.grad, xr.grad) < GTOL and rel(wg.grad, wr.grad) < GTOL, tag
+        if bias:
+            assert rel(bg.grad, br.grad) < GTOL, tag
+        g = ops._geom(xg, None, wg, stride, pad)
+        import ctypes as C
+        done.add((int(ops._lib().dynmm_conv2d_uses_operand_ring(C.byref(g), 0)), int(ops._lib().dynmm_conv2d_wgrad_variant(C.byref(g)))))
+    assert {v for _, v in done} >= {0, 4, 6} and {r for r, _ in done} == {0, 1}, done      # every family was exercised
+
+
 def test_conv2d_dual_input(ops):
     """GlobalGate's first conv: cat(rgb, depth) is never materialised."""
     a, b2 = rnd(2, 64, 24, 32, seed=5), rnd(2, 64, 24, 32, seed=6)
