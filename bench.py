@@ -265,13 +265,16 @@ def kernel_timing(step_fn, model):
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     agg, shapes = {}, {}
-    for name, flops, e0, e1, shape in rec:
+    for name, flops, e0, e1, shape, (kind, extra) in rec:
         ms = e0.elapsed_time(e1)
         n_, ci, h, w, co, kh, kw, sh, sw, nprob = shape
-        # algorithmic bytes of the launch: every operand once (input + output/gradient tensor + weights), fp32;
+        # algorithmic bytes of the launch: every operand once (input + output/gradient tensor + weights), fp32, plus the
+        # epilogue's own operands — the ReLU-mask source and the accumulated residual gradient of an input-gradient launch,
+        # the residual of a forward launch — each a tensor of the launch's OUTPUT size;
         # nprob > 1: a grouped weight-gradient launch (dynmm_conv2d_wgrad_group) of that many same-shape convolutions
         ho, wo = -(-h // sh), -(-w // sw)
-        abytes = 4.0 * nprob * (n_ * ci * h * w + n_ * co * ho * wo + co * ci * kh * kw)
+        out_elems = n_ * ci * h * w if kind == 'dgrad' else n_ * co * ho * wo
+        abytes = 4.0 * nprob * (n_ * ci * h * w + n_ * co * ho * wo + co * ci * kh * kw) + 4.0 * extra * out_elems
         for d, key in ((agg, name), (shapes, (name, shape))):
             a = d.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1

@@ -246,7 +246,7 @@ def _tile(co, m=1 << 30):
 _SMALL_DIRECT = _os.environ.get('DYNMM_NO_SMALL_CO') is None
 
 
-def _timed(kind, g, call, nprob=1):
+def _timed(kind, g, call, nprob=1, extra=0):
     if PROFILE is None:
         return call()
     co = g.Ci if kind == 'dgrad' else g.Co
@@ -279,7 +279,8 @@ def _timed(kind, g, call, nprob=1):
     e0.record()
     r = call()
     e1.record()
-    PROFILE.append((name, flops, e0, e1, (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, nprob)))
+    # extra: epilogue operands of the launch that are tensors of the OUTPUT's size (ReLU-mask source, residual / accumulated gradient)
+    PROFILE.append((name, flops, e0, e1, (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, nprob), (kind, int(extra))))
     return r
 
 
@@ -603,7 +604,8 @@ class _Conv2d(Function):
                         L.check(rc, 'conv2d_dgrad_bnstats')
                 if rc == L.DYNMM_EUNSUPPORTED:
                     L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad_ws(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
-                                                                                 _p(dx2), C.byref(g), _p(ws), nws, st)), 'conv2d_dgrad')
+                                                                                 _p(dx2), C.byref(g), _p(ws), nws, st),
+                                   extra=(mask is not None) + (accum is not None)), 'conv2d_dgrad')
         dw_ret = None
         ws_stream = None
         if DIRECT_GRAD and WGRAD_GROUP > 1:
@@ -750,7 +752,8 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     else:
         ws, nws = _conv_scratch(g, 0, x.device)
         L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_ws(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
-                                                                 _p(y), C.byref(g), ACT[act], _p(ws), nws, st)), 'conv2d_fwd')
+                                                                 _p(y), C.byref(g), ACT[act], _p(ws), nws, st),
+                       extra=int(residual is not None)), 'conv2d_fwd')
     return y
 
 
