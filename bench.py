@@ -126,6 +126,32 @@ def host_cpu():
     return model, (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
 
 
+def cpu_allowance():
+    """What this process may actually use: the scheduler affinity mask and the cgroup CPU quota (v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`) — a container can see 128 cores in /proc/cpuinfo and be throttled to 16."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    cpu_max, quota = None, None
+    try:
+        cpu_max = open('/sys/fs/cgroup/cpu.max').read().strip()
+        q, per = cpu_max.split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            cpu_max = f'{q} {per}'
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = aff if quota is None else min(aff, max(1, int(quota + 0.999)))
+    return {'affinity': aff, 'cpu_max': cpu_max, 'quota_cpus': quota, 'effective': eff}
+
+
 def cpu_baseline_and_parity(args, device):
     """Times the oracle's step on a bounded sample (batch args.cpu_batch of the same workload) for several thread
     counts and keeps the best; the last oracle run is also the checker for one HIP step on identical inputs."""
@@ -165,8 +191,15 @@ def cpu_baseline_and_parity(args, device):
                    total=total.detach())
 
     model_name, phys, logical = host_cpu()
+    avail = cpu_allowance()
     default_threads = torch.get_num_threads()
-    cands = sorted({t for t in (phys, 64, 32, 16, default_threads) if 1 <= t <= logical}, reverse=True)
+    cap = min(logical, avail['affinity'])
+    # widths from "every physical core" down to 4; the cgroup quota (if any) is a candidate of its own: on a host that
+    # shows 128 cores to a container allowed ~16 CPUs' worth of time, more threads than the quota only add contention
+    cands = {phys, 64, 32, 16, 8, 4, default_threads}
+    if avail['quota_cpus'] is not None:
+        cands.add(max(1, int(round(avail['quota_cpus']))))
+    cands = sorted({t for t in cands if 1 <= t <= cap}, reverse=True)
     sweep, best = {}, None
     one()                                              # warm-up (allocator, oneDNN primitive caches)
     for t in cands:
@@ -178,20 +211,34 @@ def cpu_baseline_and_parity(args, device):
         sweep[t] = round(n / dt, 4)
         if best is None or dt < best[1]:
             best = (t, dt)
+        elif t < best[0] and dt > 1.25 * best[1]:
+            break                                      # the curve has turned: narrower widths only get slower
     torch.set_num_threads(best[0])
-    small = round(n / best[1], 4)
-    # the workload's own batch: ONE timed step at the winning thread count (one step is the whole 10-30 s CPU budget;
-    # thread widths are compared on the small sample above because a sweep at full batch would take minutes)
-    full_n, value, sample_n, why = args.batch if train else 16, small, n, None
+
+    def median_rate(batch, nb, max_s):
+        """1 warm-up + >= 3 timed steps, median (fewer timed steps only if one step exceeds max_s / 4)"""
+        t0 = time.perf_counter()
+        one(batch)                                     # warm-up at THIS batch size: first touch of its activations
+        warm = time.perf_counter() - t0
+        reps = 3 if warm * 4 <= max_s else 1
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            one(batch)
+            ts.append(time.perf_counter() - t0)
+        return round(nb / sorted(ts)[len(ts) // 2], 4), reps
+
+    small, small_reps = median_rate(None, n, 60.0)
+    # the workload's own batch at the winning width; the line reports the BEST rate the host reaches over the two samples
+    full_n, value, sample_n, reps_used, why, full_rate = args.batch if train else 16, small, n, small_reps, None, None
     if args.cpu_full_batch and full_n > n:
         try:
             gb = torch.Generator().manual_seed(99)
             big = make_batch(full_n, args.height, args.width, 'cpu', 4322) + \
                 ([torch.empty(full_n, 2).exponential_(generator=gb) for _ in range(4)],)
-            t0 = time.perf_counter()
-            one(big)
-            dt = time.perf_counter() - t0
-            value, sample_n = round(full_n / dt, 4), full_n
+            full_rate, full_reps = median_rate(big, full_n, 120.0)
+            if full_rate > value:
+                value, sample_n, reps_used = full_rate, full_n, full_reps
             del big
         except (RuntimeError, MemoryError) as e:       # host RAM: a batch-32 training step keeps ~45 GB of activations
             why = f'batch {full_n} step failed on this host ({type(e).__name__}); batch {n} figure reported'
@@ -199,11 +246,15 @@ def cpu_baseline_and_parity(args, device):
     torch.set_num_threads(default_threads)
     cpu = {'value': value, 'unit': 'images/s', 'cores': best[0], 'kind': 'port',
            'cpu_model': model_name, 'physical_cores': phys, 'logical_cpus': logical,
+           'cores_available': avail['effective'], 'sched_affinity': avail['affinity'], 'cgroup_cpu_max': avail['cpu_max'],
            'batch': sample_n, f'batch{n}_images_per_s': small,
+           f'batch{full_n}_images_per_s': full_rate,
            'threads_sweep_images_per_s': {str(k): v for k, v in sweep.items()},
-           'sample': f'oracle (PyTorch CPU fp32): ONE {args.height}x{args.width} {args.mode} step (fwd + weighted 4-scale CE + '
-                     f'flop loss + bwd) at batch {sample_n} with {best[0]} threads; thread count chosen by a sweep {cands} '
-                     f'over batch-{n} steps of the same workload' + (f'; {why}' if why else '')}
+           'sample': f'oracle (PyTorch CPU fp32): {args.height}x{args.width} {args.mode} steps (fwd + weighted 4-scale CE + '
+                     f'flop loss + bwd) at batch {sample_n} with {best[0]} threads, 1 warm-up + {reps_used} timed, median; the best '
+                     f'of the batch-{n} and batch-{full_n} rates is reported; thread count chosen by a sweep {list(sweep)} '
+                     f'over batch-{n} steps; the host allows {avail["effective"]} CPUs (affinity {avail["affinity"]}, cgroup '
+                     f'cpu.max {avail["cpu_max"]})' + (f'; {why}' if why else '')}
 
     # ---- parity: the HIP path on the same inputs, against the oracle run above ----
     parity = None
@@ -521,7 +572,10 @@ def main():
         ones = torch.ones(1)
         dist.all_reduce(ones)
         if rank == 0:
-            print(json.dumps({'probe': True, 'n_gpus': world, 'ranks_seen': int(ones.item()), 'steps': args.steps}))
+            print(json.dumps({'probe': True, 'n_gpus': world, 'ranks_seen': int(ones.item()), 'steps': args.steps,
+                              'omp_num_threads': os.environ.get('OMP_NUM_THREADS'),
+                              'master': f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                              'ipc_mode_legacy': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}))
         dist.destroy_process_group()
         return
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

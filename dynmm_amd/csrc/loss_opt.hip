@@ -22,12 +22,12 @@ template <int CMAX>
 __global__ void __launch_bounds__(256) ce2d_fwd_kernel(const float* __restrict__ x,
                                                        const unsigned char* __restrict__ target,
                                                        const float* __restrict__ cw,
-                                                       double* __restrict__ out2, int C, int HW) {
+                                                       double* __restrict__ out2, int C, int HW, int dual) {
     __shared__ float red[4];
     const int n = blockIdx.y;
     const float* xn = x + (size_t)n * C * HW;
     const unsigned char* tn = target + (size_t)n * HW;
-    float ls = 0.f, ws = 0.f;
+    float ls = 0.f, ws = 0.f, us = 0.f, cnt = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         const int t = (int)tn[p] - 1;
         if (t < 0 || t >= C) continue;   // void (ignore_index = -1 after the shift)
@@ -46,12 +46,22 @@ __global__ void __launch_bounds__(256) ce2d_fwd_kernel(const float* __restrict__
         const float w = cw[t];
         ls += w * (lse - xt);
         ws += w;
+        us += lse - xt;
+        cnt += 1.f;
     }
     const float tl = block_reduce_sum_256<float>(ls, red);
     const float tw = block_reduce_sum_256<float>(ws, red);
     if (threadIdx.x == 0) {
         atomicAdd(&out2[0], (double)tl);
         atomicAdd(&out2[1], (double)tw);
+    }
+    if (dual) {   // validation: the unweighted sum and the non-void pixel count from the same pass (src/utils.py:77-97)
+        const float tu = block_reduce_sum_256<float>(us, red);
+        const float tc = block_reduce_sum_256<float>(cnt, red);   // <= 256 * ceil(HW / (256 * gridDim.x)): exact in fp32
+        if (threadIdx.x == 0) {
+            atomicAdd(&out2[2], (double)tu);
+            atomicAdd(&out2[3], (double)tc);
+        }
     }
 }
 
@@ -284,9 +294,27 @@ extern "C" int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const
     int bx = ceil_div(HW, 256);
     if (bx > 256) bx = 256;
     if (C <= 40)
-        hipLaunchKernelGGL(ce2d_fwd_kernel<40>, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW);
+        hipLaunchKernelGGL(ce2d_fwd_kernel<40>, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW, 0);
     else
-        hipLaunchKernelGGL(ce2d_fwd_kernel<kMaxClasses>, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW);
+        hipLaunchKernelGGL(ce2d_fwd_kernel<kMaxClasses>, dim3(bx, N), dim3(256), 0, st, x, target, cw, loss_sum_wsum, C, HW, 0);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+// validate()'s two losses (train.py:104-115, src/utils.py:53-97) from ONE pass over the logits: acc4 +=
+// (sum w[t]*CE, sum w[t], sum CE, #non-void pixels).  Always accumulates (the caller zeroes acc4 per validation run).
+extern "C" int dynmm_ce2d_valid(const float* x, const unsigned char* target, const float* cw,
+                                double* acc4, int N, int C, int HW, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !target || !cw || !acc4 || N <= 0 || C <= 0 || C > kMaxClasses || HW <= 0)
+        return DYNMM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int bx = ceil_div(HW, 256);
+    if (bx > 256) bx = 256;
+    if (C <= 40)
+        hipLaunchKernelGGL(ce2d_fwd_kernel<40>, dim3(bx, N), dim3(256), 0, st, x, target, cw, acc4, C, HW, 1);
+    else
+        hipLaunchKernelGGL(ce2d_fwd_kernel<kMaxClasses>, dim3(bx, N), dim3(256), 0, st, x, target, cw, acc4, C, HW, 1);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -31,13 +31,12 @@ class SyntheticRGBD:
                     for r in (8, 16, 32)}
             yield {'image': rgb, 'depth': depth, 'label': label, 'label_down': down, 'label_orig': label}
 
-    def compute_class_weights(self, weight_mode='median_frequency', c=1.02):
-        """src/datasets/dataset_base.py:147-208 over this source's own label maps (void = class 0 removed):
-        median_frequency = median(f) / f with f = pixels of the class / pixels of the images containing it;
-        logarithmic = 1 / log(c + p); linear = pixel counts."""
+    def class_counts(self):
+        """(pixels per class, pixels of the images containing the class) over this source's label maps, void included at
+        index 0 — the two histograms src/datasets/dataset_base.py:160-186 accumulates.  Additive over shards: under data
+        parallel the ranks SUM them before forming the weights (dynmm_amd/train.py), so every replica uses the weights of
+        the whole training set, as the reference does."""
         import numpy as np
-        if weight_mode not in ('median_frequency', 'logarithmic', 'linear'):
-            raise ValueError(f'unknown class weighting {weight_mode!r}')
         n_cls = self.n_classes_without_void + 1
         per_class, with_class = np.zeros(n_cls), np.zeros(n_cls)
         for i in range(len(self)):
@@ -47,6 +46,15 @@ class SyntheticRGBD:
                 dist = np.bincount(img.numpy(), minlength=n_cls)[:n_cls]
                 per_class += dist
                 with_class += (dist > 0) * img.numel()
+        return per_class, with_class
+
+    @staticmethod
+    def weights_from_counts(per_class, with_class, weight_mode='median_frequency', c=1.02):
+        """src/datasets/dataset_base.py:188-208 (void = class 0 removed): median_frequency = median(f) / f with
+        f = pixels of the class / pixels of the images containing it; logarithmic = 1 / log(c + p); linear = counts."""
+        import numpy as np
+        if weight_mode not in ('median_frequency', 'logarithmic', 'linear'):
+            raise ValueError(f'unknown class weighting {weight_mode!r}')
         per_class, with_class = per_class[1:], with_class[1:]
         if weight_mode == 'linear':
             w = per_class
@@ -58,3 +66,6 @@ class SyntheticRGBD:
         if np.isnan(np.sum(w)):
             raise ValueError('class weighting contains NaNs')
         return w
+
+    def compute_class_weights(self, weight_mode='median_frequency', c=1.02):
+        return self.weights_from_counts(*self.class_counts(), weight_mode=weight_mode, c=c)

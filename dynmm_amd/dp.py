@@ -63,6 +63,7 @@ class GradBucketReducer:
         self._next = 0                                       # buckets are launched strictly in index order (see _arrived)
         self.launched_in_backward = 0                        # buckets whose all-reduce started before finish()
         self.launch_log = []                                 # (bucket, 'backward' | 'finish') of the last step
+        self.pending_scale = 1.0                             # 1/world still owed to the flat buffer after finish(average=False)
         if self.overlap:
             # (a) plain autograd accumulation (torch modules): post-accumulate hooks;
             # (b) the HIP kernels' in-place gradient protocol (ops.DIRECT_GRAD: autograd never sees these
@@ -131,8 +132,11 @@ class GradBucketReducer:
             self._streams[b][st.cuda_stream] = st
         self._arrived(p)
 
-    def finish(self):
-        """After backward: make sure every bucket is reduced, then average."""
+    def finish(self, average=True):
+        """After backward: make sure every bucket is reduced, then average.  `average=False` leaves the SUM over ranks in
+        the flat buffer (and the loss slot): engine.TrainStep folds 1/world into the fused optimizer kernel's
+        `grad_scale` argument instead of spending a pass over the 130 MB buffer on it; `pending_scale` says what is owed."""
+        self.pending_scale = 1.0
         if (self.world == 1 and not self.force) or not self.enabled:
             return
         first = self._next if self.overlap else 0
@@ -144,7 +148,10 @@ class GradBucketReducer:
             w.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self._store.mul_(1.0 / self.world)
+        if average:
+            self._store.mul_(1.0 / self.world)
+        else:
+            self.pending_scale = 1.0 / self.world
         self._works = []
 
     def set_loss(self, total):

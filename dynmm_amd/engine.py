@@ -106,6 +106,8 @@ class _FlatOptimizer:
             per.setdefault(self.group_of[i], []).append(self.fp.span[i])
         return [(gi, _merge(sp)) for gi, sp in sorted(per.items())]
 
+    grad_scale = 1.0           # multiplies every gradient inside the update kernel (data parallel: 1/world of the SUM)
+
     def step(self, touched=None, loss=None):
         lib = L.load()
         ops.note_mutation()                 # parameters are rewritten through raw pointers
@@ -150,7 +152,7 @@ class _FlatOptimizer:
     def load_state_dict(self, sd):
         index, _ = self._index()
         if 'param_groups' not in sd:                       # rounds 1-2 layout: the flat buffers themselves
-            for key, buf in zip(('momentum_buffer', 'exp_avg', 'exp_avg_sq'), self.state_tensors()):
+            for key, buf in zip(self.STATE_KEYS, self.state_tensors()[:len(self.STATE_KEYS)]):
                 if key in sd:
                     buf.copy_(sd[key])
             if 'steps' in sd:
@@ -199,7 +201,7 @@ class SGDNesterov(_FlatOptimizer):
     def _launch(self, lib, lo, hi, sp, lp, st):
         L.check(lib.dynmm_sgd_nesterov(self.p.data_ptr(), self.g.data_ptr(), self.buf.data_ptr(),
                                        C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), self.weight_decay,
-                                       1.0, lp, self.nan_flag.data_ptr(), sp, st), 'sgd_nesterov')
+                                       float(self.grad_scale), lp, self.nan_flag.data_ptr(), sp, st), 'sgd_nesterov')
 
     STATE_KEYS = ('momentum_buffer',)
 
@@ -234,7 +236,7 @@ class Adam(_FlatOptimizer):
 
     def _launch(self, lib, lo, hi, sp, lp, st):
         L.check(lib.dynmm_adam(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                               C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), sp, self.weight_decay, 1.0,
+                               C.c_size_t(lo), C.c_size_t(hi), self.hyper.data_ptr(), sp, self.weight_decay, float(self.grad_scale),
                                lp, self.nan_flag.data_ptr(), int(self.decoupled),
                                None if self.grad_scale_dev is None else self.grad_scale_dev.data_ptr(), st), 'adam')
 
@@ -360,7 +362,10 @@ class TrainStep:
 
     def _finish(self):
         red = self.reducer
-        red.finish()
+        # the all-reduce leaves the SUM over ranks in the flat buffer; 1/world is applied inside the optimizer kernel
+        # (its grad_scale argument) instead of by a separate pass over the 130 MB of gradients
+        red.finish(average=False)
+        self.opt.grad_scale = red.pending_scale
         touched = self._touched
         if red.world > 1 and red.enabled and touched is not None and self._rank_dependent_touch():
             # the all-reduced gradient of a parameter is non-zero on EVERY rank as soon as one rank touched it: update the
@@ -371,6 +376,10 @@ class TrainStep:
             dp.dist.all_reduce(mask, op=dp.dist.ReduceOp.MAX, group=red.group)
             touched = {i for i, v in zip(ids, mask.tolist()) if v}
         self.opt.step(touched, red.reduced_loss(self.last['total']))
+        if self.last['total'].data_ptr() == red.loss_slot.data_ptr():
+            # data parallel: `total` was written into the reducer's loss slot (mean over ranks after finish()); the slot
+            # is cleared by the next step's zero(), so callers that keep per-step losses (train.py appends them) get a copy
+            self.last['total'] = red.loss_slot * red.pending_scale          # a new tensor: the mean over ranks
 
     def _graph_key(self, rgb, depth, targets):
         m = self.model
@@ -445,17 +454,86 @@ class TrainStep:
         return graph, static, self.last, self._touched
 
 
+def _dist_world(group=None):
+    return (dp.dist.get_rank(group), dp.dist.get_world_size(group)) if dp.dist.is_initialized() else (0, 1)
+
+
 @torch.no_grad()
-def evaluate(model, batches, num_classes=40, hard=True):
-    """batches: iterable of (rgb, depth, label_orig[N,H0,W0] with 0 = void).  Returns (mIoU*100, cm)."""
+def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard=True, group=None, losses=None):
+    """batches: iterable of (rgb, depth, label_orig[N,H0,W0] with 0 = void[, label[N,H,W] at the network's resolution]).
+    Returns (mIoU*100, cm).
+
+    Data parallel (new; the reference is single-device): with `shard` and an initialised process group, rank r runs
+    batches r, r + world, ... and the 40x40 confusion matrix (int64: exact) is all-reduced once at the end — every rank
+    returns the same mIoU for 1/world of the forward passes.
+
+    `losses` (a dict) + `class_weight`: also accumulate validate()'s two validation losses (train.py:432-440;
+    src/utils.py:53-97) from batches that carry the 4th element; the dict receives `sum_weighted`, `weight_sum`,
+    `sum_unweighted`, `pixels` (python floats, summed over ranks)."""
     was_training = model.training
     model.eval()
-    old_hard, model.hard_gate = model.hard_gate, hard
-    cm = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=next(model.parameters()).device)
-    for rgb, depth, label in batches:
-        ops.eval_confusion(model(rgb, depth, True), label, cm)     # resize + argmax + void mask + bincount, one kernel
+    old_hard, model.hard_gate = getattr(model, 'hard_gate', False), hard
+    dev = next(model.parameters()).device
+    cm = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=dev)
+    acc4 = torch.zeros(4, dtype=torch.float64, device=dev)
+    cw = None if class_weight is None else torch.as_tensor(class_weight, dtype=torch.float32, device=dev)
+    rank, world = _dist_world(group) if shard else (0, 1)
+    for i, batch in enumerate(batches):
+        if i % world != rank:
+            continue
+        rgb, depth, label = batch[:3]
+        logits = model(rgb, depth, True)
+        if losses is not None and cw is not None and len(batch) > 3:
+            ops.validation_loss_accumulate(logits, batch[3], cw, acc4)
+        ops.eval_confusion(logits, label, cm)     # resize + argmax + void mask + bincount, one kernel
     model.hard_gate = old_hard
     model.train(was_training)
+    if world > 1:
+        if dp.dist.get_backend(group) == 'gloo':
+            cm_h, acc_h = cm.cpu(), acc4.cpu()
+            dp.dist.all_reduce(cm_h, group=group)
+            dp.dist.all_reduce(acc_h, group=group)
+            cm, acc4 = cm_h.to(dev), acc_h.to(dev)
+        else:
+            dp.dist.all_reduce(cm, group=group)
+            dp.dist.all_reduce(acc4, group=group)
+    if losses is not None:
+        losses.update(zip(('sum_weighted', 'weight_sum', 'sum_unweighted', 'pixels'), acc4.tolist()))
     cmd = cm.double()
     iou = cmd.diag() / (cmd.sum(1) + cmd.sum(0) - cmd.diag() + 1e-15)
     return iou.mean().item() * 100.0, cm.cpu()
+
+
+def validate(model, loaders_by_camera, class_weight, logs=None, split='test', soft_eval=False, dynamic=True,
+             weighted_pixel_sum=None, num_classes=40, shard=True, group=None):
+    """FusionDynMM/train.py:368-551 `validate` on the HIP path: one confusion matrix per camera (all images of a camera
+    share a resolution, :398-404), mIoU per camera under `mIoU_{split}_{camera}`, the class-weighted validation loss
+    `loss_{split}` = sum_px w[t]*CE / weighted_pixel_sum (src/utils.py:53-74; `weighted_pixel_sum` = sum_c pixels_c*w_c
+    over the validation labels, train.py:104-108 — when None it is accumulated from the labels the loss is evaluated on,
+    which is the same number whenever the loader's labels are the data set's) and `loss_{split}_unweighted`
+    (:77-97), hard gates unless `soft_eval` (:384), gate statistics through start_weight / end_weight (:385-387, :512).
+    `loaders_by_camera`: {camera: iterable of dicts with image / depth / label_orig / label}.  Returns (miou, logs)
+    with `miou[camera]` and the confusion matrices under logs['confusion_matrices'] (train.py pickles them, :521-525)."""
+    import time
+    t0 = time.time()
+    logs = {} if logs is None else logs
+    if dynamic and hasattr(model, 'start_weight'):
+        model.start_weight()
+    miou, cms, tot = {}, {}, dict(sum_weighted=0.0, weight_sum=0.0, sum_unweighted=0.0, pixels=0.0)
+    for camera, loader in loaders_by_camera.items():
+        part = {}
+        batches = ((s['image'], s['depth'], s['label_orig'], s['label']) for s in loader)
+        miou[camera], cms[camera] = evaluate(model, batches, num_classes, hard=not soft_eval, class_weight=class_weight,
+                                             shard=shard, group=group, losses=part)
+        for k in tot:
+            tot[k] += part[k]
+    if dynamic and hasattr(model, 'end_weight'):
+        model.end_weight(print_each=True)
+    wsum = float(weighted_pixel_sum) if weighted_pixel_sum is not None else tot['weight_sum']
+    logs[f'loss_{split}'] = tot['sum_weighted'] / wsum if wsum else float('nan')
+    logs[f'loss_{split}_unweighted'] = tot['sum_unweighted'] / tot['pixels'] if tot['pixels'] else float('nan')
+    for camera in loaders_by_camera:
+        logs[f'mIoU_{split}_{camera}'] = miou[camera]
+    logs['time_validation'] = time.time() - t0
+    logs['confusion_matrices'] = cms
+    return miou, logs

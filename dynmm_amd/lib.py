@@ -110,6 +110,7 @@ SIGNATURES = {
     'dynmm_up2ce_bwd_workspace_bytes': (c_sz, [c_i] * 4),
     'dynmm_up2ce_bwd': (c_i, [c_f] * 11 + [c_i] * 4 + [c_f]),
     'dynmm_loss_head': (c_i, [c_f, c_i, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
+    'dynmm_ce2d_valid': (c_i, [c_f] * 4 + [c_i, c_i, c_i, c_f]),
     'dynmm_ce2d_bwd': (c_i, [c_f] * 5 + [c_i, c_i, c_i, c_f]),
     'dynmm_eval_confusion': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
     'dynmm_batch_gather': (c_i, [c_f, c_f, c_f, c_i, c_sz, c_f]),

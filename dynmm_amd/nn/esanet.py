@@ -27,9 +27,14 @@ class ESANet(SkipGateESANet):
         del self.gate_layer                      # no gate parameters: the reference ESANet has none
         self.baseline = True
 
-    def forward(self, rgb, depth):
-        # model.py:189-241: every stage fuses; SkipGateESANet with baseline = True computes the same blend with w = e_4
+    def forward(self, rgb, depth, test=True, return_weight=False):
+        # model.py:189-241: every stage fuses; SkipGateESANet with baseline = True computes the same blend with w = e_4.
+        # The reference's ESANet.forward takes (rgb, depth) only; the two extra arguments are what train.py's `validate`
+        # / eval.py pass to the dynamic models (train.py:438, eval.py:106) and are accepted so that engine.evaluate and
+        # those callers work on either model: there is no gate, hence no FLOP loss to return and `weight` is e_4.
         self.baseline = True
+        if return_weight:
+            return super().forward(rgb, depth, test=True, return_weight=True)
         return super().forward(rgb, depth, test=True)
 
     def freeze(self):

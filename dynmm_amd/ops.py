@@ -1739,6 +1739,23 @@ def multi_scale_loss_backward(outs, targets, class_weight, flop_loss=None, ratio
     return {'losses': losses, 'loss_flop': lf if lf is not None else torch.zeros((), **f32), 'total': total}
 
 
+def validation_loss_accumulate(logits, target, class_weight, acc4):
+    """acc4 (float64 [4], device) += (sum w[t]*CE, sum w[t], sum CE, #non-void pixels) of this batch — the running sums of
+    CrossEntropyLoss2dForValidData / ...Unweighted.add_loss_of_batch (src/utils.py:65-69, 89-94), one pass over the logits."""
+    lib = _lib()
+    logits, class_weight = _chk(logits, 'logits'), _chk(class_weight, 'class_weight')
+    t = target if target.dtype == torch.uint8 else target.to(torch.uint8)
+    t = t if t.is_contiguous() else t.contiguous()
+    N, Cc, H, W = logits.shape
+    if tuple(t.shape) != (N, H, W):
+        raise L.DynmmHipError(f'validation loss: label {tuple(t.shape)} does not match logits {tuple(logits.shape)}')
+    if acc4.dtype != torch.float64 or acc4.numel() != 4 or not acc4.is_contiguous():
+        raise L.DynmmHipError('acc4 must be a contiguous float64 [4] tensor')
+    L.check(lib.dynmm_ce2d_valid(_p(logits), t.data_ptr(), _p(class_weight), acc4.data_ptr(), N, Cc, H * W, _stream()),
+            'ce2d_valid')
+    return acc4
+
+
 def eval_confusion(logits, label, cm):
     """cm (int64 [C,C], device) += confusion counts of argmax(bilinear_resize(logits, label size)) vs label-1
     over non-void pixels — eval.py:117-141 fused into one kernel (no resized logits, no arg-max map)."""

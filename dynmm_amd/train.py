@@ -65,9 +65,28 @@ def train_main(argv=None):
     return run(args, model, train, valid, ckpt_dir, rank, world)
 
 
+CAMERA = 'kv1'        # NYUv2's only camera (src/datasets/nyuv2/nyuv2.py: CAMERAS); train.py:217 reports mIoU_test_kv1
+
+
+def class_weights(args, train_loader, world=1):
+    """--class_weighting over the WHOLE training set (train.py:100-103): each rank holds a shard of it, so the two label
+    histograms are summed over ranks before the weights are formed — every replica then weighs its CE identically."""
+    if args.class_weighting == 'None':
+        return np.ones(40)
+    if world > 1 and hasattr(train_loader, 'class_counts'):
+        per, with_ = train_loader.class_counts()
+        both = torch.from_numpy(np.stack([per, with_]))                 # float64 pixel counts: exact in a sum over ranks
+        if dist.get_backend() != 'gloo':
+            both = both.cuda()
+        dist.all_reduce(both)
+        per, with_ = both.cpu().numpy()
+        return train_loader.weights_from_counts(per, with_, args.class_weighting, c=args.c_for_logarithmic_weighting)
+    return train_loader.compute_class_weights(args.class_weighting, c=args.c_for_logarithmic_weighting)
+
+
 def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
     dp.broadcast_parameters(model)
-    cw = train_loader.compute_class_weights(args.class_weighting, c=args.c_for_logarithmic_weighting) if args.class_weighting != 'None' else np.ones(40)
+    cw = class_weights(args, train_loader, world)
     if args.freeze and args.dynamic:                      # train.py:139-141
         print('Freeze everything but the soft gates')
         model.freeze()
@@ -112,25 +131,34 @@ def run(args, model, train_loader, valid_loader, ckpt_dir, rank=0, world=1):
         row = {'epoch': epoch, 'lr_0': lr, 'loss_train_total': total,
                'loss_flop': torch.stack([f.reshape(()) for f in flop]).mean().item(),
                'time_training': time.time() - t0, 'temp': model.temp}
-        if epoch == 0 or epoch % args.eval_every == 0:
-            batches = ((s['image'], s['depth'], s['label_orig']) for s in valid_loader)
-            miou, _ = engine.evaluate(model, batches, hard=not args.soft_eval)
-            row['mIoU_test'] = miou
-            if miou > best_miou:
-                best_miou, best_epoch = miou, epoch
-                # train.py:235 deep-copies the model here; a CPU snapshot of its state_dict is what gets saved
-                best_state = {k: v.detach().to('cpu', copy=True) for k, v in model.state_dict().items()}
+        if epoch == start_epoch or epoch % args.eval_every == 0:        # train.py:207
+            # validate (train.py:368-551): per-camera mIoU + weighted / unweighted validation loss; under data parallel
+            # the validation batches are sharded over the ranks and the confusion matrix is all-reduced once
+            miou, row = engine.validate(model, {CAMERA: valid_loader}, cw, logs=row, split='test',
+                                        soft_eval=args.soft_eval, dynamic=args.dynamic)
+            row.pop('confusion_matrices', None)
+            row['mIoU_test'] = miou[CAMERA]
+            if miou[CAMERA] > best_miou:
+                best_miou, best_epoch = miou[CAMERA], epoch
+                if rank == 0:
+                    # train.py:235 deep-copies the model here; a CPU snapshot of its state_dict is what gets saved
+                    # (rank 0 only: it is the rank that writes checkpoints)
+                    best_state = {k: v.detach().to('cpu', copy=True) for k, v in model.state_dict().items()}
         if rank == 0:
             print(f"Epoch {epoch} | Train loss {row['loss_train_total']:.4f} | Flop loss {row['loss_flop']:.4f} "
-                  f"Temperature {model.temp} | lr {lr}" + (f" | mIoU {row['mIoU_test']:.2f}" if 'mIoU_test' in row else ''))
+                  f"Temperature {model.temp} | lr {lr}" + (f" | Test loss {row['loss_test']:.4f} | Test mIoU {row['mIoU_test']:.2f}" if 'mIoU_test' in row else ''))
             if epoch >= 10 and epoch % args.save_every == args.save_every - 1:
                 save_ckpt(ckpt_dir, model, step.opt, epoch, best_miou, best_epoch)
         logs.append(row)
     if rank == 0:
         # train.py:250: the BEST model's weights under the best epoch's name
-        path = os.path.join(ckpt_dir, f'ckpt_epoch_{best_epoch}.pth')
-        state = best_state if best_state is not None else {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        torch.save({'epoch': best_epoch, 'state_dict': state, 'optimizer': step.opt.state_dict()}, path)
+        if best_state is not None:
+            path = os.path.join(ckpt_dir, f'ckpt_epoch_{best_epoch}.pth')
+            torch.save({'epoch': best_epoch, 'state_dict': best_state, 'optimizer': step.opt.state_dict()}, path)
+        else:
+            # no new best in this run (e.g. a resume whose earlier best still stands): the best checkpoint on disk keeps
+            # its name and content; the final weights go under the last epoch's name instead of overwriting it
+            save_ckpt(ckpt_dir, model, step.opt, max(start_epoch, args.epochs - 1), best_miou, best_epoch)
         with open(os.path.join(ckpt_dir, 'finished.txt'), 'w') as f:
             f.write(f'best miou: {best_miou}\nbest miou epoch: {best_epoch}\n')
     if world > 1:

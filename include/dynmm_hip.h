@@ -359,6 +359,11 @@ int dynmm_gate_head_bwd(const float* d_weight, const float* d_wcum, const float*
  * dx = (softmax - onehot) * w[t] * gscale[0]   (gscale = upstream_grad / wsum, device scalar). */
 int dynmm_ce2d_fwd(const float* x, const unsigned char* target, const float* cw,
                    double* loss_sum_wsum /*[2]*/, int N, int C, int HW, int acc_is_zero, void* stream);
+/* validate()'s losses (train.py:104-115; src/utils.py:53-74 CrossEntropyLoss2dForValidData, :77-97 ...Unweighted):
+ * acc4 += (sum_px w[t]*CE, sum_px w[t], sum_px CE, #non-void px) in ONE pass over the logits; the caller zeroes acc4
+ * at the start of a validation run and divides at its end (acc4[0]/weighted_pixel_sum, acc4[2]/acc4[3]). */
+int dynmm_ce2d_valid(const float* x, const unsigned char* target, const float* cw,
+                     double* acc4, int N, int C, int HW, void* stream);
 /* train.py:313-321 on the device: losses[s] = acc[2s]/acc[2s+1] for the S scales,
  * total = sum_s losses[s] + ratio*max(0, flop_loss - budget), and the backward seeds gscale[s] = 1/acc[2s+1]
  * (for dynmm_ce2d_bwd) and d_flop = ratio*[flop_loss > budget].  flop_loss / d_flop optional. */

@@ -330,6 +330,23 @@ def cross_entropy_2d(logits_scales, target_scales, class_weight):
     return losses
 
 
+def validation_losses(logits_batches, target_batches, class_weight, weighted_pixel_sum=None):
+    """validate()'s two losses over a validation run (train.py:104-115, :432-440): CrossEntropyLoss2dForValidData
+    (src/utils.py:53-74: sum over batches of the weighted CE with reduction='sum', divided by
+    weighted_pixel_sum = sum_c pixels_c * w_c of the validation labels) and CrossEntropyLoss2dForValidDataUnweighted
+    (:77-97: plain CE sum / number of non-void pixels).  targets: 0 = void."""
+    cw = torch.as_tensor(class_weight, dtype=torch.float32)
+    tw, tu, npx, wps = 0.0, 0.0, 0, 0.0
+    for x, t in zip(logits_batches, target_batches):
+        tm = t.long() - 1
+        tw = tw + F.cross_entropy(x, tm, weight=cw.to(x.dtype), reduction='sum', ignore_index=-1)
+        tu = tu + F.cross_entropy(x, tm, reduction='sum', ignore_index=-1)
+        npx += int((tm >= 0).sum())
+        wps += float((torch.bincount(t.flatten().long(), minlength=len(cw) + 1)[1:].double() * cw.double()).sum())
+    wps = wps if weighted_pixel_sum is None else float(weighted_pixel_sum)
+    return float(tw) / wps, float(tu) / npx
+
+
 def confusion_matrix(label, pred, num_classes):
     """ConfusionMatrixPytorch.update (src/confusion_matrix.py:118-130): rows = label."""
     idx = num_classes * label.long() + pred.long()

@@ -15,6 +15,7 @@ What is stored (data only: inputs are regenerated from dynmm_amd.synth on both s
   nyu8_P_se.npz            BASELINE config[0] restated on 8 synthetic NYUv2-like pairs, 480x640,
                            eval --baseline: strided logits, argmax histogram, CM and mIoU.
   ops.npz                  DiffSoftmax cases, Upsample fixed init, CE loss, temperature schedule.
+  valid_loss.npz           validate()'s weighted / unweighted validation losses from the reference's own classes.
   esanet_P_se_96x128.npz   the STATIC model (src/models/model.py:19-241, what build_model returns without --dynamic):
                            state_dict contract, eval logits, train outputs + gradient norms / samples.
   skip_P_96x128.npz        SkipESANet (per-stage Gumbel gates, model_skip_mod.py): per mode the Exp(1) draws
@@ -226,6 +227,32 @@ def ops_fixture():
     blob['temp/epochs'] = np.array([0, 1, 50, 299, 300, 400])
     blob['temp/values'] = np.array([sched.get_t(int(e)) for e in blob['temp/epochs']])
     np.savez_compressed(os.path.join(HERE, 'ops.npz'), **blob)
+
+
+def valid_loss_fixture():
+    """validate()'s two losses exactly as train.py:104-115 builds them and :432-440 feeds them: the reference's own
+    CrossEntropyLoss2dForValidData (weighted_pixel_sum = sum_c pixels_c * w_c over the validation labels) and
+    CrossEntropyLoss2dForValidDataUnweighted (src/utils.py:53-97), two batches added, then compute_whole_loss()."""
+    r = np.random.Generator(np.random.PCG64(11))
+    cw = r.uniform(0.5, 2.0, size=40).astype(np.float32)
+    xs = [torch.from_numpy(r.standard_normal(size=(3, 40, 12, 14)).astype(np.float32) * 2) for _ in range(2)]
+    ts = [torch.from_numpy(r.integers(0, 41, size=(3, 12, 14)).astype(np.uint8)) for _ in range(2)]
+    pixels = np.zeros(40)
+    for t in ts:
+        pixels += np.bincount(t.numpy().reshape(-1), minlength=41)[1:]          # dataset.compute_class_weights('linear')
+    wps = np.sum(pixels * cw)
+    lw = ref_utils.CrossEntropyLoss2dForValidData(torch.device('cpu'), cw, wps)
+    lu = ref_utils.CrossEntropyLoss2dForValidDataUnweighted(torch.device('cpu'))
+    lw.reset_loss()
+    lu.reset_loss()
+    for x, t in zip(xs, ts):
+        lw.add_loss_of_batch(x, t.long())
+        lu.add_loss_of_batch(x, t.long())
+    blob = {'weight': cw, 'weighted_pixel_sum': np.float64(wps),
+            'loss_weighted': np.float64(lw.compute_whole_loss()), 'loss_unweighted': np.float64(lu.compute_whole_loss())}
+    for i in range(2):
+        blob[f'x{i}'], blob[f't{i}'] = xs[i].numpy(), ts[i].numpy()
+    np.savez_compressed(os.path.join(HERE, 'valid_loss.npz'), **blob)
 
 
 def train_steps_fixture():
@@ -465,6 +492,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'r50':
         model_fixture('R50_se', 96, 128, 2, ['eval_hard', 'train_soft'])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'valid':
+        valid_loss_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'esanet':
         esanet_fixture()

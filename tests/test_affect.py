@@ -360,3 +360,51 @@ def test_infer_modes_record_the_gate_weights():
             assert _rel(out, want) < 1e-5, mode
     assert w0.shape == (B, 2) and bool(((w0 == 0) | (w0 == 1)).all())
     assert np.isfinite(m.cal_flop())
+
+
+@pytest.mark.gpu
+def test_configs4_batch128_properties():
+    """BASELINE configs[4] per GPU at its OWN size (DynMMNetV2, batch 128, T = 50; checker = the self-written oracle:
+    PARITY UNPINNED).  Eval-mode arithmetic is per sample, so
+      * the batch-128 forward equals two batch-64 forwards of its halves, sample by sample;
+      * a batch permutation permutes outputs and gate weights and leaves the mean gate regulariser unchanged;
+      * the first 4 samples agree with the oracle (2e-4, the small-batch bar);
+      * one full training step (dropout on, clip + AdamW, hipGraph off) is finite and touches every trainable parameter."""
+    from dynmm_amd.nn import affect as A
+    from oracle import affect_oracle as O
+    ref = O.fill_(O.DynMMNetV2(0.7, False), seed=1)
+    mine = A.DynMMNetV2(0.7, False)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda().eval()
+    inputs, y = O.synth_batch(128, seed=5)
+    xs, lens = [x.cuda() for x in inputs[0]], inputs[1]
+    assert xs[0].shape[:2] == (128, 50)
+
+    def sub(idx):
+        li = idx if isinstance(idx, slice) else idx.cpu()
+        return [[x[idx].contiguous() for x in xs], [l[li] for l in lens]]
+    with torch.no_grad():
+        out, aux = mine([xs, lens])
+        oa, aux_a = mine(sub(slice(0, 64)))
+        ob, aux_b = mine(sub(slice(64, 128)))
+        perm = torch.randperm(128, generator=torch.Generator().manual_seed(3)).cuda()
+        op, aux_p = mine(sub(perm))
+    scale = out.abs().max().item()
+    assert bool(torch.isfinite(out).all())
+    assert (torch.cat([oa, ob]) - out).abs().max().item() <= 2e-6 * scale
+    assert abs(0.5 * (aux_a.item() + aux_b.item()) - aux.item()) < 1e-6
+    assert (op - out[perm]).abs().max().item() <= 2e-6 * scale and abs(aux_p.item() - aux.item()) < 1e-6
+    with torch.no_grad():
+        out_r, aux_r, _ = ref([[x[:4] for x in inputs[0]], [l[:4] for l in lens]])
+        o4, _ = mine(sub(slice(0, 4)))
+    assert _rel(o4, out_r) < 2e-4
+    assert (o4 - out[:4]).abs().max().item() <= 2e-6 * scale
+    mine.train()
+    step = A.AffectTrainStep(mine, lr=1e-4, weight_decay=0.01, lossw=0.2, use_graph=False)
+    res = step([xs, lens], y.cuda())
+    torch.cuda.synchronize()
+    assert np.isfinite(res['total'].item())
+    step.opt.check_finite()
+    for n_, p in mine.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n_

@@ -30,6 +30,22 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['steps'] == 4
 
 
+def test_eight_ranks_like_the_scaling_run():
+    """the driver's largest point (8 x MI355X): launcher, rendezvous on 127.0.0.1 with a free port, the host-thread split
+    (OMP_NUM_THREADS = cpus / ranks, so 8 ranks do not oversubscribe the host 8-fold), dmabuf IPC for RCCL, and still
+    exactly ONE JSON line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'OMP_NUM_THREADS')}
+    env.update(DYNMM_BENCH_LAUNCH_PROBE='1')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == 8 and line['steps'] == 3
+    assert int(line['omp_num_threads']) == max(1, (os.cpu_count() or 8) // 8)
+    assert line['master'].startswith('127.0.0.1:') and line['ipc_mode_legacy'] == '0'
+
+
 def test_single_rank_does_not_spawn():
     r = _run(['--gpus', '1'])
     assert r.returncode == 0, r.stderr[-2000:]

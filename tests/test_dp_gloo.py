@@ -42,10 +42,17 @@ def _worker(rank, world, port, overlap, q):
     torch.manual_seed(100)
     x = torch.randn(4, 3, 8, 8)
     lo, hi = dp.shard_batch(4, rank, world)
-    for _ in range(2):                 # two steps: zero() must reset state
+    for it in range(2):                # two steps: zero() must reset state
         red.zero()
         (m(x[lo:hi]).sum() / 4.0).backward()     # mean over the GLOBAL batch, per-rank share
-        red.finish()
+        if it == 0:
+            red.finish()
+            assert red.pending_scale == 1.0
+        else:
+            # what engine.TrainStep does: keep the SUM, hand 1/world to the optimizer kernel's grad_scale
+            red.finish(average=False)
+            assert red.pending_scale == 1.0 / world
+            red.flat.mul_(red.pending_scale)
     # numpy payloads: a torch tensor on an mp.Queue travels as a file descriptor the parent must fetch from a
     # still-living child; numpy arrays are pickled by value, so the worker may exit right after put()
     q.put((rank, [p.grad.numpy().copy() for p in m.parameters()], [p.detach().numpy().copy() for p in m.parameters()],

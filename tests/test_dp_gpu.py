@@ -65,8 +65,23 @@ def _worker(rank, world, port, q):
     step.opt.step(step._touched, step.last['total'])
     torch.cuda.synchronize()
     n_diff = int((reduced != want).sum().item())
+    manual = step.flatp.flat.clone()
+    # (3) the product call: the all-reduce leaves the SUM and 1/world goes into the optimizer kernel's grad_scale
+    # (no pass over the flat gradient buffer) — same parameters as the averaged path above, bit for bit (x0.5 is exact),
+    # and the per-step total it returns must survive the next step's zero() (train.py keeps one per step)
+    m.load_state_dict(sd)
+    step.opt.buf.zero_()
+    step.opt.steps.zero_()
+    out1 = step(rgb, depth, labels)
+    total1 = out1['total']
+    t1 = float(total1.item())
+    folded = step.flatp.flat.clone()
+    summed = red.flat.clone()
+    step(rgb, depth, labels)
+    fold = (int((folded != manual).sum().item()), int((summed != both[0] + both[1]).sum().item()),
+            float(total1.item()) == t1, t1)
     q.put((rank, in_bwd, nb, log, (n_diff, float((reduced - want).abs().max()), float(want.abs().max())),
-           reduced.cpu().numpy(), step.flatp.flat.cpu().numpy(), float((local - want).abs().max())))
+           reduced.cpu().numpy(), step.flatp.flat.cpu().numpy(), float((local - want).abs().max()), fold))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,11 +97,14 @@ def test_real_model_two_ranks_overlap_and_exact_mean():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, in_bwd, nb, log, exact, reduced, params, spread in res:
+    for rank, in_bwd, nb, log, exact, reduced, params, spread, fold in res:
         assert in_bwd == nb, (rank, in_bwd, nb, log)           # every bucket launched from inside backward
         assert all(where == 'backward' for _, where in log), log
         assert exact[0] == 0, (rank, exact)                      # reduced == mean of the per-rank gradients, bit for bit
         assert spread > 0                                        # the two shards really had different gradients
+        assert fold[0] == 0 and fold[1] == 0, fold               # 1/world folded into the optimizer == averaged buffer
+        assert fold[2] and np.isfinite(fold[3]), fold            # step k's total is not aliased by step k+1
+    assert res[0][8][3] == res[1][8][3]                          # ... and is the mean over ranks on both
     assert np.array_equal(res[0][5], res[1][5])                  # replicas agree on the reduced gradient
     assert np.array_equal(res[0][6], res[1][6])                  # ... and on the updated parameters
 

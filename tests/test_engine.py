@@ -397,3 +397,78 @@ def test_prepacked_weights_step_is_bit_identical(monkeypatch):
         assert torch.equal(v, res[False][1][k]), k
     for k, v in res[True][2].items():
         assert torch.equal(v, res[False][2][k]), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# validate(): validation losses + per-camera mIoU (train.py:368-551)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_validation_losses_match_reference_fixture(golden_dir):
+    """dynmm_ce2d_valid (one pass: weighted sum, weight sum, unweighted sum, pixel count) accumulated over two batches
+    vs the reference's CrossEntropyLoss2dForValidData / ...Unweighted (tests/golden/valid_loss.npz)."""
+    from dynmm_amd import ops
+    g = np.load(os.path.join(golden_dir, 'valid_loss.npz'))
+    cw = torch.from_numpy(g['weight']).cuda()
+    acc = torch.zeros(4, dtype=torch.float64, device='cuda')
+    for i in range(2):
+        ops.validation_loss_accumulate(torch.from_numpy(g[f'x{i}']).cuda(), torch.from_numpy(g[f't{i}']).cuda(), cw, acc)
+    sw, ws, su, npx = acc.tolist()
+    assert abs(ws - float(g['weighted_pixel_sum'])) < 1e-6 * ws       # = sum_c pixels_c * w_c of the labels (train.py:104-108)
+    assert abs(sw / float(g['weighted_pixel_sum']) - float(g['loss_weighted'])) < 2e-6 * float(g['loss_weighted'])
+    assert abs(su / npx - float(g['loss_unweighted'])) < 2e-6 * float(g['loss_unweighted'])
+    assert npx == sum(int((g[f't{i}'] > 0).sum()) for i in range(2))
+
+
+@pytest.mark.gpu
+def test_validate_mirrors_the_reference_protocol():
+    """engine.validate = train.py:368-551: hard gates unless soft_eval, one confusion matrix per camera, mIoU per camera,
+    weighted + unweighted validation loss; every number against the oracle evaluated on the same (HIP) logits, and the
+    model's mode / gate flag restored afterwards."""
+    from dynmm_amd import engine
+    from dynmm_amd.data import SyntheticRGBD
+    from dynmm_amd.nn.net import SkipGateESANet
+    from oracle import dynmm_oracle as O
+    h, w = 96, 128
+    m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+    synth.fill_state_dict(m.state_dict(), 0)
+    m = m.cuda().train()
+    m.hard_gate = False
+    cw = np.linspace(0.5, 2.0, 40)
+    cams = {'kv1': SyntheticRGBD(6, 4, h, w, seed=5, device='cuda'), 'xtion': SyntheticRGBD(3, 3, h, w, seed=9, device='cuda')}
+    miou, logs = engine.validate(m, cams, cw, split='test')
+    assert m.training and m.hard_gate is False
+    assert set(miou) == {'kv1', 'xtion'}
+    for k in ('loss_test', 'loss_test_unweighted', 'mIoU_test_kv1', 'mIoU_test_xtion', 'time_validation'):
+        assert k in logs, k
+    m.eval()
+    m.hard_gate = True
+    xs, ts = [], []
+    for cam, loader in cams.items():
+        cm = torch.zeros(40, 40, dtype=torch.int64)
+        for s in loader:
+            with torch.no_grad():
+                logits = m(s['image'], s['depth'], True).cpu()
+            xs.append(logits)
+            ts.append(s['label'].cpu())
+            lab, pred = O.eval_postprocess(logits, s['label_orig'].cpu().long())
+            cm += O.confusion_matrix(lab, pred, 40)
+        assert torch.equal(cm, logs['confusion_matrices'][cam])
+        assert abs(100 * float(O.iou_from_cm(cm)[1]) - miou[cam]) < 1e-9
+    lw, lu = O.validation_losses(xs, ts, cw)
+    assert abs(lw - logs['loss_test']) < 1e-5 * lw and abs(lu - logs['loss_test_unweighted']) < 1e-5 * lu
+
+
+def test_legacy_flat_optimizer_checkpoints_load_into_the_right_buffers():
+    """the rounds-1-2 checkpoint layout ({'exp_avg': flat, 'exp_avg_sq': flat, 'steps': ...}) must restore Adam's
+    two moment buffers (it used to copy exp_avg into v and exp_avg_sq into the int32 step counters)."""
+    from dynmm_amd import engine
+    ps = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(3, 2))]
+    fp = engine.FlatParameters(ps)
+    grads = torch.zeros_like(fp.flat)
+    adam = engine.Adam(fp, grads, lr=1e-3)
+    sd = {'exp_avg': torch.arange(11.0), 'exp_avg_sq': torch.arange(11.0) * 2, 'steps': torch.tensor([7], dtype=torch.int32)}
+    adam.load_state_dict(sd)
+    assert torch.equal(adam.m, sd['exp_avg']) and torch.equal(adam.v, sd['exp_avg_sq']) and int(adam.steps[0]) == 7
+    sgd = engine.SGDNesterov(fp, grads, lr=1e-3)
+    sgd.load_state_dict({'momentum_buffer': torch.arange(11.0) * 3, 'steps': torch.tensor([2], dtype=torch.int32)})
+    assert torch.equal(sgd.buf, torch.arange(11.0) * 3) and int(sgd.steps[0]) == 2

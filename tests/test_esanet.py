@@ -209,3 +209,29 @@ def test_resume_reproduces_the_next_step(tmp_path, optimizer):
         assert torch.equal(a, b), k
     with pytest.raises(FileNotFoundError):
         load_ckpt(m2, s2.opt, str(tmp_path / 'missing.pth'))
+
+
+@pytest.mark.gpu
+def test_esanet_through_evaluate_and_the_train_driver(tmp_path):
+    """build_model returns ESANet for non-dynamic runs, and both callers of a model — engine.evaluate
+    (eval.py / validate: model(rgb, depth, test=True)) and the training driver with its epoch-0 validation — must accept
+    it.  Also the resume protocol of train.py:207 (validation at the FIRST epoch of a resumed run) and the rule that a
+    resume without a new best does not overwrite the best checkpoint's file."""
+    from dynmm_amd import engine, train
+    m = esanet()
+    synth.fill_state_dict(m.state_dict(), seed=0)
+    m = m.cuda().eval()
+    rgb, depth = synth.synth_inputs(2, 96, 128, seed=5, device='cuda')
+    label = synth.synth_labels(2, 96, 128, seed=6, device='cuda')
+    miou, cm = engine.evaluate(m, [(rgb, depth, label)], num_classes=40)
+    assert np.isfinite(miou) and int(cm.sum()) == int((label > 0).sum())
+    with torch.no_grad():
+        out, weight = m(rgb, depth, test=True, return_weight=True)
+    assert out.shape == (2, 40, 96, 128) and torch.equal(weight.cpu()[:, 4], torch.ones(2))   # no gate: always "fuse all"
+    common = ['--encoder', 'resnet34', '--encoder_block', 'NonBottleneck1D', '--decoder_channels_mode', 'constant',
+              '--no_imagenet_pretraining', '--dataset', 'synthetic', '--height', '96', '--width', '128',
+              '--batch_size', '4', '--synthetic_samples', '8', '--eval-every', '5', '--results_dir', str(tmp_path)]
+    logs = train.train_main(common + ['--epochs', '2'])
+    assert len(logs) == 2 and all(np.isfinite(r['loss_train_total']) for r in logs)
+    assert 'mIoU_test_kv1' in logs[0] and 'loss_test' in logs[0] and 'loss_test_unweighted' in logs[0]
+    assert 'mIoU_test' not in logs[1]                       # eval_every = 5: only the first epoch validates

@@ -628,3 +628,67 @@ def test_configs1_forward_only_batch16_properties():
     with torch.no_grad():
         ref = O.forward(sd, rgb[:2].cpu(), depth[:2].cpu(), Hh.CFGS['P_se'], test=True, baseline=True)
     assert Hh.rel_err(out[:2].cpu(), ref) < LOGIT_TOL
+
+
+def test_configs3_hard_gate_compaction_at_its_own_size():
+    """BASELINE configs[3] per GPU at its FULL size (batch 32, 480x640, hard gates, the uniform synthetic branch distribution
+    k = n mod 5 the bench line is quoted on, `compact_train` on), where the oracle is too slow:
+      * the real training step (BatchNorm batch statistics, weighted 4-scale CE + FLOP loss): stage batches 25/18/12/6,
+        finite losses and gradients, EVERY parameter receives a gradient (also the depth stages that ran on a 6-sample
+        prefix and the gate, through its straight-through term);
+      * with BatchNorm in eval mode — the only per-batch coupling of the depth path — the compacted forward and backward
+        equal the dense ones on every non-gate parameter (2e-4): sorted-prefix stages, pass-through of skipped samples,
+        permutation and un-permutation at 480x640 tile counts, not only at 96x128."""
+    from dynmm_amd import engine
+    h, w, n = 480, 640, 32
+    branches = [i % 5 for i in range(n)]
+    rgb, depth = synth.synth_inputs(n, h, w, seed=21, device='cuda')
+    labels = [synth.synth_labels(n, h // s, w // s, seed=50 + s, device='cuda').to(torch.uint8) for s in (1, 8, 16, 32)]
+    m = hip_model('P_se', h, w, seed=3)
+    m.train()
+    m.hard_gate, m.temp = True, 0.7
+    m.branch_override, m.compact_train = branches, True
+    step = engine.TrainStep(m, np.linspace(0.5, 2.0, 40).astype(np.float32), lr=0.0, loss_ratio=0.5, flop_budget=0.0)
+    step._body(rgb, depth, labels)
+    torch.cuda.synchronize()
+    assert m.last_stage_batch == [25, 18, 12, 6]
+    assert torch.isfinite(step.last['losses']).all() and torch.isfinite(step.last['total']).all()
+    grads = torch.cat([p.grad.detach().flatten() for p in m.parameters()])
+    assert torch.isfinite(grads).all()
+    assert len(step._touched) == sum(1 for _ in m.parameters())
+    dead = [k for k, p in m.named_parameters() if p.grad.abs().max().item() == 0 and 'gate_layer.conv' not in k]
+    assert not dead, dead[:8]
+    del step, m, grads
+    torch.cuda.empty_cache()
+
+    res = {}
+    probe = None
+    for compact in (False, True):
+        m = hip_model('P_se', h, w, seed=3)
+        m.eval()                                   # BN: running statistics; gradients are still recorded below
+        m.hard_gate, m.temp = True, 0.7
+        m.branch_override, m.compact_train = branches, compact
+        out, lf = m(rgb, depth)
+        assert (m.last_stage_batch == [25, 18, 12, 6]) if compact else (m.last_stage_batch is None)
+        if probe is None:
+            probe = Hh.grad_probe((2, 40, 96, 128), 'c').cuda().repeat(16, 1, 5, 5)       # a fixed non-uniform seed gradient
+        (out * probe).mean().backward()
+        torch.cuda.synchronize()
+        res[compact] = (out.detach()[:, :, ::8, ::8].clone(), lf.detach(),
+                        {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        del out, m
+        torch.cuda.empty_cache()
+    (od, ld, gd), (oc, lc, gc) = res[False], res[True]
+    assert Hh.rel_err(oc.cpu(), od.cpu()) < 1e-5 and abs(lc.item() - ld.item()) < 1e-6
+    gmax = max(v.abs().max().item() for v in gd.values())
+    upstream = ('gate', 'encoder_rgb.conv1', 'encoder_rgb.bn1', 'encoder_depth.conv1', 'encoder_depth.bn1', 'se_layer0')
+    checked, worst = 0, (0.0, None)
+    for k, g in gd.items():
+        if any(u in k for u in upstream) or g.abs().max().item() < 1e-6 * gmax:
+            continue
+        e = _rl2(gc[k].cpu(), g.cpu())
+        worst = max(worst, (e, k))
+        assert e < 2e-4, (k, e)
+        checked += 1
+    print(f'configs[3] batch 32: compacted vs dense non-gate gradients, worst rel-L2 {worst[0]:.2e} ({worst[1]}), {checked} tensors')
+    assert checked > 400

@@ -102,6 +102,18 @@ def test_ops_fixture(golden_dir):
         assert abs(O.exp_decay_temp(1.0, 0.001, 300, int(e)) - v) < 1e-12
 
 
+def test_validation_losses_fixture(golden_dir):
+    """oracle.validation_losses vs the reference's CrossEntropyLoss2dForValidData / ...Unweighted (src/utils.py:53-97)"""
+    g = np.load(os.path.join(golden_dir, 'valid_loss.npz'))
+    xs = [torch.from_numpy(g[f'x{i}']) for i in range(2)]
+    ts = [torch.from_numpy(g[f't{i}']) for i in range(2)]
+    lw, lu = O.validation_losses(xs, ts, g['weight'], float(g['weighted_pixel_sum']))
+    assert abs(lw - float(g['loss_weighted'])) < 1e-5 * abs(float(g['loss_weighted']))
+    assert abs(lu - float(g['loss_unweighted'])) < 1e-5 * abs(float(g['loss_unweighted']))
+    lw2, _ = O.validation_losses(xs, ts, g['weight'])          # weighted_pixel_sum accumulated from the same labels
+    assert abs(lw2 - lw) < 1e-6 * abs(lw)
+
+
 def test_reference_known_answers():
     """The reference's only self-checks: confusion-matrix example (src/confusion_matrix.py:181-198)
     and the R34 MAC table relation total - no-weight = gate cost (…globalgate.py:419-424)."""
