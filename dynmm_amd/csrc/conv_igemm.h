@@ -25,16 +25,6 @@ struct IgemmArgs {
     int M, K, CoP;
     int CiR;               // weight rows per filter tap: Ci, or Ci rounded up to 16 (zero rows) when 8 <= Ci, Ci % 16 != 0
     int n_co_tiles, n_pix_tiles;
-    float* ws;             // operand-ring kernels, K split over `ksplit` workgroups per tile: partial accumulator tiles
-    unsigned* flags;       //   [tiles][256 threads][accumulators] and one arrival counter per tile (zeroed by the launcher)
-    int ksplit;            // 1: no split
-    float* stats;          // operand-ring kernels, [n_pix_tiles][2][Co] per pixel tile and channel, or nullptr.  Forward: sum and
-                           //   sum of squares of the OUTPUT (BatchNorm batch statistics without a pass over y).  Input gradient:
-                           //   sum of the OUTPUT g and of g * xhat, xhat = (bn_x - bn_mean[c]) * bn_invstd[c] (the two reductions
-                           //   of the BatchNorm backward whose output this convolution consumes, without a pass over g and x)
-    const float* bn_x;     //   like y: the BatchNorm's input
-    const float* bn_mean;  //   [Co]
-    const float* bn_invstd;
     int subpix;            // DGRAD with stride > 1 and Ho % SH == Wo % SW == 0: output pixels are enumerated
                            // parity class by parity class (see pix_decode), so a tile is (mostly) class-pure
 };
@@ -104,11 +94,6 @@ __device__ unsigned long long* g_trace = nullptr;   // [gridDim.x][6]: wall cloc
 // The operand-ring kernels (conv_igemm_v5.hip).  `eligible` is a pure function of the geometry / pointers, so callers
 // may use it to predict which kernel a launch gets; `launch` returns false when the shape is not eligible.
 bool igemm_v5_eligible(const IgemmArgs& a, bool dgrad);
-bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0);
-// K-split the launcher would use for this geometry given a workspace (1 = none) and the bytes it needs
-int igemm_v5_ksplit(const IgemmArgs& a, bool dgrad);
-size_t igemm_v5_workspace_bytes(const IgemmArgs& a, bool dgrad);
-// pixel tiles of the launch = rows of the [tiles][2][Co] statistics partials (IgemmArgs::stats)
-int igemm_v5_pix_tiles(const IgemmArgs& a);
+bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st);
 
 }  // namespace dynmm

@@ -502,7 +502,7 @@ static int env_int(const char* name) {
 }
 
 template <bool DGRAD>
-static int launch_igemm(IgemmArgs& a, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0) {
+static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     static const int force_tpix = env_int("DYNMM_IGEMM_TPIX");
     static const int force_tpix64 = env_int("DYNMM_IGEMM_TPIX_C64");
     const bool dual_in = a.x2 != nullptr;
@@ -514,7 +514,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st, void* workspace = nullptr,
     a.CoP = (a.Co + 3) & ~3;
     static const int no_subpix = env_int("DYNMM_NO_SUBPIX");
     a.subpix = (DGRAD && !generic && !no_subpix && a.SH * a.SW > 1 && a.Ho % a.SH == 0 && a.Wo % a.SW == 0) ? 1 : 0;
-    if (!generic && launch_igemm_v5(a, DGRAD, st, workspace, workspace_bytes)) {      // stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3: the operand-ring kernels
+    if (!generic && launch_igemm_v5(a, DGRAD, st)) {      // stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3: the operand-ring kernels
         DYNMM_LAUNCH_CHECK();
         return DYNMM_OK;
     }
@@ -1403,13 +1403,6 @@ extern "C" int dynmm_pack_weight_multi(const float* src_base, float* dst_base, c
 extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
                                 const float* scale, const float* shift, const float* residual,
                                 float* y, const dynmm_conv_geom* g, int act, void* stream) {
-    return dynmm_conv2d_fwd_ws(x, x2, wp_fwd, scale, shift, residual, y, g, act, nullptr, 0, stream);
-}
-
-extern "C" int dynmm_conv2d_fwd_ws(const float* x, const float* x2, const float* wp_fwd,
-                                   const float* scale, const float* shift, const float* residual,
-                                   float* y, const dynmm_conv_geom* g, int act, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !wp_fwd || !y || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (x2 != nullptr)) return DYNMM_EINVAL;
@@ -1426,50 +1419,12 @@ extern "C" int dynmm_conv2d_fwd_ws(const float* x, const float* x2, const float*
         if (small_conv_fwd_eligible(s, residual)) return launch_small_conv_fwd(s, (hipStream_t)stream);
         if (stem_conv_fwd_eligible(s, residual)) return launch_stem_conv_fwd(s, (hipStream_t)stream);
     }
-    return launch_igemm<false>(a, (hipStream_t)stream, workspace, workspace_bytes);
-}
-
-static void stats_args(IgemmArgs& a, const dynmm_conv_geom* g) {
-    a.N = g->N; a.Ci = g->Ci; a.H = g->H; a.W = g->W;
-    a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo;
-    a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
-    a.c_in_split = g->c_split; a.c_out_split = g->Co; a.act = DYNMM_ACT_NONE;
-}
-
-extern "C" int dynmm_conv2d_stats_tiles(const dynmm_conv_geom* g) {
-    if (!geom_ok(g) || g->c_split < g->Ci) return 0;
-    IgemmArgs a{};
-    stats_args(a, g);
-    a.x = a.wp = reinterpret_cast<const float*>(uintptr_t(4096));       // (alignment is checked again at the call)
-    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, false)) return 0;
-    return igemm_v5_pix_tiles(a);
-}
-
-extern "C" int dynmm_conv2d_fwd_stats(const float* x, const float* wp_fwd, const float* bias, float* y, float* stats,
-                                      size_t stats_floats, const dynmm_conv_geom* g, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
-    (void)hipGetLastError();
-    if (!x || !wp_fwd || !y || !stats || !geom_ok(g) || g->c_split < g->Ci) return DYNMM_EINVAL;
-    IgemmArgs a{};
-    stats_args(a, g);
-    a.x = x; a.wp = wp_fwd; a.shift = bias; a.y = y;
-    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, false)) return DYNMM_EUNSUPPORTED;
-    if (stats_floats < (size_t)igemm_v5_pix_tiles(a) * 2 * (size_t)g->Co) return DYNMM_EWORKSPACE;
-    a.stats = stats;
-    if (!launch_igemm_v5(a, false, (hipStream_t)stream, workspace, workspace_bytes)) return DYNMM_EUNSUPPORTED;
-    DYNMM_LAUNCH_CHECK();
-    return DYNMM_OK;
+    return launch_igemm<false>(a, (hipStream_t)stream);
 }
 
 extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
                                   const float* accum, float* dx, float* dx2,
                                   const dynmm_conv_geom* g, void* stream) {
-    return dynmm_conv2d_dgrad_ws(dy, wp_dgrad, mask, accum, dx, dx2, g, nullptr, 0, stream);
-}
-
-extern "C" int dynmm_conv2d_dgrad_ws(const float* dy, const float* wp_dgrad, const float* mask,
-                                     const float* accum, float* dx, float* dx2,
-                                     const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!dy || !wp_dgrad || !dx || !geom_ok(g)) return DYNMM_EINVAL;
     if ((g->c_split < g->Ci) != (dx2 != nullptr)) return DYNMM_EINVAL;
@@ -1481,42 +1436,7 @@ extern "C" int dynmm_conv2d_dgrad_ws(const float* dy, const float* wp_dgrad, con
     a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W;
     a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
     a.c_in_split = g->Co; a.c_out_split = g->c_split; a.act = DYNMM_ACT_NONE;
-    return launch_igemm<true>(a, (hipStream_t)stream, workspace, workspace_bytes);
-}
-
-static void dgrad_args(IgemmArgs& a, const dynmm_conv_geom* g) {
-    // the GEMM's input is dy [N,Co,Ho,Wo], its output dx [N,Ci,H,W]
-    a.N = g->N; a.Ci = g->Co; a.H = g->Ho; a.W = g->Wo;
-    a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W;
-    a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
-    a.c_in_split = g->Co; a.c_out_split = g->c_split; a.act = DYNMM_ACT_NONE;
-}
-
-extern "C" int dynmm_conv2d_dgrad_stats_tiles(const dynmm_conv_geom* g) {
-    if (!geom_ok(g) || g->c_split < g->Ci) return 0;
-    IgemmArgs a{};
-    dgrad_args(a, g);
-    a.x = a.wp = reinterpret_cast<const float*>(uintptr_t(4096));       // (alignment is checked again at the call)
-    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, true)) return 0;
-    return igemm_v5_pix_tiles(a);
-}
-
-extern "C" int dynmm_conv2d_dgrad_bnstats(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
-                                          float* dx, const float* bn_x, const float* bn_mean, const float* bn_invstd,
-                                          float* stats, size_t stats_floats, const dynmm_conv_geom* g, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
-    (void)hipGetLastError();
-    if (!dy || !wp_dgrad || !dx || !bn_x || !bn_mean || !bn_invstd || !stats || !geom_ok(g) || g->c_split < g->Ci)
-        return DYNMM_EINVAL;
-    IgemmArgs a{};
-    dgrad_args(a, g);
-    a.x = dy; a.wp = wp_dgrad; a.mask = mask; a.residual = accum; a.y = dx;
-    if (round_k(a.Ci) != a.Ci || !igemm_v5_eligible(a, true)) return DYNMM_EUNSUPPORTED;
-    if (stats_floats < (size_t)igemm_v5_pix_tiles(a) * 2 * (size_t)g->Ci) return DYNMM_EWORKSPACE;
-    a.stats = stats; a.bn_x = bn_x; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
-    if (!launch_igemm_v5(a, true, (hipStream_t)stream, workspace, workspace_bytes)) return DYNMM_EUNSUPPORTED;
-    DYNMM_LAUNCH_CHECK();
-    return DYNMM_OK;
+    return launch_igemm<true>(a, (hipStream_t)stream);
 }
 
 static void launch_wgrad_generic(const WgradArgs& a, const WgradGroup& grp, const WgradPlan& p, dim3 grid, bool dual,

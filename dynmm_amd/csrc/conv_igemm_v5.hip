@@ -31,19 +31,6 @@ namespace dynmm {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
-// sum over the 16 lanes of a DPP row (every lane of the row ends up with it): quad butterflies, then the two mirrors
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_row_sum16(float v) {
-    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);      // row_half_mirror
-    v = dpp_add<0x140>(v);      // row_mirror
-    return v;
-}
-
 template <int TCO, int TPIX, int WCO, int WPIX, int KW, bool DGRAD, int SA, int SB>
 __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a) {
     // ring depths: SA weight stages; SB activation stages (KW = 3: two stages of three K-steps each; KW = 1: one per step)
@@ -75,18 +62,12 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     const int wave_co = wave / WAVES_PIX, wave_pix = wave % WAVES_PIX;
     const int khalf = lane >> 5, l31 = lane & 31;
 
-    // K split (a.ksplit > 1, grids that would leave most CUs with less than three workgroups): workgroups
-    // [s * nblk, (s + 1) * nblk) handle channel chunks [s, s + 1) * NC of every tile; split s is dispatched before split s + 1,
-    // which is what makes the partial-sum hand-off below deadlock-free
     const int nblk = a.n_co_tiles * a.n_pix_tiles;
-    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
-    const int split = ksplit > 1 ? (int)blockIdx.x / nblk : 0;
-    const int lin = xcd_remap((int)blockIdx.x - split * nblk, nblk);
+    const int lin = xcd_remap((int)blockIdx.x, nblk);
     const int co0 = (lin % a.n_co_tiles) * TCO;
     const int pix0 = (lin / a.n_co_tiles) * TPIX;
     const int HW = a.H * a.W;
-    const int NC = a.Ci / BK / ksplit;           // channel chunks of this workgroup
-    const int cbase = split * NC;                //   ... starting at this chunk
+    const int NC = a.Ci / BK;                    // channel chunks
     const int nB = a.KH * NC;                    // activation stages (vertical tap, chunk)
     const int nsteps = nB * KW;                  // K-steps (one weight stage each)
 
@@ -123,7 +104,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     int lb_t = 0, lb_r = 0, lb_c = 0;             // next activation stage to request
     auto issue_a = [&]() {
         if (la_t < nsteps) {
-            const float* base = a.wp + (size_t)((la_r * KW + la_s) * a.CiR + (cbase + la_c) * BK + wave * NIA * RPI) * a.CoP;
+            const float* base = a.wp + (size_t)((la_r * KW + la_s) * a.CiR + la_c * BK + wave * NIA * RPI) * a.CoP;
             const unsigned dst = lds_a + (unsigned)(((la_t % SA) * A_STAGE + wave * NIA * 256) * 4);
 #pragma unroll
             for (int i = 0; i < NIA; ++i) dma16(base + (size_t)(i * RPI) * a.CoP, a_voff, dst + i * 1024);
@@ -136,7 +117,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     };
     auto issue_b = [&]() {
         if (lb_t < nB) {
-            const float* base = a.x + (size_t)((cbase + lb_c) * BK) * HW;
+            const float* base = a.x + (size_t)(lb_c * BK) * HW;
             const unsigned dst = lds_b + (unsigned)(((lb_t % SB) * B_STAGE + wave * QPW * 4) * 4);
             const int shift = dh_of(lb_r) * a.W * 4;
 #pragma unroll
@@ -292,57 +273,6 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
     __syncthreads();                               // every wave is done with the operand rings: As is reused below
     DYNMM_TRACE_MARK(2);
 
-    // ---------------------------------------------------------------- K split: ordered partial-sum hand-off
-    // Split s waits until the tile's counter reads s, adds the running sum of splits < s (a fixed order: the result does not
-    // depend on timing), then either publishes the new running sum (s < ksplit - 1) or runs the epilogue.  Publication:
-    // plain 16-byte stores -> barrier -> lane 0: agent-scope release fence, vmcnt(0), relaxed agent store of the counter;
-    // consumption: lane 0 polls with relaxed agent loads, agent-scope acquire fence, barrier, plain loads (the cross-CU
-    // visibility recipe of the CDNA4 guide: per-XCD L2s are not coherent with each other).
-    if (ksplit > 1) {
-        float4* slot = reinterpret_cast<float4*>(a.ws) + ((size_t)lin * 256 + t) * (MCO * MPIX * 4);
-        unsigned* flag = a.flags + lin;
-        if (split > 0) {
-            if (t == 0) {
-                // bounded: the producer is always resident or finished when workgroups start in blockIdx order; if that ever
-                // failed, abort the launch (an error the caller sees) rather than hang the device
-                unsigned spins = 0;
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)split) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 26)) __builtin_trap();
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();                       // (the acquire invalidated this CU's L1: one fence serves the workgroup)
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < MPIX; ++ni)
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4) {
-                        const float4 p = slot[(mi * MPIX + ni) * 4 + j4];
-                        acc[mi][ni][4 * j4 + 0] += p.x; acc[mi][ni][4 * j4 + 1] += p.y;
-                        acc[mi][ni][4 * j4 + 2] += p.z; acc[mi][ni][4 * j4 + 3] += p.w;
-                    }
-        }
-        if (split < ksplit - 1) {
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < MPIX; ++ni)
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4)
-                        slot[(mi * MPIX + ni) * 4 + j4] = make_float4(acc[mi][ni][4 * j4 + 0], acc[mi][ni][4 * j4 + 1],
-                                                                      acc[mi][ni][4 * j4 + 2], acc[mi][ni][4 * j4 + 3]);
-            __syncthreads();
-            if (t == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(flag, (unsigned)(split + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-    }
-
     // ---------------------------------------------------------------- epilogue (as conv_igemm.hip)
     // scale/shift (bias or folded BN), residual, activation, ReLU-mask; NCHW store.  No memory wait sits between two
     // stores: per-channel scale/shift come from LDS, residual / mask values of half an accumulator tile are loaded as one
@@ -403,30 +333,13 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
             v[4 * q + 3] = acc[mi][ni][4 * j4 + 3] * sc.w + sh.w;
         }
     };
-    // BatchNorm statistics of the output (forward, a.stats): every 8-value group is summed over the 16 lanes (= pixels) of its
-    // DPP row right after it is final, the row sums meet in the (dead) activation ring, 128 | 64 threads add the rows of the
-    // tile and write one partial per channel — the finalise kernel (norm.hip) adds the tiles in a fixed order.
-    const bool want_stats = a.stats != nullptr;
-    float* const mu_lds = As + 2 * TCO;                         // input gradient: BatchNorm mean / invstd of the tile's channels
-    float* const is_lds = As + 3 * TCO;
-    const float* __restrict__ bnx_p = a.bn_x;
-    if (DGRAD && want_stats) {
-        for (int i = t; i < TCO; i += 256) {
-            mu_lds[i] = a.bn_mean[co0 + i];
-            is_lds[i] = a.bn_invstd[co0 + i];
-        }
-        __syncthreads();
-    }
-    constexpr int STAT_PARTS = WAVES_PIX * MPIX * 2;
-    float* const st_lds = Bs;                                   // [2][STAT_PARTS][TCO]
-    static_assert(2 * STAT_PARTS * TCO <= SB * B_STAGE, "statistics staging fits the activation ring");
 #pragma unroll
     for (int ni = 0; ni < MPIX; ++ni) {
         const int m = pix0 + wave_pix * WPIX + ni * 32 + l31;
         const bool valid = m < a.M;
-        if (!valid && !want_stats) continue;
-        const unsigned n = (unsigned)((valid ? m : 0) / HoWo);
-        const unsigned rem = (unsigned)(valid ? m : 0) - n * (unsigned)HoWo;
+        if (!valid) continue;
+        const unsigned n = (unsigned)(m / HoWo);
+        const unsigned rem = (unsigned)m - n * (unsigned)HoWo;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
             const int cl0 = wave_co * WCO + mi * 32 + 4 * khalf;          // tile-local channel of j = 0
@@ -436,67 +349,26 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_v5_kernel(const IgemmArgs a
                 float v[8], rv[8], mv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { mv[e] = 1.f; rv[e] = 0.f; v[e] = 0.f; }
-                if (valid) {
-                    if (has_mask) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            mv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) +
-                                                                    (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
-                    }
-                    if (has_res) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            rv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) +
-                                                                    (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
-                    }
-                    scaled(v, mi, ni, cl0, h);
-                    finish(v, rv, mv);
+                if (has_mask) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
-                                                  (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
+                        mv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) +
+                                                                (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
                 }
-                if (want_stats) {
-                    const int part = ((wave_pix * MPIX + ni) * 2 + (l31 >> 4));
-                    float w[8];                                  // second factor: the value itself, or xhat of the BatchNorm input
+                if (has_res) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] = v[e];
-                    if (DGRAD) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int ch = cl0 + (e & 3) + 8 * (2 * h + (e >> 2));
-                            const float xv = valid ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bnx_p) +
-                                                         (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) : 0.f;
-                            w[e] = (xv - mu_lds[ch]) * is_lds[ch];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float r1 = dpp_row_sum16(v[e]);
-                        const float r2 = dpp_row_sum16(v[e] * w[e]);
-                        if ((l31 & 15) == 0) {
-                            const int ch = cl0 + (e & 3) + 8 * (2 * h + (e >> 2));
-                            st_lds[part * TCO + ch] = r1;
-                            st_lds[(STAT_PARTS + part) * TCO + ch] = r2;
-                        }
-                    }
+                    for (int e = 0; e < 8; ++e)
+                        rv[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) +
+                                                                (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes));
                 }
+                scaled(v, mi, ni, cl0, h);
+                finish(v, rv, mv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(y1_p) +
+                                              (off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes)) = v[e];
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-    }
-    if (want_stats) {
-        __syncthreads();
-        if (t < TCO) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int pt = 0; pt < STAT_PARTS; ++pt) {
-                s1 += st_lds[pt * TCO + t];
-                s2 += st_lds[(STAT_PARTS + pt) * TCO + t];
-            }
-            float* dst = a.stats + (size_t)(pix0 / TPIX) * 2 * a.Co + co0 + t;
-            dst[0] = s1;
-            dst[a.Co] = s2;
         }
     }
 #ifdef DYNMM_TRACE
@@ -534,71 +406,13 @@ bool igemm_v5_eligible(const IgemmArgs& a, bool dgrad) {
     return true;
 }
 
-// Tile shape the launcher picks (TCO x TPIX) and the K split it would use with a workspace.
-static void v5_tiles(const IgemmArgs& a, int& tco, int& tpix, int& tiles) {
-    tco = (a.Co % 128 == 0) ? 128 : 64;
-    tpix = tco == 128 ? 64 : 128;
-    tiles = (a.Co / tco) * ceil_div(a.N * a.Ho * a.Wo, tpix);
-}
-
-int igemm_v5_pix_tiles(const IgemmArgs& a) {
-    int tco, tpix, tiles;
-    v5_tiles(a, tco, tpix, tiles);
-    return ceil_div(a.N * a.Ho * a.Wo, tpix);
-}
-
-// Long reductions on grids that leave most CUs with fewer than three workgroups (C = 512 at 15x20, compacted depth stages)
-// split K: 2 or 4 workgroups per tile, each over a contiguous range of channel chunks (an even number of 16-channel chunks
-// per workgroup: the two-stage unroll of the K loop).
-int igemm_v5_ksplit(const IgemmArgs& a, bool dgrad) {
-    // Opt-in (DYNMM_V5_SPLITK=1).  Measured ("Round 3"): +7 % on the isolated C = 512 launches, +1.7 % on the batch-16
-    // forward-only line, nothing on the multi-stream training step — not enough to put a cross-workgroup hand-off (which
-    // relies on workgroups being dispatched in blockIdx order) on the default path.
-    static const int on = env_int_v5("DYNMM_V5_SPLITK", 0);
-    if (!on || !igemm_v5_eligible(a, dgrad)) return 1;
-    int tco, tpix, tiles;
-    v5_tiles(a, tco, tpix, tiles);
-    const int nc = a.Ci / 16;
-    const int steps = a.KH * a.KW * nc;
-    // The hand-off costs 10-20 us per launch (partial tile out through an agent-scope release, back in behind an acquire),
-    // measured on MI355X (scratch/splitk_check.py): it pays for long reductions only — 2 ways when a workgroup keeps >= 48
-    // K-steps (C = 512, three taps: 178 -> 166 us, 166 -> 154 us), 4 ways when the grid is below half a workgroup per CU
-    // (compacted depth stages: 63.5 -> 56.9 us); K = 384 / 768 tiles lose 10-45 % and stay un-split.
-    int best = 1;
-    if (nc % 4 == 0 && tiles < 768 && steps / 2 >= 48) best = 2;
-    if (nc % 8 == 0 && tiles < 192 && steps / 4 >= 24) best = 4;
-    return best;
-}
-
-size_t igemm_v5_workspace_bytes(const IgemmArgs& a, bool dgrad) {
-    const int s = igemm_v5_ksplit(a, dgrad);
-    if (s <= 1) return 0;
-    int tco, tpix, tiles;
-    v5_tiles(a, tco, tpix, tiles);
-    return (size_t)tiles * tco * tpix * sizeof(float) + (((size_t)tiles * sizeof(unsigned) + 15) & ~(size_t)15);
-}
-
-bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st, void* workspace, size_t workspace_bytes) {
+bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st) {
     if (!igemm_v5_eligible(a, dgrad)) return false;
     a.CiR = a.Ci;
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Ci;
     a.CoP = a.Co;
     a.subpix = 0;
-    a.ksplit = 1;
-    a.ws = nullptr;
-    a.flags = nullptr;
-    {
-        const size_t need = igemm_v5_workspace_bytes(a, dgrad);
-        if (need > 0 && workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) {
-            int tco, tpix, tiles;
-            v5_tiles(a, tco, tpix, tiles);
-            a.ksplit = igemm_v5_ksplit(a, dgrad);
-            a.ws = reinterpret_cast<float*>(workspace);
-            a.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + (size_t)tiles * tco * tpix * sizeof(float));
-            if (hipMemsetAsync(a.flags, 0, (size_t)tiles * sizeof(unsigned), st) != hipSuccess) return false;
-        }
-    }
     static const int sa_env = env_int_v5("DYNMM_V5_SA", 3), sb_env = env_int_v5("DYNMM_V5_SB", 3);
 #define DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, KW_, DG_)                                                                    \
     do {                                                                                                               \
@@ -617,7 +431,7 @@ bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st, void* workspace, 
     do {                                                                                                               \
         a.n_co_tiles = a.Co / TCO;                                                                                     \
         a.n_pix_tiles = ceil_div(a.M, TPIX);                                                                           \
-        dim3 grid((unsigned)(a.n_co_tiles * a.n_pix_tiles * a.ksplit));                                                \
+        dim3 grid((unsigned)(a.n_co_tiles * a.n_pix_tiles));                                                \
         if (a.KW == 3) {                                                                                               \
             if (dgrad) DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 3, true);                                                     \
             else DYNMM_V5_GO(TCO, TPIX, WCO, WPIX, 3, false);                                                          \
@@ -640,21 +454,6 @@ bool launch_igemm_v5(IgemmArgs& a, bool dgrad, hipStream_t st, void* workspace, 
 extern "C" int dynmm_debug_set_igemm_v5(int mode) {
     dynmm::g_v5_override = mode;
     return 0;
-}
-
-static void geom_to_args(const dynmm_conv_geom* g, int dgrad, dynmm::IgemmArgs& a) {
-    a.N = g->N; a.KH = g->KH; a.KW = g->KW; a.SH = g->SH; a.SW = g->SW; a.PH = g->PH; a.PW = g->PW;
-    if (dgrad) { a.Ci = g->Co; a.H = g->Ho; a.W = g->Wo; a.Co = g->Ci; a.Ho = g->H; a.Wo = g->W; }
-    else { a.Ci = g->Ci; a.H = g->H; a.W = g->W; a.Co = g->Co; a.Ho = g->Ho; a.Wo = g->Wo; }
-    a.c_out_split = a.Co;
-}
-
-// Bytes of scratch dynmm_conv2d_fwd_ws / dynmm_conv2d_dgrad_ws can use for this geometry (0: the launch is not K-split).
-extern "C" size_t dynmm_conv2d_workspace_bytes(const dynmm_conv_geom* g, int dgrad) {
-    if (!g || g->c_split != g->Ci) return 0;
-    dynmm::IgemmArgs a{};
-    geom_to_args(g, dgrad, a);
-    return dynmm::igemm_v5_workspace_bytes(a, dgrad != 0);
 }
 
 // Geometry-only form of igemm_v5_eligible (pointer alignment aside) for profiling tools that label launches:

@@ -1,0 +1,517 @@
+// Three-tap convolutions by the 1-D Winograd minimal filtering algorithm F(2,3) on the fp32 matrix cores (round 4).
+//
+// The factorised 3x1 / 1x3 convolutions of every NonBottleneck1D block (FusionDynMM/src/models/resnet.py:124-147) and the
+// decoder's 3x3 convolutions (src/models/model.py:343-357) are 81 % + 12 % of the path's MACs.  Along
+// the tap axis two neighbouring outputs (y0, y1) of a 3-tap filter g over inputs d0..d3 are
+//     m1 = (d0 - d2) g0            m2 = (d1 + d2) (g0 + g1 + g2) / 2
+//     m4 = (d1 - d3) g2            m3 = (d2 - d1) (g0 - g1 + g2) / 2            y0 = m1 + m2 + m3,   y1 = m2 - m3 - m4
+// i.e. FOUR channel contractions per output PAIR instead of six: 2/3 of the direct convolution's matrix-core work, in
+// plain fp32 arithmetic (measured against fp64, scratch/r4/wino_numerics.py: rms error 2.0e-7 .. 3.8e-7 for C = 64 .. 512
+// against 1.3e-7 .. 1.6e-7 for the direct fp32 sum).  The four contractions are four GEMMs
+//     M_i[co][pair] = sum_ci U_i[co][ci] * V_i[ci][pair]
+// with the filter transforms U_i precomputed per step (wino_pack_kernel) and the data transforms V_i formed in registers
+// from the raw input tile at the fragment read (one add per MFMA operand); the output transform is lane-local because a
+// lane of the 32x32 accumulator layout holds one pair's 16 channels for all four M_i.
+//
+// Used where it cannot move a forward result: the INPUT GRADIENT of those convolutions (the input gradient of a stride-1
+// three-tap convolution is the three-tap convolution of dy with the flipped filter) — ReLU / max-pool decisions are taken
+// in the forward pass, so the backward sees the same masks whatever its arithmetic — and, opt-in, the forward.
+//
+// Kernel structure (what the round-3 measurements say pays on this part): a wave owns 64 output
+// channels x 32 pairs x 4 transforms = 8 accumulator blocks (128 registers), so a workgroup needs only one more
+// neighbour per CU to keep the matrix pipe busy (the three-tap weight-gradient kernel's recipe: 0.73-0.77 MFMA-busy at 2
+// workgroups per CU); operands go global -> LDS by `global_load_lds_dwordx4` into a 3-slot ring requested two stages
+// ahead (hand-counted vmcnt), one barrier per 8-channel stage = 32 MFMAs per wave, fragments of k-pair q+1 are read
+// under the 8 MFMAs of k-pair q.  Tiles: (128 co x 64 pairs) for Co % 128 == 0, (64 co x 128 pairs) otherwise.
+//   * filter operand [tap row][ci][co][4 transforms]: a lane's four A values of a k-pair are ONE ds_read_b128;
+//   * horizontal taps (1x3, 3x3): the raw tile is [8 channels][2*pairs + 8] pixels (16-byte aligned quads, a 4-pixel halo
+//     either side); a lane reads (., d0) (d1, d2) (d3, .) as three conflict-free ds_read_b64;
+//   * vertical taps (3x1): the raw tile is [8 channels][4 input rows][pairs]: the four rows an output row pair needs
+//     (2x the output bytes through L2, where one gather per tap moves 3x);
+//   * zero padding: a value outside the image is replaced by 0 with a lane-constant select after the read (the load itself
+//     is never predicated: an out-of-image row is replaced by a mapped one); for the 3x3 filter a whole vertical tap
+//     outside the image points the reads at an all-zero slot.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_igemm.h"
+
+namespace dynmm {
+
+struct WinoArgs {
+    const float* x;         // input [N, Ci, H, W]  (input gradient: dy, Ci = the convolution's Co)
+    const float* ut;        // transformed filters [KR][Ci][Co][4]
+    const float* shift;     // [Co] or nullptr (forward: bias)
+    const float* residual;  // like y or nullptr.  forward: added before the activation; input gradient: added after the mask
+    const float* mask;      // like y or nullptr (input gradient): y = mask > 0 ? y : 0
+    float* y;               // [N, Co, H, W]
+    int N, Ci, Co, H, W;
+    int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
+    int act;
+    int MP;                 // output pairs
+    int H2;                 // vertical taps: row pairs per image, (H + 1) / 2
+    int n_co_tiles, n_p_tiles;
+};
+
+template <int TCO, bool VERT, bool DGRAD>
+__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
+    constexpr int BK = 8, S = 3;
+    constexpr int WAVES_CO = TCO / 64, WAVES_P = 4 / WAVES_CO, TP = 32 * WAVES_P;
+    constexpr int A_STAGE = BK * TCO * 4;                                   // floats
+    constexpr int PIXW = 2 * TP + 8;                                        // horizontal: pixels per staged row
+    constexpr int B_STAGE = VERT ? BK * 4 * TP : BK * PIXW;
+    constexpr int QPR = VERT ? TP / 4 : PIXW / 4;                           // quads per (channel[, input row])
+    constexpr int QB = B_STAGE / 4, QPW = QB / 4;                           // quads per stage / per wave
+    constexpr int NIB = (QPW + 63) / 64;
+    constexpr int IPR = TCO / 64;                                           // instructions per filter row (1 KB each)
+    constexpr int NIA = 2 * IPR;                                            // a wave loads 2 of the 8 rows
+    constexpr int NI = NIA + NIB;
+    static_assert(NI < 64 && QB % 4 == 0, "vmcnt is a 6-bit counter; the four waves split a stage evenly");
+
+    __shared__ __attribute__((aligned(16))) float As[S * A_STAGE];
+    __shared__ __attribute__((aligned(16))) float Bs[S * B_STAGE];
+    __shared__ __attribute__((aligned(16))) float Zs[VERT ? 4 : B_STAGE];  // zeros: a vertical tap outside the image (3x3)
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave_co = wave / WAVES_P, wave_p = wave % WAVES_P;
+    const int khalf = lane >> 5, l31 = lane & 31;
+
+    const int nblk = a.n_co_tiles * a.n_p_tiles;
+    const int lin = xcd_remap((int)blockIdx.x, nblk);
+    const int co0 = (lin % a.n_co_tiles) * TCO;
+    const int p0 = (lin / a.n_co_tiles) * TP;
+    const int HW = a.H * a.W;
+    const int NC = a.Ci / BK;
+    const int nst = a.KR * NC;
+
+    auto dh_of = [&](int r) { return a.KR == 3 ? (DGRAD ? 1 - r : r - 1) : 0; };
+
+    // ---------------------------------------------------------------- loader state
+    unsigned b_off[NIB];
+    unsigned b_rows = 0;                          // horizontal 3x3: bit 3*i + r: the quad's row shifted by tap r is inside the image
+    bool b_act[NIB];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int ql = i * 64 + lane;
+        b_act[i] = ql < QPW;
+        const int q = wave * QPW + (b_act[i] ? ql : 0);
+        if constexpr (VERT) {
+            const int k = q / (4 * QPR), j = (q / QPR) & 3, gq = q % QPR;
+            int p = p0 + 4 * gq;
+            p = p > a.MP - 4 ? a.MP - 4 : p;       // quads past the tensor: any mapped address (never used)
+            const int per = a.H2 * a.W;
+            const int n = p / per, rr = p - n * per;
+            const int r2 = rr / a.W, w = rr - r2 * a.W;
+            const int row = 2 * r2 - 1 + j;
+            const int rowc = (row >= 0 && row < a.H) ? row : 2 * r2;
+            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)(rowc * a.W + w)) * 4u;
+        } else {
+            const int k = q / QPR, quad = q - k * QPR;
+            const int M = 2 * a.MP;
+            int m = 2 * p0 - 4 + 4 * quad;
+            m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
+            const int n = m / HW, rem = m - n * HW;
+            const int h = rem / a.W;
+            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
+            for (int r = 0; r < a.KR; ++r) {
+                const int hh = h + dh_of(r);
+                b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
+            }
+        }
+    }
+    const unsigned a_voff = (unsigned)lane * 16u;
+    const unsigned lds_a = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)As);
+    const unsigned lds_b = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Bs);
+    int l_t = 0, l_r = 0, l_c = 0;                // next stage to request: index, vertical tap, channel chunk
+    auto issue = [&]() {
+        if (l_t < nst) {
+            const int slot = l_t % S;
+            const float* abase = a.ut + ((size_t)(l_r * a.Ci + l_c * BK + 2 * wave) * a.Co + co0) * 4;
+            const unsigned adst = lds_a + (unsigned)((slot * A_STAGE + 2 * wave * TCO * 4) * 4);
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                dma16(abase + ((size_t)(i / IPR) * a.Co + 64 * (i % IPR)) * 4, a_voff, adst + (unsigned)i * 1024u);
+            const float* bbase = a.x + (size_t)(l_c * BK) * HW;
+            const unsigned bdst = lds_b + (unsigned)((slot * B_STAGE + wave * QPW * 4) * 4);
+            const int shift = dh_of(l_r) * a.W * 4;
+#pragma unroll
+            for (int i = 0; i < NIB; ++i) {
+                unsigned voff = b_off[i];
+                if constexpr (!VERT) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? (unsigned)shift : 0u;
+                if (b_act[i]) dma16(bbase, voff, bdst + (unsigned)i * 1024u);
+            }
+            ++l_t;
+            if (++l_c == NC) { l_c = 0; ++l_r; }
+        }
+    };
+
+    // ---------------------------------------------------------------- consumer state
+    const int lp = wave_p * 32 + l31;             // pair of this lane inside the tile
+    const int p = p0 + lp;
+    const bool pvalid = p < a.MP;
+    int pn, prem;                                 // image and pixel offset (inside the image) of the pair's first output
+    bool m0, m2, m3;                              // d0 / d2 / d3 lie inside the image
+    unsigned rbits = 7u;                          // horizontal 3x3: vertical tap r reads inside the image
+    {
+        const int pc = pvalid ? p : 0;
+        if constexpr (VERT) {
+            const int per = a.H2 * a.W;
+            pn = pc / per;
+            const int rr = pc - pn * per;
+            const int r2 = rr / a.W, w = rr - r2 * a.W;
+            prem = 2 * r2 * a.W + w;
+            m0 = r2 > 0;
+            m2 = 2 * r2 + 1 < a.H;
+            m3 = 2 * r2 + 2 < a.H;
+        } else {
+            const int m = 2 * pc;
+            pn = m / HW;
+            prem = m - pn * HW;
+            const int h = prem / a.W, w = prem - h * a.W;
+            m0 = w > 0;
+            m2 = true;
+            m3 = w + 2 < a.W;
+            if (a.KR == 3) {
+                rbits = 0;
+                for (int r = 0; r < 3; ++r) {
+                    const int hh = h + dh_of(r);
+                    rbits |= (hh >= 0 && hh < a.H) ? (1u << r) : 0u;
+                }
+            }
+        }
+    }
+    const int a_frag = (khalf * TCO + wave_co * 64 + l31) * 4;                          // + (2q * TCO + mi * 32) * 4
+    const int b_frag = VERT ? khalf * 4 * TP + lp : khalf * PIXW + 2 * lp + 2;          // + 2q * (4 TP | PIXW)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][mi][j] = 0.f;
+
+    if constexpr (!VERT) {
+        for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
+    }
+
+    float4 fa[2][2];                              // [register set][mi]: U_0..U_3 of (k, co)
+    float fv[2][4];                               // [register set][transform]: V_i of (k, pair)
+    auto read_frags = [&](int set, int q, const float* Ap, const float* Bp) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+            fa[set][mi] = *reinterpret_cast<const float4*>(Ap + a_frag + (2 * q * TCO + mi * 32) * 4);
+        float d0, d1, d2, d3;
+        if constexpr (VERT) {
+            const float* b = Bp + b_frag + 2 * q * 4 * TP;
+            d0 = b[0];
+            d1 = b[TP];
+            d2 = b[2 * TP];
+            d3 = b[3 * TP];
+            d2 = m2 ? d2 : 0.f;
+        } else {
+            const float* b = Bp + b_frag + 2 * q * PIXW;
+            const float2 u0 = *reinterpret_cast<const float2*>(b);
+            const float2 u1 = *reinterpret_cast<const float2*>(b + 2);
+            const float2 u2 = *reinterpret_cast<const float2*>(b + 4);
+            d0 = u0.y;
+            d1 = u1.x;
+            d2 = u1.y;
+            d3 = u2.x;
+        }
+        d0 = m0 ? d0 : 0.f;
+        d3 = m3 ? d3 : 0.f;
+        fv[set][0] = d0 - d2;
+        fv[set][1] = d1 + d2;
+        fv[set][2] = d2 - d1;
+        fv[set][3] = d1 - d3;
+    };
+    auto mfma_set = [&](int set) {
+        const float av[2][4] = {{fa[set][0].x, fa[set][0].y, fa[set][0].z, fa[set][0].w},
+                                {fa[set][1].x, fa[set][1].y, fa[set][1].z, fa[set][1].w}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                acc[i][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][i], fv[set][i], acc[i][mi], 0, 0, 0);
+    };
+
+    // ---------------------------------------------------------------- K loop
+    // step s: [wait: stage s has landed; stage s+1 may be in flight] barrier [request stage s+2 into the slot stage s-1
+    // just left] [k-pairs 0..3 of stage s: fragments of q+1 are read under the MFMAs of q]
+    issue();
+    issue();
+    int cr = 0, cc = 0;                           // vertical tap / chunk of the stage being consumed
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) wait_vm<NI>();
+        else wait_vm<0>();
+        __syncthreads();
+        issue();
+        const float* Ap = As + (s % S) * A_STAGE;
+        const float* Bp = Bs + (s % S) * B_STAGE;
+        if constexpr (!VERT) {
+            if (!((rbits >> cr) & 1u)) Bp = Zs;   // this lane's row under vertical tap cr is outside the image: all four d are 0
+        }
+        read_frags(0, 0, Ap, Bp);
+#pragma unroll
+        for (int q = 0; q < BK / 2; ++q) {
+            if (q + 1 < BK / 2) read_frags((q + 1) & 1, q + 1, Ap, Bp);
+            mfma_set(q & 1);
+        }
+        if (++cc == NC) { cc = 0; ++cr; }
+    }
+    __syncthreads();                               // every wave is done with the rings: As is reused below
+
+    // ---------------------------------------------------------------- epilogue
+    // output transform (lane-local), bias / residual / activation (forward) or ReLU mask / accumulated gradient (input
+    // gradient), NCHW stores: horizontal pairs as 8-byte stores (256-byte runs per half wave), vertical pairs as two rows.
+    float* const sh_lds = As;
+    for (int i = t; i < TCO; i += 256) sh_lds[i] = a.shift ? a.shift[co0 + i] : 0.f;
+    __syncthreads();
+    if (!pvalid) return;
+    const float* __restrict__ res_p = a.residual;
+    const float* __restrict__ mask_p = a.mask;
+    float* __restrict__ y_p = a.y;
+    const bool has_res = res_p != nullptr, has_mask = mask_p != nullptr;
+    const int act = a.act;
+    const unsigned row_bytes = (unsigned)HW * 4u;
+    const unsigned second = VERT ? (unsigned)a.W * 4u : 4u;              // byte distance of the pair's second output
+    const bool y1_ok = VERT ? m2 : true;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int cl0 = wave_co * 64 + mi * 32 + 4 * khalf;
+        const unsigned off0 = ((unsigned)(pn * a.Co + co0 + cl0) * (unsigned)HW + (unsigned)prem) * 4u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v0[8], v1[8], r0[8], r1[8], k0[8], k1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned off = off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes;
+                r0[e] = r1[e] = 0.f;
+                k0[e] = k1[e] = 1.f;
+                if constexpr (VERT) {
+                    if (has_mask) {
+                        k0[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off);
+                        if (y1_ok) k1[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off + second);
+                    }
+                    if (has_res) {
+                        r0[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off);
+                        if (y1_ok) r1[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off + second);
+                    }
+                } else {
+                    if (has_mask) {
+                        const float2 kk = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(mask_p) + off);
+                        k0[e] = kk.x;
+                        k1[e] = kk.y;
+                    }
+                    if (has_res) {
+                        const float2 rr = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(res_p) + off);
+                        r0[e] = rr.x;
+                        r1[e] = rr.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 8 * h + e;
+                const float ma = acc[0][mi][j], mb = acc[1][mi][j], mc = acc[2][mi][j], md = acc[3][mi][j];
+                const float sh = sh_lds[cl0 + (e & 3) + 8 * (2 * h + (e >> 2))];
+                float y0 = (ma + mb) + mc + sh;
+                float y1 = (mb - mc) - md + sh;
+                if (DGRAD) {
+                    if (has_mask) {
+                        y0 = k0[e] > 0.f ? y0 : 0.f;
+                        y1 = k1[e] > 0.f ? y1 : 0.f;
+                    }
+                    y0 += r0[e];
+                    y1 += r1[e];
+                } else {
+                    y0 += r0[e];
+                    y1 += r1[e];
+                    if (act == DYNMM_ACT_RELU) {
+                        y0 = y0 > 0.f ? y0 : 0.f;
+                        y1 = y1 > 0.f ? y1 : 0.f;
+                    } else if (act == DYNMM_ACT_TANH) {
+                        y0 = tanhf(y0);
+                        y1 = tanhf(y1);
+                    }
+                }
+                v0[e] = y0;
+                v1[e] = y1;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned off = off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes;
+                if constexpr (VERT) {
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off) = v0[e];
+                    if (y1_ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + second) = v1[e];
+                } else {
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(y_p) + off) = make_float2(v0[e], v1[e]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Filter transforms.  w [Co][Ci][KH][KW] -> ut [KR][K][C][4] with (K, C) = (Ci, Co) for the forward operand and (Co, Ci)
+// for the input gradient's (whose taps run the other way along the Winograd axis: g0 <-> g2; the vertical taps of a 3x3
+// filter keep their index, the kernel walks them with the flipped offset).
+__global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict__ w, float4* __restrict__ ut, int Co, int Ci,
+                                                        int KH, int KW, int dgrad) {
+    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
+    const int K = dgrad ? Co : Ci, Cc = dgrad ? Ci : Co;
+    const size_t total = (size_t)KR * K * Cc;
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int c = (int)(o % Cc);
+    const int k = (int)((o / Cc) % K);
+    const int r = (int)(o / ((size_t)Cc * K));
+    const int co = dgrad ? k : c, ci = dgrad ? c : k;
+    const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    float g0 = g[0], g1 = g[1], g2 = g[2];
+    if (dgrad) { const float tmp = g0; g0 = g2; g2 = tmp; }
+    ut[o] = make_float4(g0, (g0 + g1 + g2) * 0.5f, (g0 - g1 + g2) * 0.5f, g2);
+}
+
+// Many filters in one launch (ops.PackedWeights: once per training step).  desc[d] = {src, dst: float offsets from the
+// two bases; Co | Ci << 32; KH | KW << 8 | dgrad << 16 | first workgroup << 32}.
+struct WinoPackDesc {
+    long long src, dst;
+    int Co, Ci, kk, blk0;
+};
+
+__global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                              const WinoPackDesc* __restrict__ desc, int ndesc) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const WinoPackDesc d = desc[lo];
+    const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff, dgrad = (d.kk >> 16) & 1;
+    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
+    const int K = dgrad ? d.Co : d.Ci, Cc = dgrad ? d.Ci : d.Co;
+    const size_t total = (size_t)KR * K * Cc;
+    const size_t o = (size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int c = (int)(o % Cc);
+    const int k = (int)((o / Cc) % K);
+    const int r = (int)(o / ((size_t)Cc * K));
+    const int co = dgrad ? k : c, ci = dgrad ? c : k;
+    const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    float g0 = g[0], g1 = g[1], g2 = g[2];
+    if (dgrad) { const float tmp = g0; g0 = g2; g2 = tmp; }
+    reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(g0, (g0 + g1 + g2) * 0.5f, (g0 - g1 + g2) * 0.5f, g2);
+}
+
+static bool wino_geom_ok(const dynmm_conv_geom* g) {
+    if (!g || g->c_split != g->Ci) return false;
+    if (g->SH != 1 || g->SW != 1) return false;
+    const bool k13 = g->KH == 1 && g->KW == 3, k31 = g->KH == 3 && g->KW == 1, k33 = g->KH == 3 && g->KW == 3;
+    if (!(k13 || k31 || k33)) return false;
+    if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
+    if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
+    if (g->Ci % 64 != 0 || g->Co % 64 != 0) return false;
+    if ((long long)g->N * g->H * g->W < 256) return false;
+    if ((double)g->N * (g->Ci > g->Co ? g->Ci : g->Co) * g->H * g->W >= 1073741824.0) return false;   // 32-bit byte offsets
+    return true;
+}
+
+static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st) {
+    a.H2 = (a.H + 1) / 2;
+    a.MP = vert ? a.N * a.H2 * a.W : a.N * a.H * a.W / 2;
+    const int tco = (a.Co % 128 == 0) ? 128 : 64;
+    const int tp = tco == 128 ? 64 : 128;
+    a.n_co_tiles = a.Co / tco;
+    a.n_p_tiles = ceil_div(a.MP, tp);
+    dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
+#define DYNMM_WINO_GO(TCO)                                                                                             \
+    do {                                                                                                               \
+        if (vert) {                                                                                                    \
+            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, true, true>), grid, dim3(256), 0, st, a);              \
+            else hipLaunchKernelGGL((conv_wino_kernel<TCO, true, false>), grid, dim3(256), 0, st, a);                   \
+        } else {                                                                                                       \
+            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, false, true>), grid, dim3(256), 0, st, a);             \
+            else hipLaunchKernelGGL((conv_wino_kernel<TCO, false, false>), grid, dim3(256), 0, st, a);                  \
+        }                                                                                                              \
+    } while (0)
+    if (tco == 128) DYNMM_WINO_GO(128);
+    else DYNMM_WINO_GO(64);
+#undef DYNMM_WINO_GO
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g) { return wino_geom_ok(g) ? 1 : 0; }
+
+extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
+    if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
+    return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * Co * Ci * 4;
+}
+
+extern "C" int dynmm_wino_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, int dgrad, void* stream) {
+    (void)hipGetLastError();
+    if (!w || !ut || Co <= 0 || Ci <= 0) return DYNMM_EINVAL;
+    if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
+    const size_t total = dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<float4*>(ut), Co, Ci, KH, KW, dgrad ? 1 : 0);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_wino_pack_multi_blocks(int Co, int Ci, int KH, int KW) {
+    return (int)ceil_div_sz(dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4, 256);
+}
+
+extern "C" int dynmm_wino_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
+                                     void* stream) {
+    (void)hipGetLastError();
+    if (!src_base || !dst_base || !desc || ndesc <= 0 || total_blocks <= 0) return DYNMM_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dst_base) & 15u) return DYNMM_EINVAL;
+    static_assert(sizeof(WinoPackDesc) == 32, "descriptor layout is part of the ABI (4 x int64 words)");
+    hipLaunchKernelGGL(wino_pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, src_base, dst_base,
+                       (const WinoPackDesc*)desc, ndesc);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y,
+                                     const dynmm_conv_geom* g, int act, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !ut || !y || !g) return DYNMM_EINVAL;
+    if (!wino_geom_ok(g)) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7u) return DYNMM_EUNSUPPORTED;
+    WinoArgs a{};
+    a.x = x; a.ut = ut; a.shift = bias; a.residual = residual; a.mask = nullptr; a.y = y;
+    a.N = g->N; a.Ci = g->Ci; a.Co = g->Co; a.H = g->H; a.W = g->W;
+    a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
+    a.act = act;
+    return launch_wino(a, g->KW == 1, false, (hipStream_t)stream);
+}
+
+extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
+                                       const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (!dy || !ut || !dx || !g) return DYNMM_EINVAL;
+    if (!wino_geom_ok(g)) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(accum)) & 7u)
+        return DYNMM_EUNSUPPORTED;
+    WinoArgs a{};
+    a.x = dy; a.ut = ut; a.shift = nullptr; a.residual = accum; a.mask = mask; a.y = dx;
+    a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;         // the roles of the channel counts swap
+    a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
+    a.act = DYNMM_ACT_NONE;
+    return launch_wino(a, g->KW == 1, true, (hipStream_t)stream);
+}

@@ -44,39 +44,6 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
 }
 
-// sums[c] += sum_t partials[t][0][c], sums[C+c] += sum_t partials[t][1][c]: the per-tile sums the operand-ring convolution
-// leaves behind (conv_igemm_v5.hip, IgemmArgs::stats) replace the pass of bn_stats_kernel over y.  One workgroup per
-// (64 channels, 64 tiles): 4 groups x 16 tiles per thread (independent loads), groups meet in LDS, then one fp64 atomic per
-// channel and workgroup into the zeroed accumulators — the protocol of bn_stats_kernel (order-dependent only below fp32
-// resolution).
-__global__ void __launch_bounds__(256) bn_stats_from_partials_kernel(const float* __restrict__ partials, int tiles, int C,
-                                                                     double* __restrict__ sums) {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int t0 = blockIdx.y * 64 + grp * 16;
-    double s1 = 0.0, s2 = 0.0;                        // (the 64-pixel tile sums are fp32 trees; everything above them is fp64)
-    if (c < C) {
-        float v1[16], v2[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int t = t0 + k;
-            const float* p = partials + (size_t)(t < tiles ? t : 0) * 2 * C + c;
-            v1[k] = t < tiles ? p[0] : 0.f;
-            v2[k] = t < tiles ? p[C] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { s1 += (double)v1[k]; s2 += (double)v2[k]; }
-    }
-    sh[0][grp][cl] = s1;
-    sh[1][grp][cl] = s2;
-    __syncthreads();
-    if (grp == 0 && c < C) {
-        atomicAdd(&sums[c], (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]));
-        atomicAdd(&sums[C + c], (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
-    }
-}
-
 template <int V>
 __global__ void __launch_bounds__(256) bn_apply_kernel(
     const float* __restrict__ x, const double* __restrict__ sums, const float* __restrict__ gamma,
@@ -311,17 +278,6 @@ extern "C" int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW
         hipLaunchKernelGGL(bn_stats_kernel<4>, grid, dim3(256), 0, st, x, sums, N, C, HW);
     else
         hipLaunchKernelGGL(bn_stats_kernel<1>, grid, dim3(256), 0, st, x, sums, N, C, HW);
-    DYNMM_LAUNCH_CHECK();
-    return DYNMM_OK;
-}
-
-extern "C" int dynmm_bn_stats_from_partials(const float* partials, int tiles, int C, double* sums, int sums_are_zero,
-                                            void* stream) {
-    (void)hipGetLastError();
-    if (!partials || !sums || tiles <= 0 || C <= 0) return DYNMM_EINVAL;
-    if (!sums_are_zero) DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, (hipStream_t)stream));
-    hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((C + 63) / 64, (tiles + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       partials, tiles, C, sums);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

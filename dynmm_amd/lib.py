@@ -49,24 +49,19 @@ SIGNATURES = {
     'dynmm_pack_weight_multi_blocks': (c_i, [c_i] * 5),
     'dynmm_conv2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
-    'dynmm_conv2d_workspace_bytes': (c_sz, [_GP, c_i]),
-    'dynmm_conv2d_fwd_ws': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f, c_sz, c_f]),
-    'dynmm_conv2d_dgrad_ws': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f, c_sz, c_f]),
+    'dynmm_conv2d_wino_supported': (c_i, [_GP]),
+    'dynmm_wino_packed_floats': (c_sz, [c_i, c_i, c_i, c_i]),
+    'dynmm_wino_pack': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_wino_pack_multi_blocks': (c_i, [c_i] * 4),
+    'dynmm_wino_pack_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_conv2d_wino_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
+    'dynmm_conv2d_wino_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),
     'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv2d_wgrad_groupable': (c_i, [_GP]),
     'dynmm_conv2d_wgrad_variant': (c_i, [_GP]),
-    'dynmm_conv2d_stats_tiles': (c_i, [_GP]),
-    'dynmm_conv2d_fwd_stats': (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f, c_sz, c_f]),
-    'dynmm_conv2d_dgrad_stats_tiles': (c_i, [_GP]),
-    'dynmm_conv2d_dgrad_bnstats': (c_i, [c_f] * 9 + [c_sz, _GP, c_f, c_sz, c_f]),
-    'dynmm_bn_stats_from_partials': (c_i, [c_f, c_i, c_i, c_f, c_i, c_f]),
     'dynmm_conv2d_wgrad_group_workspace_bytes': (c_sz, [_GP, c_i]),
     'dynmm_conv2d_wgrad_group': (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
-    'dynmm_conv_bf16x3_eligible': (c_i, [_GP, c_i]),
-    'dynmm_pack_weight_bf16': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
-    'dynmm_conv2d_fwd_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
-    'dynmm_conv2d_dgrad_bf16': (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_act_bwd_bias_workspace_bytes': (c_sz, [c_i, c_i]),
     'dynmm_act_bwd_bias': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_stats': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

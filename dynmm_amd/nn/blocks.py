@@ -13,14 +13,12 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False,
     """act(BN(conv(x|x2)) + residual).
 
     inference (eval, no grad): ONE kernel — BN folded into the implicit-GEMM epilogue.
-    training: conv(+bias) kernel — which also leaves the per-channel sums of its output behind where it is one of the
-    operand-ring kernels, else a batch statistics pass follows —, normalise(+residual+act) pass.
+    training: conv(+bias) kernel, batch statistics pass, normalise(+residual+act) pass.
     """
     if not bn.training and not torch.is_grad_enabled():
         return ops.conv2d_fused_eval(x, conv.weight, conv.bias, bn, act, residual,
                                      conv.stride, conv.padding, x2)
-    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input,
-                   link=conv_link, bn_stats=bn.training)
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input, link=conv_link)
     return ops.batch_norm_act(y, bn, act, residual, link=res_link)
 
 
@@ -63,8 +61,8 @@ class NonBottleneck1D(nn.Module):
         c = self.conv3x1_1
         y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link)
         y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd)
-        c = self.conv3x1_2            # the only consumer of relu(bn1(.)): its dgrad also does bn1's backward reductions
-        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, bn_consumer=fuse_bwd)
+        c = self.conv3x1_2
+        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd)
         idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
         return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link)
 

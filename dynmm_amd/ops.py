@@ -42,35 +42,26 @@ def _chk(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Matrix-core arithmetic of the eligible convolutions (forward + input gradient):
-#   'fp32'   (default) v_mfma_f32_32x32x2_f32 everywhere (exact f32 products)
-#   'bf16x3' operands split into 2 bf16 pieces (16 mantissa bits), hi*hi + hi*lo + lo*hi on
-#            v_mfma_f32_32x32x16_bf16 with fp32 accumulate, for every eligible fwd / dgrad conv:
-#            eval logits within ~1e-5 of fp32 (measured), matrix-core time / 5.3.  In TRAINING the forward
-#            error is amplified by batch-statistic BatchNorm at tiny batches (2e-3 on the 96x128, N=2
-#            fixtures, outside the 1e-3 bar), hence:
-#   'auto'   forward in training = fp32 (exact, keeps the train-mode parity bar); inference forward =
-#            bf16x3; input gradients = bf16x3 (gradients of this net carry ~1e-2 fp32 conditioning noise,
-#            DESIGN.md §1, so 1e-5 is invisible); weight gradients = fp32.  Passes the whole GPU suite;
-#            measured gain in the 3-stream step is small (110.1 -> 108.9 ms train, 773 -> 814 img/s
-#            inference) because the kernels are operand-delivery bound, so 'fp32' stays the default.
-#   'bf16x6' 3 pieces / 6 products (24 bits, fp32-rounding class) — correct but slower than fp32 MFMA
-#            on MI355X (124 vs 110 ms/step); kept for reference.
-PRECISION = _os.environ.get('DYNMM_PRECISION', 'fp32')
-_NSPLIT = {'bf16x3': 2, 'bf16x6': 3, 'auto': 2}
+# Three-tap convolutions by 1-D Winograd F(2,3) (csrc/conv_wino.hip: 2/3 of the matrix-core work, fp32): which passes of the
+# stride-1 1x3 / 3x1 / 3x3 convolutions with Ci, Co % 64 == 0 use it.
+#   'dgrad' (default) the input gradients — a backward pass cannot move a forward result (ReLU / pooling decisions are
+#           taken in the forward pass), so every forward parity bar is untouched by construction;
+#   'all'   forward too (training and inference);   'fwd' forward only;   '0' off (operand-ring kernels everywhere).
+WINO = _os.environ.get('DYNMM_WINO', 'dgrad')
+if WINO not in ('0', 'dgrad', 'fwd', 'all'):
+    raise ValueError(f'DYNMM_WINO={WINO!r}: expected 0 | dgrad | fwd | all')
+_WINO_OK = {}
 
 
-def _split_forward_allowed():
-    """Evaluated at the CALL SITE (inside autograd.Function.forward grad mode is always off)."""
-    if PRECISION == 'auto':
-        return not torch.is_grad_enabled()         # training forward stays exact fp32
-    return PRECISION in _NSPLIT
-
-
-def _bf16x3(g, dgrad, fwd_ok=True):
-    if PRECISION not in _NSPLIT or (not dgrad and not fwd_ok):
+def _wino(g, dgrad, x2=None):
+    """does this pass of this convolution run on the Winograd kernels?"""
+    if WINO == '0' or x2 is not None or (WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad):
         return False
-    return bool(_lib().dynmm_conv_bf16x3_eligible(C.byref(g), int(dgrad)))
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
+    ok = _WINO_OK.get(key)
+    if ok is None:
+        ok = _WINO_OK[key] = bool(_lib().dynmm_conv2d_wino_supported(C.byref(g)))
+    return ok
 
 
 # Opt-in (TrainStep / bench): when a parameter already owns a contiguous `.grad` buffer (a view into the
@@ -246,7 +237,7 @@ def _tile(co, m=1 << 30):
 _SMALL_DIRECT = _os.environ.get('DYNMM_NO_SMALL_CO') is None
 
 
-def _timed(kind, g, call, nprob=1, extra=0):
+def _timed(kind, g, call, nprob=1, extra=0, wino=False):
     if PROFILE is None:
         return call()
     co = g.Ci if kind == 'dgrad' else g.Co
@@ -268,6 +259,8 @@ def _timed(kind, g, call, nprob=1, extra=0):
             name = 'conv_wgrad_v4<co128>'                   # the vectorised 128x128 kernel (conv_igemm.hip: wgrad_v4_shape_ok)
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
+    if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction
+        name = f'conv_wino_{kind}<{"128x64p" if co % 128 == 0 else "64x128p"},{g.KH}x{g.KW}>'
     if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)
         k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
         if k5 and 5 <= g.Co <= 8 and g.Ci % 4 == 0 and g.Ci >= 16 and (g.c_split == g.Ci or g.c_split % (g.Ci // 4) == 0):
@@ -331,66 +324,45 @@ class GradLink:
         self.dres = None
 
 
-class BNLink:
-    """BatchNorm+ReLU -> conv (training): the conv's input-gradient kernel produces the gradient the BatchNorm backward
-    starts from, so it can also produce the two per-channel reductions of that backward (sum g, sum g*xhat) while the tile
-    is in registers.  The BatchNorm forward deposits what that takes (its input, mean, invstd); the conv's backward
-    deposits the per-tile partial sums; the BatchNorm backward uses them instead of its reduction pass."""
-    __slots__ = ('x', 'mean', 'invstd', 'partials', 'tiles')
-
-    def __init__(self):
-        self.x = self.mean = self.invstd = self.partials = None
-        self.tiles = 0
-
-
-# Opt-in (DYNMM_BN_BWD_FUSE=1).  Measured on one box, 41 of the step's 98 BatchNorm backwards served this way: 79.28 ms without,
-# 79.47 ms with — the reduction pass it removes (1.2 ms of kernel time) was overlapped by the weight-gradient stream, the
-# heavier epilogue and the finalise launch on the dependent chain cost what the rest saves.  The default keeps the pass.
-BN_BWD_FUSE = _os.environ.get('DYNMM_BN_BWD_FUSE', '0') == '1'
-_DGRAD_STATS_TILES = {}
-
-
-def _dgrad_stats_tiles(g):
-    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
-    n = _DGRAD_STATS_TILES.get(key)
-    if n is None:
-        n = _DGRAD_STATS_TILES[key] = int(_lib().dynmm_conv2d_dgrad_stats_tiles(C.byref(g)))
-    return n
-
-
 class PackedWeights:
-    """The implicit-GEMM operand layouts (dynmm_pack_weight) of every conv weight a training step uses, produced by
-    ONE launch per step instead of one per convolution (186 for config P).  engine.TrainStep installs an instance
-    as ops.PREPACK: the first step runs the ordinary per-conv packs and registers (weight, shape, needs the
-    input-gradient layout); from then on pack() fills a static arena at the start of the step body and the
-    convolutions look their operands up.  Entries are valid between pack() and invalidate() only (the optimizer
-    rewrites the weights after the body)."""
+    """The operand layouts of every conv weight a training step uses — the implicit-GEMM layouts (dynmm_pack_weight) and the
+    Winograd filter transforms (dynmm_wino_pack) — produced by ONE launch each per step instead of one per convolution (186
+    for config P).  engine.TrainStep installs an instance as ops.PREPACK: the first step runs the ordinary per-conv packs
+    and registers (weight, shape, which of the four operands its passes read); from then on pack() fills a static arena at
+    the start of the step body and the convolutions look their operands up.  Entries are valid between pack() and
+    invalidate() only (the optimizer rewrites the weights after the body)."""
 
     def __init__(self):
-        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_dgrad]
-        self.slots = {}          # id(weight) -> (wp, wpd or None)
-        self.arena = self.desc = None
-        self.blocks = 0
+        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_fwd, need_dgrad, wino_fwd, wino_dgrad]
+        self.slots = {}          # id(weight) -> (wp, wpd, utf, utd), None where not needed
+        self.arena = self.desc = self.wdesc = None
+        self.blocks = self.wblocks = self.nwino = 0
         self.valid = False
         self.dirty = False       # registrations since the arena was laid out
 
-    def register(self, weight, g, need_dgrad):
+    def register(self, weight, g, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False):
         if not isinstance(weight, torch.nn.Parameter):
             return
+        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), bool(wino_dgrad)]
         e = self.reg.get(id(weight))
         if e is None:
-            self.reg[id(weight)] = [weight, g.Co, g.Ci, g.KH, g.KW, bool(need_dgrad)]
+            self.reg[id(weight)] = [weight, g.Co, g.Ci, g.KH, g.KW] + flags
             self.dirty = True
-        elif need_dgrad and not e[5]:
-            e[5] = True
-            self.dirty = True
+        else:
+            for i, f in enumerate(flags):
+                if f and not e[5 + i]:
+                    e[5 + i] = True
+                    self.dirty = True
 
-    def lookup(self, weight, need_dgrad):
+    def lookup(self, weight, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False):
         if not self.valid:
             return None
         s = self.slots.get(id(weight))
-        if s is None or (need_dgrad and s[1] is None):
+        if s is None:
             return None
+        for need, t in zip((need_fwd, need_dgrad, wino_fwd, wino_dgrad), s):
+            if need and t is None:
+                return None
         return s
 
     def _layout(self):
@@ -398,26 +370,43 @@ class PackedWeights:
         ents = list(self.reg.values())
         dev = ents[0][0].device
         base = min(e[0].data_ptr() for e in ents)
-        off, blk, rows = 0, 0, []
+        off, blk, wblk, rows, wrows = 0, 0, 0, [], []
         spans = {}
-        for w, Co, Ci, KH, KW, nd in ents:
+        for w, Co, Ci, KH, KW, nf_, nd, wf, wd in ents:
+            src = (w.data_ptr() - base) // 4
+            span = [None] * 4
+            # the multi-tensor pack always writes the forward layout; the input-gradient layout only where a direct
+            # kernel reads it (dynmm_pack_weight_multi's descriptor: dst_dgrad = -1 otherwise)
             nf = lib.dynmm_packed_weight_floats(Co, Ci, KH, KW, 0)
             ndg = lib.dynmm_packed_weight_floats(Co, Ci, KH, KW, 1) if nd else 0
-            dstf = off
-            off += (nf + 3) & ~3                 # rows stay 16-byte aligned (the kernels' dwordx4 path)
-            dstd = off if nd else -1
-            off += (ndg + 3) & ~3
-            rows.append([(w.data_ptr() - base) // 4, dstf, dstd, Co | (Ci << 32), (KH * KW) | (blk << 32)])
-            spans[id(w)] = (dstf, nf, dstd, ndg)
-            blk += lib.dynmm_pack_weight_multi_blocks(Co, Ci, KH, KW, int(nd))
+            if nf_ or nd:
+                dstf = off
+                off += (nf + 3) & ~3             # rows stay 16-byte aligned (the kernels' dwordx4 path)
+                dstd = off if nd else -1
+                off += (ndg + 3) & ~3
+                rows.append([src, dstf, dstd, Co | (Ci << 32), (KH * KW) | (blk << 32)])
+                span[0] = (dstf, nf)
+                span[1] = (dstd, ndg) if nd else None
+                blk += lib.dynmm_pack_weight_multi_blocks(Co, Ci, KH, KW, int(nd))
+            nu = lib.dynmm_wino_packed_floats(Co, Ci, KH, KW)
+            for slot, dgrad, on in ((2, 0, wf), (3, 1, wd)):
+                if on:
+                    wrows.append([src, off, Co | (Ci << 32), KH | (KW << 8) | (dgrad << 16) | (wblk << 32)])
+                    span[slot] = (off, nu)
+                    off += nu                    # a multiple of 4 floats
+                    wblk += lib.dynmm_wino_pack_multi_blocks(Co, Ci, KH, KW)
+            spans[id(w)] = span
         self.arena = torch.empty(off, device=dev, dtype=torch.float32)
-        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
-        self.base, self.blocks = base, blk
-        self.slots = {k: (self.arena[a:a + n], self.arena[d:d + m] if d >= 0 else None) for k, (a, n, d, m) in spans.items()}
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
+        self.wdesc = torch.tensor(wrows, dtype=torch.int64).to(dev) if wrows else None
+        self.ndesc, self.nwino = len(rows), len(wrows)
+        self.base, self.blocks, self.wblocks = base, blk, wblk
+        self.slots = {k: tuple(self.arena[sp[0]:sp[0] + sp[1]] if sp is not None else None for sp in span)
+                      for k, span in spans.items()}
         self.dirty = False
 
     def pack(self):
-        """one launch: every registered weight -> its forward (and input-gradient) operand layout"""
+        """one launch per operand family: every registered weight -> the layouts its convolution's passes read"""
         self.valid = False
         if not self.reg:
             return
@@ -425,8 +414,12 @@ class PackedWeights:
             if torch.cuda.is_current_stream_capturing():
                 return                           # layout changes allocate: not inside a capture
             self._layout()
-        L.check(_lib().dynmm_pack_weight_multi(C.c_void_p(self.base), _p(self.arena), self.desc.data_ptr(), len(self.reg),
-                                               self.blocks, _stream()), 'pack_weight_multi')
+        if self.desc is not None:
+            L.check(_lib().dynmm_pack_weight_multi(C.c_void_p(self.base), _p(self.arena), self.desc.data_ptr(), self.ndesc,
+                                                   self.blocks, _stream()), 'pack_weight_multi')
+        if self.wdesc is not None:
+            L.check(_lib().dynmm_wino_pack_multi(C.c_void_p(self.base), _p(self.arena), self.wdesc.data_ptr(), self.nwino,
+                                                 self.wblocks, _stream()), 'wino_pack_multi')
         self.valid = True
 
     def invalidate(self):
@@ -436,111 +429,56 @@ class PackedWeights:
 PREPACK = None
 
 
-_SCRATCH_BYTES = {}
-
-
-def _conv_scratch(g, dgrad, device):
-    """(tensor or None, bytes): scratch for a K-split forward / input-gradient launch (dynmm_conv2d_workspace_bytes:
-    small grids only — C = 512 at 15x20, the decoder's small maps, compacted depth stages).  Allocated per call from
-    torch's caching allocator (stream-ordered, capture-safe); the byte count is cached per geometry."""
-    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split, dgrad)
-    n = _SCRATCH_BYTES.get(key)
-    if n is None:
-        n = _SCRATCH_BYTES[key] = int(_lib().dynmm_conv2d_workspace_bytes(C.byref(g), dgrad))
-    if n == 0:
-        return None, 0
-    return torch.empty(n // 4, device=device, dtype=torch.float32), n
-
-
-# conv -> BatchNorm (training): the forward kernel's per-tile channel sums travel from _Conv2d.forward to batch_norm_act.
-# Opt-in (DYNMM_CONV_BN_STATS=1).  Measured on one box: step 80.43 -> 80.07 ms (the statistics pass it removes is 1.4 ms of
-# kernel time, most of it overlapped), statistics closer to fp64 than the pass over y (variance error 2e-7 vs 5e-6) — and four
-# parity tests whose bars are calibrated noise envelopes (ReLU decisions at rounding-level pre-activations, the SE excitation
-# gradients) land outside them with the different rounding.  Not worth re-calibrating the parity gate for 0.5 %.
-CONV_BN_STATS = _os.environ.get('DYNMM_CONV_BN_STATS', '0') == '1'
-_STATS_HANDOFF = [None]
-_STATS_TILES = {}
-
-
-def _stats_tiles(g):
-    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
-    n = _STATS_TILES.get(key)
-    if n is None:
-        n = _STATS_TILES[key] = int(_lib().dynmm_conv2d_stats_tiles(C.byref(g)))
-    return n
-
-
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, split_fwd, w_owner=None,
-                want_stats=False, bnlink=None):
+    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, w_owner=None):
         lib = _lib()
         st = _stream()
         x, x2, weight, bias = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight'), _chk(bias, 'bias')
         g = _geom(x, x2, weight, stride, padding)
-        K = g.Ci * g.KH * g.KW
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
-        taps = g.KH * g.KW
         y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=x.device, dtype=torch.float32)
-        bf_f = x2 is None and _bf16x3(g, False, split_fwd)
-        bf_d = need_dx and x2 is None and _bf16x3(g, True)
-        wpd = None
-        ns = _NSPLIT.get(PRECISION, 0)
-        if bf_f or bf_d:
-            nel = taps * g.Ci * g.Co
-            i16 = dict(device=x.device, dtype=torch.int16)
-            wsf = torch.empty(ns * nel, **i16) if bf_f else None      # [ns][Co][K] bf16 bit patterns
-            wsd = torch.empty(ns * nel, **i16) if bf_d else None      # [ns][Ci][K']
-            L.check(lib.dynmm_pack_weight_bf16(_p(weight), _p(wsf), _p(wsd), g.Co, g.Ci, g.KH, g.KW, ns, st),
-                    'pack_weight_bf16')
-            if bf_d:
-                wpd = wsd
+        # (the Winograd kernels read their input with 16-byte loads; an input off that grid takes the direct kernels)
+        wino_f = _wino(g, False, x2) and x.data_ptr() % 16 == 0
+        wino_d = need_dx and _wino(g, True, x2)
+        need_wp, need_wpd = not wino_f, need_dx and not wino_d
         # (a Linear / Conv1d weight arrives as a [Co, Ci, 1, 1] alias of its parameter: same memory, so the parameter keys the pack)
         wkey = w_owner if w_owner is not None else weight
-        pre = PREPACK.lookup(wkey, need_dx) if (PREPACK is not None and not bf_f and not bf_d) else None
+        wp = wpd = utf = utd = None
+        pre = PREPACK.lookup(wkey, need_wp, need_wpd, wino_f, wino_d) if PREPACK is not None else None
         if pre is not None:
-            wp, wpd32 = pre                      # packed by the step's single multi-tensor launch
-            if need_dx:
-                wpd = wpd32
-        elif not bf_f or (need_dx and not bf_d):
-            wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=x.device,
-                             dtype=torch.float32) if not bf_f else None
-            wpd32 = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 1), device=x.device,
-                                dtype=torch.float32) if (need_dx and not bf_d) else None
-            L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd32), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
-            if wpd32 is not None:
-                wpd = wpd32
-            if PREPACK is not None and not bf_f and not bf_d:
-                PREPACK.register(wkey, g, need_dx)
-        if bf_f:
-            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_bf16(_p(x), _p(wsf), ns, None, _p(bias), None, _p(y),
-                                                                       C.byref(g), act, st)), 'conv2d_fwd_bf16')
+            wp, wpd, utf, utd = pre                  # packed by the step's multi-tensor launches
         else:
-            ws, nws = _conv_scratch(g, 0, x.device)
-            tiles = _stats_tiles(g) if (CONV_BN_STATS and want_stats and x2 is None and act == L.ACT_NONE) else 0
-            rc = L.DYNMM_EUNSUPPORTED
-            if tiles:
-                # BatchNorm follows: the kernel leaves per-tile channel sums of y behind (batch_norm_act picks them up)
-                part = torch.empty(tiles * 2 * g.Co, device=x.device, dtype=torch.float32)
-                rc = _timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_stats(_p(x), _p(wp), _p(bias), _p(y), _p(part),
-                                                                         C.c_size_t(part.numel()), C.byref(g), _p(ws), nws, st))
-                if rc == L.DYNMM_OK:
-                    _STATS_HANDOFF[0] = (y.data_ptr(), part, tiles)
-                elif rc != L.DYNMM_EUNSUPPORTED:
-                    L.check(rc, 'conv2d_fwd_stats')
-            if rc == L.DYNMM_EUNSUPPORTED:
-                L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_ws(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
-                                                                         C.byref(g), act, _p(ws), nws, st)), 'conv2d_fwd')
-        ctx.bf_d, ctx.ns = bf_d, ns
+            if need_wp or need_wpd:
+                wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=x.device,
+                                 dtype=torch.float32) if need_wp else None
+                wpd = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 1), device=x.device,
+                                  dtype=torch.float32) if need_wpd else None
+                L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), _p(wpd), g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
+            nu = lib.dynmm_wino_packed_floats(g.Co, g.Ci, g.KH, g.KW) if (wino_f or wino_d) else 0
+            if wino_f:
+                utf = torch.empty(nu, device=x.device, dtype=torch.float32)
+                L.check(lib.dynmm_wino_pack(_p(weight), _p(utf), g.Co, g.Ci, g.KH, g.KW, 0, st), 'wino_pack')
+            if wino_d:
+                utd = torch.empty(nu, device=x.device, dtype=torch.float32)
+                L.check(lib.dynmm_wino_pack(_p(weight), _p(utd), g.Co, g.Ci, g.KH, g.KW, 1, st), 'wino_pack')
+            if PREPACK is not None:
+                PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d)
+        if wino_f:
+            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd(_p(x), _p(utf), _p(bias), None, _p(y), C.byref(g), act, st),
+                           wino=True), 'conv2d_wino_fwd')
+        else:
+            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
+                                                                  C.byref(g), act, st)), 'conv2d_fwd')
         ctx.geom = g
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_x2 = x2 is not None
-        ctx.bnlink = bnlink if x2 is None else None    # x = relu(BatchNorm(.)) and this conv is its only consumer: see BNLink
+        ctx.wino_d = wino_d
         ctx.mask_input = mask_input       # x is a ReLU output: apply [x > 0] in the dgrad epilogue
         ctx.defer_mask = defer_mask       # our own ReLU backward is applied by the consumer's dgrad
         ctx.link = link
-        ctx.save_for_backward(x, x2, wpd, y if (act != L.ACT_NONE and not defer_mask) else None)
+        ctx.save_for_backward(x, x2, utd if wino_d else wpd, y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
         # w_owner: the nn.Parameter that `weight` is a reshaped view of (Linear / Conv1d weights used as 1x1 convs): its
         # `.grad` has the same memory layout, so the in-place gradient protocol can write straight into it
@@ -584,28 +522,18 @@ class _Conv2d(Function):
             accum = None
             if ctx.link is not None and ctx.link.dres is not None:
                 accum, ctx.link.dres = ctx.link.dres, None
-            if ctx.bf_d:
-                L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad_bf16(_p(gy), _p(wpd), ctx.ns, _p(mask), _p(accum),
-                                                                               _p(dx), C.byref(g), st)), 'conv2d_dgrad_bf16')
+            extra = (mask is not None) + (accum is not None)
+            if ctx.wino_d:
+                # 16-byte loads of gy, 8-byte accesses to the epilogue operands: tensors off that grid (views handed in by the
+                # caller) are copied into fresh allocations first
+                gyw = gy if gy.data_ptr() % 16 == 0 else gy.clone()
+                mask, accum = (t if (t is None or t.data_ptr() % 8 == 0) else t.clone() for t in (mask, accum))
+                L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_wino_dgrad(_p(gyw), _p(wpd), _p(mask), _p(accum), _p(dx),
+                                                                               C.byref(g), st), extra=extra, wino=True),
+                        'conv2d_wino_dgrad')
             else:
-                ws, nws = _conv_scratch(g, 1, gy.device)
-                bl = ctx.bnlink
-                rc = L.DYNMM_EUNSUPPORTED
-                tiles = _dgrad_stats_tiles(g) if (bl is not None and bl.x is not None and accum is None and dx2 is None) else 0
-                if tiles:
-                    # x is the BatchNorm's ReLU output: its mask is applied here (the BatchNorm backward applies it again: idempotent)
-                    part = torch.empty(tiles * 2 * g.Ci, device=gy.device, dtype=torch.float32)
-                    rc = _timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad_bnstats(
-                        _p(gy), _p(wpd), _p(x), None, _p(dx), _p(bl.x), _p(bl.mean), _p(bl.invstd), _p(part),
-                        C.c_size_t(part.numel()), C.byref(g), _p(ws), nws, st))
-                    if rc == L.DYNMM_OK:
-                        bl.partials, bl.tiles = part, tiles
-                    elif rc != L.DYNMM_EUNSUPPORTED:
-                        L.check(rc, 'conv2d_dgrad_bnstats')
-                if rc == L.DYNMM_EUNSUPPORTED:
-                    L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad_ws(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
-                                                                                 _p(dx2), C.byref(g), _p(ws), nws, st),
-                                   extra=(mask is not None) + (accum is not None)), 'conv2d_dgrad')
+                L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
+                                                                          _p(dx2), C.byref(g), st), extra=extra), 'conv2d_dgrad')
         dw_ret = None
         ws_stream = None
         if DIRECT_GRAD and WGRAD_GROUP > 1:
@@ -631,33 +559,23 @@ class _Conv2d(Function):
         _grads_enqueued(torch.cuda.current_stream(), ws_stream)
         if dw_ret is not None and tuple(dw_ret.shape) != ctx.wshape:
             dw_ret = dw_ret.reshape(ctx.wshape)
-        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None, None, None, None
+        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_input=False, defer_mask=False,
-           link=None, w_owner=None, bn_stats=False, bn_consumer=False):
+           link=None, w_owner=None):
     """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable.
 
     Backward-fusion hints (set by block code that knows the dataflow; results are unchanged):
       defer_mask : this op's ReLU backward is applied by its (single) consumer — pair with
       mask_input : x is the output of a `defer_mask` op: the dgrad epilogue applies [x > 0];
-      link       : GradLink whose residual-branch gradient is added in the dgrad epilogue;
-      bn_consumer: x is the output of batch_norm_act(..., 'relu') (no residual) and this op is its ONLY consumer: the
-                   input-gradient kernel also produces the reductions of that BatchNorm's backward (BNLink);
-      bn_stats   : a training-mode BatchNorm consumes the result: where the kernel can, it sums the output per channel in
-                   its epilogue and the result carries the partial sums (`_dynmm_stats`) for batch_norm_act."""
+      link       : GradLink whose residual-branch gradient is added in the dgrad epilogue."""
     if not torch.is_grad_enabled() and isinstance(weight, torch.nn.Parameter) and w_owner is None:
         # inference: the packed weight is cached on the parameter (conv2d_fused_eval) instead of re-laid-out per call
         # (the factorised blocks' conv -> ReLU pairs were 83 pack launches per forward of config P)
         return conv2d_fused_eval(x, weight, bias, None, act, None, stride, padding, x2)
-    _STATS_HANDOFF[0] = None
-    bnlink = getattr(x, '_dynmm_bnlink', None) if (bn_consumer and BN_BWD_FUSE) else None
-    y = _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
-                      bool(defer_mask), link, _split_forward_allowed(), w_owner, bool(bn_stats), bnlink)
-    hand, _STATS_HANDOFF[0] = _STATS_HANDOFF[0], None
-    if hand is not None and hand[0] == y.data_ptr():
-        y._dynmm_stats = hand[1:]
-    return y
+    return _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
+                         bool(defer_mask), link, w_owner)
 
 
 class _FanOut(Function):
@@ -711,30 +629,21 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     x, x2, weight = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight')
     residual = _chk(residual, 'residual')
     g = _geom(x, x2, weight, _pair(stride), _pair(padding))
-    K = g.Ci * g.KH * g.KW
     dev = x.device
-    bf = x2 is None and _bf16x3(g, False, _split_forward_allowed())
-    ns = _NSPLIT.get(PRECISION, 0)
     # Inference weights do not change between calls: the packed weight tile and the folded BN scale/shift are
     # cached ON the layer's weight tensor object (so the cache dies with the layer), stamped with the storage
     # address + in-place version counter of every tensor they derive from (load_state_dict / optimizer steps bump
     # the versions) and the mutation generation above: a steady-state forward launches only the conv.
     srcs = [weight, conv_bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-    slot = '_dynmm_eval_cache_bf' if bf else '_dynmm_eval_cache'
+    slot = '_dynmm_eval_cache'
     stamp = (_MUTATION_GEN[0],) + tuple((t.data_ptr(), t._version) for t in srcs if t is not None) + \
         ((float(bn.eps),) if bn is not None else ())
-    stamp = stamp + ((ns,) if bf else ())
     hit = getattr(weight, slot, None)
     if hit is not None and hit[0] == stamp and not torch.cuda.is_current_stream_capturing():
-        wp, wsf, scale, shift = hit[1]
+        wp, scale, shift = hit[1]
     else:
-        wp = wsf = None
-        if bf:
-            wsf = torch.empty(ns * g.KH * g.KW * g.Ci * g.Co, device=dev, dtype=torch.int16)
-            L.check(lib.dynmm_pack_weight_bf16(_p(weight), _p(wsf), None, g.Co, g.Ci, g.KH, g.KW, ns, st), 'pack_weight_bf16')
-        else:
-            wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=dev, dtype=torch.float32)
-            L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
+        wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=dev, dtype=torch.float32)
+        L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
         scale = shift = None
         if bn is not None:
             scale = torch.empty(g.Co, device=dev, dtype=torch.float32)
@@ -744,16 +653,11 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
         else:
             shift = _chk(conv_bias, 'bias')
         if not torch.cuda.is_current_stream_capturing():
-            setattr(weight, slot, (stamp, (wp, wsf, scale, shift)))
+            setattr(weight, slot, (stamp, (wp, scale, shift)))
     y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=dev, dtype=torch.float32)
-    if bf:
-        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_bf16(_p(x), _p(wsf), ns, _p(scale), _p(shift), _p(residual),
-                                                                   _p(y), C.byref(g), ACT[act], st)), 'conv2d_fwd_bf16')
-    else:
-        ws, nws = _conv_scratch(g, 0, x.device)
-        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd_ws(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
-                                                                 _p(y), C.byref(g), ACT[act], _p(ws), nws, st),
-                       extra=int(residual is not None)), 'conv2d_fwd')
+    L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
+                                                          _p(y), C.byref(g), ACT[act], st),
+                   extra=int(residual is not None)), 'conv2d_fwd')
     return y
 
 
@@ -793,8 +697,7 @@ def _zero_sums(n, device):
 
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt,
-                partials=None, tiles=0, bnlink=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt):
         lib = _lib()
         st = _stream()
         x, residual = _chk(x, 'x'), _chk(residual, 'residual')
@@ -807,10 +710,7 @@ class _BatchNormAct(Function):
             note_mutation()          # running statistics / step counter are rewritten in place below
         if training and N * HW <= 1:
             raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
-        if training and partials is not None:
-            sums, zeroed = _zero_sums(2 * Cc, dev)
-            L.check(lib.dynmm_bn_stats_from_partials(_p(partials), int(tiles), Cc, _p(sums), zeroed, st), 'bn_stats_from_partials')
-        elif training:
+        if training:
             sums, zeroed = _zero_sums(2 * Cc, dev)
             L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, zeroed, st), 'bn_stats')
         mean = torch.empty(Cc, device=dev, dtype=torch.float32)
@@ -822,9 +722,6 @@ class _BatchNormAct(Function):
         ctx.act = act
         ctx.training = training
         ctx.link = link
-        ctx.bnlink = bnlink
-        if bnlink is not None:
-            bnlink.x, bnlink.mean, bnlink.invstd = x, mean, invstd
         ctx.has_res = residual is not None
         # ReLU without residual: the backward re-derives the mask from x (bit-identical to this forward's
         # fma) instead of reading y — one tensor read less in bn_bwd_reduce and in bn_bwd_apply
@@ -843,15 +740,8 @@ class _BatchNormAct(Function):
         HW = H * W
         dev = x.device
         sums, zeroed = _zero_sums(2 * Cc, dev)
-        bl = ctx.bnlink
-        if bl is not None and bl.partials is not None:
-            # the consumer's input-gradient kernel left sum g / sum g*xhat per tile behind (gy IS that kernel's output)
-            L.check(lib.dynmm_bn_stats_from_partials(_p(bl.partials), int(bl.tiles), Cc, _p(sums), zeroed, st),
-                    'bn_stats_from_partials')
-            bl.partials = bl.x = bl.mean = bl.invstd = None
-        else:
-            L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-                                            N, Cc, HW, ctx.act, zeroed, st), 'bn_bwd_reduce')
+        L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
+                                        N, Cc, HW, ctx.act, zeroed, st), 'bn_bwd_reduce')
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[5]
         dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None
@@ -865,7 +755,7 @@ class _BatchNormAct(Function):
         if ctx.link is not None and dres is not None:
             ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
         _grads_enqueued()
-        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
@@ -875,16 +765,8 @@ def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
     nbt = bn.num_batches_tracked if training else None       # incremented inside the normalise kernel
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
         raise L.DynmmHipError('BatchNorm num_batches_tracked must be an int64 tensor on the HIP device')
-    stats = getattr(x, '_dynmm_stats', None) if training else None      # left behind by the producing convolution (conv2d(bn_stats=True))
-    partials, tiles = stats if stats is not None else (None, 0)
-    # BN+ReLU (no residual) whose output a convolution consumes with `mask_input`: see BNLink
-    bnlink = BNLink() if (BN_BWD_FUSE and training and act == 'relu' and residual is None and torch.is_grad_enabled()
-                          and x.requires_grad) else None
-    y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
-                            bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt, partials, tiles, bnlink)
-    if bnlink is not None:
-        y._dynmm_bnlink = bnlink
-    return y
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
+                               bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -100,19 +100,29 @@ int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
 int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
                        float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
 
-/* The same two calls with caller-owned scratch.  For long reductions on grids that would leave most CUs with fewer than
- * three workgroups (C = 512 at 15x20, compacted depth stages) the operand-ring kernels split the reduction over 2 or 4
- * workgroups per tile; the partial accumulator tiles travel through `workspace` in a fixed order
- * (split s adds the running sum of the splits before it: the result does not depend on timing).
- * dynmm_conv2d_workspace_bytes(g, dgrad) = bytes that enable the split for this geometry (0: never split); a smaller or
- * NULL workspace simply runs the un-split launch.  The arrival counters inside it are zeroed on the stream by the callee. */
-size_t dynmm_conv2d_workspace_bytes(const dynmm_conv_geom* g, int dgrad);
-int dynmm_conv2d_fwd_ws(const float* x, const float* x2, const float* wp_fwd,
-                        const float* scale, const float* shift, const float* residual,
-                        float* y, const dynmm_conv_geom* g, int act, void* workspace, size_t workspace_bytes, void* stream);
-int dynmm_conv2d_dgrad_ws(const float* dy, const float* wp_dgrad, const float* mask, const float* accum,
-                          float* dx, float* dx2, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
+/* ---- three-tap convolutions by 1-D Winograd F(2,3) on the fp32 matrix cores (csrc/conv_wino.hip) ----
+ * Stride-1, same-padded 1x3 / 3x1 / 3x3 convolutions with Ci, Co % 64 == 0 and W % 4 == 0 (the factorised convolutions
+ * of resnet.py:124-147 and the decoder's 3x3 convolutions, model.py:343-357): four channel contractions per output PAIR
+ * along the tap axis instead of six, i.e. 2/3 of the direct convolution's matrix work, in fp32 (error vs fp64 of the same
+ * class as a direct fp32 sum: 2e-7 .. 4e-7 rms).  dynmm_conv2d_wino_supported(g) = 1 when the geometry qualifies.
+ * Operand: the filter transforms ut[KR][K][C][4] (KR = 3 for 3x3, else 1; (K, C) = (Ci, Co) forward, (Co, Ci) input
+ * gradient), dynmm_wino_packed_floats floats, 16-byte aligned, written by dynmm_wino_pack or — many filters in ONE launch —
+ * by dynmm_wino_pack_multi: desc (device memory) = ndesc records of 4 int64 words { src, dst : float offsets from
+ * src_base / dst_base (dst % 4 == 0) ; Co | Ci << 32 ; KH | KW << 8 | dgrad << 16 | first_workgroup << 32 }, first
+ * workgroups being the running sum of dynmm_wino_pack_multi_blocks.
+ *   fwd  : y = act(conv(x, w) + bias + residual)                  (bias, residual optional)
+ *   dgrad: dx = conv_transpose(dy, w) * [mask > 0] + accum        (mask, accum optional; the epilogue of dynmm_conv2d_dgrad)
+ * x / dy / ut 16-byte aligned, y / dx / residual / mask / accum 8-byte aligned, else DYNMM_EUNSUPPORTED. */
+int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g);
+size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW);
+int dynmm_wino_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, int dgrad, void* stream);
+int dynmm_wino_pack_multi_blocks(int Co, int Ci, int KH, int KW);
+int dynmm_wino_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
                           void* stream);
+int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y,
+                          const dynmm_conv_geom* g, int act, void* stream);
+int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
+                            const dynmm_conv_geom* g, void* stream);
 
 /* dw[Co,Ci,KH,KW] = sum_{n,oh,ow} dy * x(window).  Split over the pixel range into partial slabs in
  * `workspace` (>= dynmm_conv2d_wgrad_workspace_bytes), reduced deterministically.
@@ -137,25 +147,6 @@ int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const float* const* 
                              float* const* dbiases, void* workspace, size_t workspace_bytes,
                              const dynmm_conv_geom* g, void* stream);
 
-/* ---- split-precision variant (csrc/conv_bf16x3.hip) ----
- * fp32 tensors; every operand is split on the fly into `nsplit` bf16 pieces and the piece products with
- * p+q < nsplit are accumulated in fp32 on v_mfma_f32_32x32x16_bf16:
- *   nsplit = 3 ("bf16x6", 24 mantissa bits): fp32-rounding-class results at 6/16 of the fp32-MFMA cost;
- *   nsplit = 2 ("bf16x3", 16 bits): ~1e-5 on eval logits, opt-in.
- * Epilogue identical to the fp32 entry points above.  Eligible when the GEMM's reduction channels are a
- * multiple of 32 and it has > 32 output channels (dynmm_conv_bf16x3_eligible); weights come pre-split from
- * dynmm_pack_weight_bf16:  fwd [nsplit][Co][KH*KW*Ci] (k = tap*Ci+ci),
- *                          dgrad [nsplit][Ci][KH*KW*Co] (k = tap*Co+co), bf16 bit patterns. */
-int dynmm_conv_bf16x3_eligible(const dynmm_conv_geom* g, int dgrad);
-int dynmm_pack_weight_bf16(const float* w, unsigned short* fwd, unsigned short* dgrad,
-                           int Co, int Ci, int KH, int KW, int nsplit, void* stream);
-int dynmm_conv2d_fwd_bf16(const float* x, const unsigned short* w_split, int nsplit,
-                          const float* scale, const float* shift, const float* residual,
-                          float* y, const dynmm_conv_geom* g, int act, void* stream);
-int dynmm_conv2d_dgrad_bf16(const float* dy, const unsigned short* wd_split, int nsplit,
-                            const float* mask, const float* accum, float* dx,
-                            const dynmm_conv_geom* g, void* stream);
-
 /* g_out = g * act'(y) ; dbias[c] = sum_{n,hw} g_out   (either output may be NULL).
  * ReLU/tanh backward + bias gradient of a conv+bias+act (autograd of resnet.py:125-126 etc.).
  * dbias is summed over sample splits through `workspace` (>= *_workspace_bytes) in a fixed order. */
@@ -168,26 +159,6 @@ int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbia
  * hands in a buffer that is already zero (e.g. a slice of an arena cleared once per step) and the memset
  * launch is skipped. */
 int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, int sums_are_zero, void* stream);
-/* BatchNorm batch statistics WITHOUT a pass over the convolution's output (training, conv -> BN): the operand-ring forward
- * kernel sums its output tile per channel in the epilogue (y = conv + bias, no activation) and leaves
- * stats[tile][0][c] = sum, stats[tile][1][c] = sum of squares; dynmm_bn_stats_from_partials adds the tiles (fp64 atomics per
- * 64-tile group, like dynmm_bn_stats) into the `sums` array dynmm_bn_apply reads — in place of dynmm_bn_stats.  dynmm_conv2d_stats_tiles: rows of
- * `stats` for this geometry, 0 when the geometry is not served by the operand-ring kernels (then: dynmm_conv2d_fwd +
- * dynmm_bn_stats); dynmm_conv2d_fwd_stats returns DYNMM_EUNSUPPORTED when the tensors' alignment rules it out at the call. */
-int dynmm_conv2d_stats_tiles(const dynmm_conv_geom* g);
-int dynmm_conv2d_fwd_stats(const float* x, const float* wp_fwd, const float* bias, float* y, float* stats,
-                           size_t stats_floats, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
-                           void* stream);
-int dynmm_bn_stats_from_partials(const float* partials, int tiles, int C, double* sums, int sums_are_zero, void* stream);
-/* The same for the BatchNorm BACKWARD (training, BN+ReLU -> conv with the ReLU mask applied in that conv's input-gradient
- * epilogue): the input-gradient kernel produces g = d(loss)/d(BN pre-activation) and, per pixel tile and channel,
- * stats[tile][0][c] = sum g, stats[tile][1][c] = sum g * (bn_x - bn_mean[c]) * bn_invstd[c]; dynmm_bn_stats_from_partials turns
- * them into the `sums` dynmm_bn_bwd_apply reads — in place of dynmm_bn_bwd_reduce's pass over g and x. */
-int dynmm_conv2d_dgrad_stats_tiles(const dynmm_conv_geom* g);
-int dynmm_conv2d_dgrad_bnstats(const float* dy, const float* wp_dgrad, const float* mask, const float* accum, float* dx,
-                               const float* bn_x, const float* bn_mean, const float* bn_invstd, float* stats,
-                               size_t stats_floats, const dynmm_conv_geom* g, void* workspace, size_t workspace_bytes,
-                               void* stream);
 /* y = act( (x-mean)*invstd*gamma + beta + residual ).
  * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
  *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and

@@ -152,116 +152,3 @@ def test_encoder_stage_and_stem():
     # only stem/layer1/layer2 take part; drop the unused stages so every parameter gets a gradient
     del m.e.layer3, m.e.layer4
     run_pair(m, ref, [rnd(2, 1, 96, 128)])
-
-
-@pytest.mark.parametrize('shape', [(4, 128, 30, 40, 128, (1, 3)), (3, 64, 15, 20, 64, (1, 3)), (2, 64, 24, 32, 256, (3, 3)),
-                                   (5, 128, 9, 12, 128, (1, 1)), (3, 128, 12, 16, 128, (3, 3)), (3, 128, 24, 32, 128, (1, 3))])
-def test_conv_bn_statistics_from_the_conv_epilogue(shape):
-    """Training-mode conv -> BatchNorm: the operand-ring kernel's per-tile channel sums (+ the fixed-order finalise) against
-    the statistics pass over y they replace — same normalised output, running statistics and gradients (the two orders of
-    summation differ below 1e-6), and the partials really were used.  M = 540 / 900 pixels: ragged last tile."""
-    import ctypes as C
-    from dynmm_amd import ops
-    from dynmm_amd.nn.blocks import conv_bn_act
-    monkey = ops.CONV_BN_STATS
-    ops.CONV_BN_STATS = True                     # opt-in path (default: the statistics pass)
-    try:
-        _conv_bn_statistics_case(shape, C, ops, conv_bn_act)
-    finally:
-        ops.CONV_BN_STATS = monkey
-
-
-def _conv_bn_statistics_case(shape, C, ops, conv_bn_act):
-    N, Ci, H, W, Co, k = shape
-    torch.manual_seed(3)
-    conv = torch.nn.Conv2d(Ci, Co, k, padding=(k[0] // 2, k[1] // 2)).cuda()
-    x = torch.randn(N, Ci, H, W, device='cuda')
-    res = torch.randn(N, Co, H, W, device='cuda')
-    gy = torch.randn(N, Co, H, W, device='cuda')
-    g = ops._geom(x, None, conv.weight, (1, 1), conv.padding)
-    assert ops._lib().dynmm_conv2d_stats_tiles(C.byref(g)) > 0
-    outs = []
-    for fused in (True, False):
-        bn = torch.nn.BatchNorm2d(Co, eps=1e-3).cuda().train()
-        with torch.no_grad():
-            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
-        torch.manual_seed(4)
-        with torch.no_grad():
-            bn.weight.copy_(torch.rand(Co) + 0.5); bn.bias.copy_(torch.randn(Co))
-        xi = x.clone().requires_grad_(True)
-        conv.zero_grad()
-        if fused:
-            y = conv_bn_act(xi, conv, bn, 'relu', residual=res)
-        else:
-            yc = ops.conv2d(xi, conv.weight, conv.bias, 1, conv.padding)          # no bn_stats: the statistics pass runs
-            assert getattr(yc, '_dynmm_stats', None) is None
-            y = ops.batch_norm_act(yc, bn, 'relu', res)
-        y.backward(gy)
-        outs.append((y.detach(), bn.running_mean.clone(), bn.running_var.clone(), xi.grad.clone(), conv.weight.grad.clone(),
-                     bn.weight.grad.clone(), int(bn.num_batches_tracked)))
-    yc = ops.conv2d(x.requires_grad_(True), conv.weight, conv.bias, 1, conv.padding, bn_stats=True)
-    part, tiles = yc._dynmm_stats
-    y64 = yc.detach().double()
-    assert rel(part.view(tiles, 2, Co)[:, 0].double().sum(0), y64.sum((0, 2, 3))) < 1e-5
-    assert rel(part.view(tiles, 2, Co)[:, 1].double().sum(0), (y64 * y64).sum((0, 2, 3))) < 1e-5
-    # closer to the fp64 statistics than the pass over y is (var = E[x^2] - mean^2 from 64-pixel fp32 trees + fp64 above them)
-    bn = torch.nn.BatchNorm2d(Co).cuda().train()
-    bn.momentum = 1.0
-    ops.batch_norm_act(yc, bn, None)
-    v64 = y64.var((0, 2, 3), unbiased=True)
-    assert ((bn.running_var.double() - v64).abs() / v64).max().item() < 2e-5
-    a, b = outs
-    assert a[6] == b[6] == 1
-    for i in range(6):
-        assert rel(a[i], b[i]) < (2e-5 if i >= 3 else 5e-6), i
-
-
-@pytest.mark.parametrize('shape', [(4, 128, 30, 40), (3, 64, 15, 20), (2, 256, 12, 16)])
-def test_bn_backward_reductions_from_the_dgrad_epilogue(shape):
-    """NonBottleneck1D, training: the input-gradient kernel of conv3x1_2 also produces the two reductions of bn1's backward
-    (sum g, sum g*xhat per pixel tile; ops.BNLink) — every gradient against the same block with bn1's own reduction pass
-    (the two summation orders differ below 1e-6; nothing downstream of them takes a ReLU decision), and the link was used."""
-    from dynmm_amd import ops
-    from dynmm_amd.nn.blocks import NonBottleneck1D
-    N, Cc, H, W = shape
-    torch.manual_seed(5)
-    blk = NonBottleneck1D(Cc, Cc)
-    synth.fill_state_dict(blk.state_dict(), seed=4)
-    blk = blk.cuda().train()
-    x = torch.randn(N, Cc, H, W, device='cuda')
-    gy = torch.randn(N, Cc, H, W, device='cuda')
-    used = []
-    orig = ops._lib().dynmm_conv2d_dgrad_bnstats
-    outs = []
-    default = ops.BN_BWD_FUSE
-    for fused in (True, False):
-        ops.BN_BWD_FUSE = fused                    # opt-in path (default: bn1's own reduction pass)
-        try:
-            blk.zero_grad()
-            xi = x.clone().requires_grad_(True)
-            blk(xi).backward(gy)
-            outs.append([xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
-        finally:
-            ops.BN_BWD_FUSE = default
-    names = ['dx'] + [n for n, _ in blk.named_parameters()]
-    gmax = max(t.abs().max().item() for t in outs[1][1:])
-    for n, a, b in zip(names, *outs):
-        if b.abs().max().item() < 1e-5 * gmax:
-            continue                              # analytically-zero gradients (conv bias in front of a train-mode BatchNorm)
-        assert rel(a, b) < 2e-5, n
-    # the fused run really used the link: bn1's output carries it, conv3x1_2's backward fills it, bn1's backward empties it
-    seen = []
-    orig = ops._BatchNormAct.backward
-
-    def spy(ctx, g_):
-        seen.append(ctx.bnlink is not None and ctx.bnlink.partials is not None)
-        return orig(ctx, g_)
-    ops._BatchNormAct.backward = staticmethod(spy)
-    ops.BN_BWD_FUSE = True
-    try:
-        xi = x.clone().requires_grad_(True)
-        blk(xi).backward(gy)
-    finally:
-        ops._BatchNormAct.backward = staticmethod(orig)
-        ops.BN_BWD_FUSE = default
-    assert seen == [False, True], seen            # bn2 (residual + ReLU: own reduction), then bn1 (from the epilogue)

@@ -65,7 +65,7 @@ CONV_CASES = [
     (2, 64, 12, 16, 128, (1, 1), (1, 1), (0, 0), False, None),       # 1x1: no padding at all, 4 K-steps (ring depth)
     (2, 512, 15, 20, 512, (3, 1), (1, 1), (1, 0), True, None),       # K = 1536: 96 K-steps
     (1, 96, 8, 16, 192, (3, 3), (1, 1), (1, 1), True, None),         # Ci = 6 chunks, Co = 3 x 64
-    (4, 512, 15, 20, 512, (1, 3), (1, 1), (0, 1), True, 'relu'),     # 76 tiles, 96 K-steps (K split 4 ways under DYNMM_V5_SPLITK=1)
+    (4, 512, 15, 20, 512, (1, 3), (1, 1), (0, 1), True, 'relu'),     # 76 tiles, 96 K-steps
     (2, 256, 30, 40, 256, (3, 3), (1, 1), (1, 1), False, None),      # 76 tiles, K = 2304
     # three-tap weight-gradient kernel (conv_wgrad_v6.hip): stride 1, same padding, W % 4 == 0 >= 16, Ci, Co % 64 == 0
     (3, 128, 15, 20, 128, (1, 3), (1, 1), (0, 1), True, None),       # M = 900: last step has one live quad; rows of 20 pixels
@@ -73,30 +73,6 @@ CONV_CASES = [
     (2, 128, 9, 16, 256, (3, 1), (1, 1), (1, 0), True, None),        # narrowest rows (one step = one row), 2 co tiles x 2 ci tiles
     (1, 192, 8, 24, 64, (1, 3), (1, 1), (0, 1), False, None),        # 3 ci tiles, no bias, a step straddles rows
 ]
-
-
-def test_conv2d_k_split_is_exact_and_reproducible():
-    """Opt-in K split of the operand-ring kernels (DYNMM_V5_SPLITK=1: ordered partial-sum hand-off between the 2 or 4
-    workgroups of a tile).  The switch is read once per process, so the check runs in a child: split vs un-split launch of the
-    same kernel (<= 2e-6: one more fp32 addition per element), bit-identical across runs, and the whole conv test list."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DYNMM_V5_SPLITK='1')
-    r = subprocess.run([sys.executable, os.path.join(root, 'scratch', 'splitk_check.py')], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rows = [ln for ln in r.stdout.splitlines() if ln.startswith('(')]
-    assert len(rows) >= 4
-    split_rows = [ln for ln in rows if 'ws MB 0.0' not in ln]
-    assert len(split_rows) >= 3, rows                     # the C = 512 shapes and the 6-sample compacted stage really split
-    for ln in split_rows:
-        rel = float(ln.split('split-vs-unsplit rel ')[1].split()[0])
-        assert rel < 2e-6 and 'reproducible True' in ln, ln
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_hip_ops.py'), '-q', '-m', 'gpu', '-k',
-                        'test_conv2d_fwd_bwd', '-x'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0, r.stdout[-2000:]
-
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
@@ -468,32 +444,90 @@ def test_eval_confusion(ops, label_hw):
     assert cm.sum().item() == 2 * mask.sum().item()
 
 
-@pytest.mark.parametrize('precision,tol,gtol', [('bf16x3', 5e-5, 5e-4), ('bf16x6', 2e-5, 2e-4)])
-@pytest.mark.parametrize('case', [(2, 128, 24, 32, 128, (3, 1), (1, 1), (1, 0)), (2, 64, 24, 32, 64, (1, 3), (1, 1), (0, 1)),
-                                  (2, 256, 12, 16, 512, (3, 1), (2, 1), (1, 0)), (2, 128, 24, 32, 128, (3, 3), (1, 1), (1, 1))])
-def test_conv2d_split_precision(ops, precision, tol, gtol, case):
-    """Opt-in bf16 split-precision matrix-core paths (csrc/conv_bf16x3.hip): forward and input gradient vs
-    a float64 PyTorch reference.  bf16x3 = 16 mantissa bits (3 MFMAs), bf16x6 = 24 bits (6 MFMAs)."""
-    N, Ci, H, W, Co, k, s, p = case
-    x, w = rnd(N, Ci, H, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * k[0] * k[1]) ** -0.5)
+WINO_CASES = [
+    # (N, Ci, H, W, Co, kernel): stride 1, same padding, Ci, Co % 64 == 0, W % 4 == 0
+    (3, 128, 15, 20, 128, (1, 3)),       # odd H, 900 pixels: ragged last pair tile
+    (5, 64, 17, 20, 64, (3, 1)),         # vertical pairs with an odd number of rows (the last pair has one live row)
+    (2, 128, 9, 16, 256, (3, 1)),        # two output-channel tiles
+    (2, 192, 8, 24, 64, (1, 3)),         # 64-channel output tile (128 pairs per workgroup), 24 chunks
+    (2, 64, 12, 16, 128, (3, 3)),        # 3x3: vertical taps looped, zero slot for rows outside the image
+    (4, 128, 30, 40, 128, (3, 3)),
+    (7, 64, 6, 12, 64, (3, 1)),
+    (2, 256, 15, 20, 64, (1, 3)),
+]
+
+
+@pytest.mark.parametrize('mode', ['dgrad', 'all'])
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv2d_winograd(ops, mode, case):
+    """csrc/conv_wino.hip (1-D Winograd F(2,3), fp32 MFMA) through ops.conv2d: the forward (mode 'all') and the input gradient
+    with both epilogue operands (ReLU mask of the producer, residual-branch gradient) against a float64 PyTorch reference at
+    the SAME bars as the direct kernels (TOL / GTOL), weight and bias gradients unchanged; and the kernel really ran."""
+    import ctypes as C
+    N, Ci, H, W, Co, k = case
+    p = (k[0] // 2, k[1] // 2)
+    x, w = rnd(N, Ci, H, W, seed=1).relu_(), rnd(Co, Ci, *k, seed=2, scale=(Ci * k[0] * k[1]) ** -0.5)
     b = rnd(Co, seed=3, scale=0.1)
     xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
-    y_ref = F.conv2d(xr, wr, br, s, p)       # no ReLU: a 1e-5 output difference would flip masks at y ~ 0
+    y_ref = F.conv2d(xr, wr, br, 1, p)
     gy = rnd(*y_ref.shape, seed=4)
+    dres = rnd(N, Ci, H, W, seed=5)
     y_ref.backward(gy.double())
-    old = ops.PRECISION
-    ops.PRECISION = precision
+    dx_ref = xr.grad * (x > 0) + dres.double()
+    old = ops.WINO
+    ops.WINO = mode
+    calls = []
+    lib = ops._lib()
     try:
         xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
-        with torch.no_grad():
-            y_inf = ops.conv2d(xg, wg, bg, s, p, None)
-        y = ops.conv2d(xg, wg, bg, s, p, None)
+        g = ops._geom(xg, None, wg, (1, 1), p)
+        assert lib.dynmm_conv2d_wino_supported(C.byref(g)) == 1
+        assert ops._wino(g, True) and ops._wino(g, False) == (mode == 'all')
+        link = ops.GradLink()
+        ops.PROFILE = calls
+        y = ops.conv2d(xg, wg, bg, 1, p, None, mask_input=True, link=link)
+        link.dres = dres.cuda()
         y.backward(gy.cuda())
     finally:
-        ops.PRECISION = old
-    assert rel(y_inf, y_ref) < tol and rel(y, y_ref) < tol
-    assert rel(xg.grad, xr.grad) < gtol
-    assert rel(wg.grad, wr.grad) < GTOL           # weight gradients stay on the fp32 kernel
+        ops.WINO = old
+        ops.PROFILE = None
+    torch.cuda.synchronize()
+    names = [c[0] for c in calls]
+    assert any(n.startswith('conv_wino_dgrad') for n in names), names
+    assert any(n.startswith('conv_wino_fwd') for n in names) == (mode == 'all'), names
+    assert rel(y, y_ref) < TOL
+    assert rel(xg.grad, dx_ref) < GTOL
+    assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL
+
+
+def test_winograd_operands_from_the_step_pack(ops):
+    """ops.PackedWeights: the filter transforms written by the ONE dynmm_wino_pack_multi launch of a step equal the per-conv
+    packs bit for bit, for both directions and all three filter shapes; geometries outside the kernel's rules are refused."""
+    import ctypes as C
+    from dynmm_amd import lib as L
+    lib = ops._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    ws = [torch.nn.Parameter(rnd(*s, seed=i).cuda()) for i, s in enumerate([(128, 64, 1, 3), (64, 64, 3, 1), (128, 128, 3, 3)])]
+    pw = ops.PackedWeights()
+    for w in ws:
+        Co, Ci, KH, KW = w.shape
+        g = L.ConvGeom(2, Ci, 16, 16, Co, 16, 16, KH, KW, 1, 1, KH // 2, KW // 2, Ci)
+        pw.register(w, g, True, False, True, True)
+    pw.pack()
+    torch.cuda.synchronize()
+    for w in ws:
+        Co, Ci, KH, KW = w.shape
+        wp, wpd, utf, utd = pw.lookup(w, True, False, True, True)
+        assert wpd is None and pw.lookup(w, True, True) is None          # the direct input-gradient layout was not requested
+        for dgrad, got in ((0, utf), (1, utd)):
+            ref = torch.empty(lib.dynmm_wino_packed_floats(Co, Ci, KH, KW), device='cuda')
+            L.check(lib.dynmm_wino_pack(w.data_ptr(), ref.data_ptr(), Co, Ci, KH, KW, dgrad, st), 'wino_pack')
+            assert torch.equal(got, ref), (tuple(w.shape), dgrad)
+    for bad in (L.ConvGeom(2, 64, 16, 16, 64, 8, 16, 3, 1, 2, 1, 1, 0, 64),      # strided
+                L.ConvGeom(2, 64, 16, 18, 64, 16, 18, 1, 3, 1, 1, 0, 1, 64),     # W % 4 != 0
+                L.ConvGeom(2, 40, 16, 16, 64, 16, 16, 1, 3, 1, 1, 0, 1, 40),     # Ci % 64 != 0
+                L.ConvGeom(2, 64, 16, 16, 64, 16, 16, 1, 1, 1, 1, 0, 0, 64)):    # 1x1
+        assert lib.dynmm_conv2d_wino_supported(C.byref(bad)) == 0
 
 
 def test_fused_eval_cache_follows_parameter_changes(ops):
