@@ -262,15 +262,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
         }
         if (++cc == NC) { cc = 0; ++cr; }
     }
-    __syncthreads();                               // every wave is done with the rings: As is reused below
-
     // ---------------------------------------------------------------- epilogue
     // output transform (lane-local), bias / residual / activation (forward) or ReLU mask / accumulated gradient (input
     // gradient), NCHW stores: horizontal pairs as 8-byte stores (256-byte runs per half wave), vertical pairs as two rows.
-    float* const sh_lds = As;
-    for (int i = t; i < TCO; i += 256) sh_lds[i] = a.shift ? a.shift[co0 + i] : 0.f;
-    __syncthreads();
-    if (!pvalid) return;
+    // The epilogue operands of batch b+1 (8 channels x 2 outputs of one accumulator block half) are requested before batch b
+    // is transformed and stored, the first batch before the rings are released: with two workgroups per CU nothing else
+    // hides their latency (a dgrad launch with a ReLU mask ran at 95 TFLOP/s against 121 without, before this).
     const float* __restrict__ res_p = a.residual;
     const float* __restrict__ mask_p = a.mask;
     float* __restrict__ y_p = a.y;
@@ -279,88 +276,105 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
     const unsigned row_bytes = (unsigned)HW * 4u;
     const unsigned second = VERT ? (unsigned)a.W * 4u : 4u;              // byte distance of the pair's second output
     const bool y1_ok = VERT ? m2 : true;
+    const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * 64 + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
+    auto off_of = [&](int b, int e) {            // batch b = 2 * mi + h, element e: channel mi * 32 + (e & 3) + 8 * (2 h + (e >> 2))
+        return off_base + (unsigned)((b >> 1) * 32 + (e & 3) + 8 * (2 * (b & 1) + (e >> 2))) * row_bytes;
+    };
+    float k0[2][8], k1[2][8], r0[2][8], r1[2][8];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int cl0 = wave_co * 64 + mi * 32 + 4 * khalf;
-        const unsigned off0 = ((unsigned)(pn * a.Co + co0 + cl0) * (unsigned)HW + (unsigned)prem) * 4u;
+    for (int e = 0; e < 8; ++e) {                 // (launches without epilogue operands never load: neutral values)
+        r0[0][e] = r1[0][e] = r0[1][e] = r1[1][e] = 0.f;
+        k0[0][e] = k1[0][e] = k0[1][e] = k1[1][e] = 1.f;
+    }
+    auto load_batch = [&](int set, int b) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float v0[8], v1[8], r0[8], r1[8], k0[8], k1[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned off = off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes;
-                r0[e] = r1[e] = 0.f;
-                k0[e] = k1[e] = 1.f;
-                if constexpr (VERT) {
-                    if (has_mask) {
-                        k0[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off);
-                        if (y1_ok) k1[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off + second);
-                    }
-                    if (has_res) {
-                        r0[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off);
-                        if (y1_ok) r1[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off + second);
-                    }
-                } else {
-                    if (has_mask) {
-                        const float2 kk = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(mask_p) + off);
-                        k0[e] = kk.x;
-                        k1[e] = kk.y;
-                    }
-                    if (has_res) {
-                        const float2 rr = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(res_p) + off);
-                        r0[e] = rr.x;
-                        r1[e] = rr.y;
-                    }
+        for (int e = 0; e < 8; ++e) {
+            const unsigned off = off_of(b, e);
+            r0[set][e] = r1[set][e] = 0.f;
+            k0[set][e] = k1[set][e] = 1.f;
+            if (!pvalid) continue;
+            if constexpr (VERT) {
+                if (has_mask) {
+                    k0[set][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off);
+                    if (y1_ok) k1[set][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off + second);
+                }
+                if (has_res) {
+                    r0[set][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off);
+                    if (y1_ok) r1[set][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off + second);
+                }
+            } else {
+                if (has_mask) {
+                    const float2 kk = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(mask_p) + off);
+                    k0[set][e] = kk.x;
+                    k1[set][e] = kk.y;
+                }
+                if (has_res) {
+                    const float2 rr = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(res_p) + off);
+                    r0[set][e] = rr.x;
+                    r1[set][e] = rr.y;
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int j = 8 * h + e;
-                const float ma = acc[0][mi][j], mb = acc[1][mi][j], mc = acc[2][mi][j], md = acc[3][mi][j];
-                const float sh = sh_lds[cl0 + (e & 3) + 8 * (2 * h + (e >> 2))];
-                float y0 = (ma + mb) + mc + sh;
-                float y1 = (mb - mc) - md + sh;
-                if (DGRAD) {
-                    if (has_mask) {
-                        y0 = k0[e] > 0.f ? y0 : 0.f;
-                        y1 = k1[e] > 0.f ? y1 : 0.f;
-                    }
-                    y0 += r0[e];
-                    y1 += r1[e];
-                } else {
-                    y0 += r0[e];
-                    y1 += r1[e];
-                    if (act == DYNMM_ACT_RELU) {
-                        y0 = y0 > 0.f ? y0 : 0.f;
-                        y1 = y1 > 0.f ? y1 : 0.f;
-                    } else if (act == DYNMM_ACT_TANH) {
-                        y0 = tanhf(y0);
-                        y1 = tanhf(y1);
-                    }
-                }
-                v0[e] = y0;
-                v1[e] = y1;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned off = off0 + (unsigned)((e & 3) + 8 * (2 * h + (e >> 2))) * row_bytes;
-                if constexpr (VERT) {
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off) = v0[e];
-                    if (y1_ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + second) = v1[e];
-                } else {
-                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(y_p) + off) = make_float2(v0[e], v1[e]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    if (has_mask || has_res) load_batch(0, 0);
+    __syncthreads();                               // every wave is done with the rings: As is reused below
+    float* const sh_lds = As;
+    for (int i = t; i < TCO; i += 256) sh_lds[i] = a.shift ? a.shift[co0 + i] : 0.f;
+    __syncthreads();
+    if (!pvalid) return;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int mi = b >> 1, h = b & 1, set = b & 1;
+        if (b + 1 < 4 && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 8 * h + e;
+            const float ma = acc[0][mi][j], mb = acc[1][mi][j], mc = acc[2][mi][j], md = acc[3][mi][j];
+            const float sh = sh_lds[wave_co * 64 + mi * 32 + 4 * khalf + (e & 3) + 8 * (2 * h + (e >> 2))];
+            float y0 = (ma + mb) + mc + sh;
+            float y1 = (mb - mc) - md + sh;
+            if (DGRAD) {
+                if (has_mask) {
+                    y0 = k0[set][e] > 0.f ? y0 : 0.f;
+                    y1 = k1[set][e] > 0.f ? y1 : 0.f;
+                }
+                y0 += r0[set][e];
+                y1 += r1[set][e];
+            } else {
+                y0 += r0[set][e];
+                y1 += r1[set][e];
+                if (act == DYNMM_ACT_RELU) {
+                    y0 = y0 > 0.f ? y0 : 0.f;
+                    y1 = y1 > 0.f ? y1 : 0.f;
+                } else if (act == DYNMM_ACT_TANH) {
+                    y0 = tanhf(y0);
+                    y1 = tanhf(y1);
+                }
+            }
+            v0[e] = y0;
+            v1[e] = y1;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned off = off_of(b, e);
+            if constexpr (VERT) {
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off) = v0[e];
+                if (y1_ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + second) = v1[e];
+            } else {
+                *reinterpret_cast<float2*>(reinterpret_cast<char*>(y_p) + off) = make_float2(v0[e], v1[e]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // Filter transforms.  w [Co][Ci][KH][KW] -> ut [KR][K][C][4] with (K, C) = (Ci, Co) for the forward operand and (Co, Ci)
 // for the input gradient's (whose taps run the other way along the Winograd axis: g0 <-> g2; the vertical taps of a 3x3
 // filter keep their index, the kernel walks them with the flipped offset).
-__global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict__ w, float4* __restrict__ ut, int Co, int Ci,
-                                                        int KH, int KW, int dgrad) {
+__global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict__ w, float4* __restrict__ ut,
+                                                        const float* __restrict__ scale, int Co, int Ci, int KH, int KW,
+                                                        int dgrad) {
     const int KR = (KH == 3 && KW == 3) ? 3 : 1;
     const int K = dgrad ? Co : Ci, Cc = dgrad ? Ci : Co;
     const size_t total = (size_t)KR * K * Cc;
@@ -373,6 +387,10 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict_
     const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
     float g0 = g[0], g1 = g[1], g2 = g[2];
     if (dgrad) { const float tmp = g0; g0 = g2; g2 = tmp; }
+    if (scale) {                                  // inference: an eval-mode BatchNorm's per-channel factor folded into the filter
+        const float sc = scale[co];
+        g0 *= sc; g1 *= sc; g2 *= sc;
+    }
     ut[o] = make_float4(g0, (g0 + g1 + g2) * 0.5f, (g0 - g1 + g2) * 0.5f, g2);
 }
 
@@ -457,14 +475,15 @@ extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
     return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * Co * Ci * 4;
 }
 
-extern "C" int dynmm_wino_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, int dgrad, void* stream) {
+extern "C" int dynmm_wino_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int KH, int KW, int dgrad,
+                               void* stream) {
     (void)hipGetLastError();
-    if (!w || !ut || Co <= 0 || Ci <= 0) return DYNMM_EINVAL;
+    if (!w || !ut || Co <= 0 || Ci <= 0 || (scale && dgrad)) return DYNMM_EINVAL;
     if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
     const size_t total = dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<float4*>(ut), Co, Ci, KH, KW, dgrad ? 1 : 0);
+                       reinterpret_cast<float4*>(ut), scale, Co, Ci, KH, KW, dgrad ? 1 : 0);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

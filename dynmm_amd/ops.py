@@ -48,14 +48,22 @@ def _chk(t, name='tensor'):
 #           taken in the forward pass), so every forward parity bar is untouched by construction;
 #   'all'   forward too (training and inference);   'fwd' forward only;   '0' off (operand-ring kernels everywhere).
 WINO = _os.environ.get('DYNMM_WINO', 'dgrad')
+# Inference (no gradient recorded: conv2d_fused_eval) is a continuous function of its roundings — no decision is
+# differentiated — so its forward takes the Winograd kernels whenever they are on at all (DYNMM_WINO_INFER=0: direct).
+WINO_INFER = _os.environ.get('DYNMM_WINO_INFER', '1') != '0'
 if WINO not in ('0', 'dgrad', 'fwd', 'all'):
     raise ValueError(f'DYNMM_WINO={WINO!r}: expected 0 | dgrad | fwd | all')
 _WINO_OK = {}
 
 
-def _wino(g, dgrad, x2=None):
+def _wino(g, dgrad, x2=None, infer=False):
     """does this pass of this convolution run on the Winograd kernels?"""
-    if WINO == '0' or x2 is not None or (WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad):
+    if WINO == '0' or x2 is not None:
+        return False
+    if infer:
+        if not WINO_INFER:
+            return False
+    elif (WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad):
         return False
     key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
     ok = _WINO_OK.get(key)
@@ -458,10 +466,10 @@ class _Conv2d(Function):
             nu = lib.dynmm_wino_packed_floats(g.Co, g.Ci, g.KH, g.KW) if (wino_f or wino_d) else 0
             if wino_f:
                 utf = torch.empty(nu, device=x.device, dtype=torch.float32)
-                L.check(lib.dynmm_wino_pack(_p(weight), _p(utf), g.Co, g.Ci, g.KH, g.KW, 0, st), 'wino_pack')
+                L.check(lib.dynmm_wino_pack(_p(weight), _p(utf), None, g.Co, g.Ci, g.KH, g.KW, 0, st), 'wino_pack')
             if wino_d:
                 utd = torch.empty(nu, device=x.device, dtype=torch.float32)
-                L.check(lib.dynmm_wino_pack(_p(weight), _p(utd), g.Co, g.Ci, g.KH, g.KW, 1, st), 'wino_pack')
+                L.check(lib.dynmm_wino_pack(_p(weight), _p(utd), None, g.Co, g.Ci, g.KH, g.KW, 1, st), 'wino_pack')
             if PREPACK is not None:
                 PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d)
         if wino_f:
@@ -635,15 +643,14 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     # address + in-place version counter of every tensor they derive from (load_state_dict / optimizer steps bump
     # the versions) and the mutation generation above: a steady-state forward launches only the conv.
     srcs = [weight, conv_bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-    slot = '_dynmm_eval_cache'
+    wino = _wino(g, False, x2, infer=True) and x.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 8 == 0)
+    slot = '_dynmm_eval_cache_wino' if wino else '_dynmm_eval_cache'
     stamp = (_MUTATION_GEN[0],) + tuple((t.data_ptr(), t._version) for t in srcs if t is not None) + \
         ((float(bn.eps),) if bn is not None else ())
     hit = getattr(weight, slot, None)
     if hit is not None and hit[0] == stamp and not torch.cuda.is_current_stream_capturing():
         wp, scale, shift = hit[1]
     else:
-        wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=dev, dtype=torch.float32)
-        L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
         scale = shift = None
         if bn is not None:
             scale = torch.empty(g.Co, device=dev, dtype=torch.float32)
@@ -652,12 +659,25 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
                                       _p(conv_bias), _p(scale), _p(shift), g.Co, bn.eps, st), 'bn_fold')
         else:
             shift = _chk(conv_bias, 'bias')
+        if wino:
+            # filter transforms of scale[co] * w: the folded BatchNorm factor rides in the operand, the kernel adds the shift
+            wp = torch.empty(lib.dynmm_wino_packed_floats(g.Co, g.Ci, g.KH, g.KW), device=dev, dtype=torch.float32)
+            L.check(lib.dynmm_wino_pack(_p(weight), _p(wp), _p(scale), g.Co, g.Ci, g.KH, g.KW, 0, st), 'wino_pack')
+            scale = None
+        else:
+            wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=dev, dtype=torch.float32)
+            L.check(lib.dynmm_pack_weight(_p(weight), _p(wp), None, g.Co, g.Ci, g.KH, g.KW, st), 'pack_weight')
         if not torch.cuda.is_current_stream_capturing():
             setattr(weight, slot, (stamp, (wp, scale, shift)))
     y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=dev, dtype=torch.float32)
-    L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
-                                                          _p(y), C.byref(g), ACT[act], st),
-                   extra=int(residual is not None)), 'conv2d_fwd')
+    if wino:
+        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd(_p(x), _p(wp), _p(shift), _p(residual), _p(y), C.byref(g),
+                                                                   ACT[act], st), extra=int(residual is not None), wino=True),
+                'conv2d_wino_fwd')
+    else:
+        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), _p(scale), _p(shift), _p(residual),
+                                                              _p(y), C.byref(g), ACT[act], st),
+                       extra=int(residual is not None)), 'conv2d_fwd')
     return y
 
 

@@ -110,12 +110,14 @@ int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask
  * by dynmm_wino_pack_multi: desc (device memory) = ndesc records of 4 int64 words { src, dst : float offsets from
  * src_base / dst_base (dst % 4 == 0) ; Co | Ci << 32 ; KH | KW << 8 | dgrad << 16 | first_workgroup << 32 }, first
  * workgroups being the running sum of dynmm_wino_pack_multi_blocks.
- *   fwd  : y = act(conv(x, w) + bias + residual)                  (bias, residual optional)
+ *   fwd  : y = act(conv(x, w) + bias + residual)                  (bias, residual optional; an eval-mode BatchNorm folds
+ *          into `scale` at pack time and `bias`: model_utils.py:11-23 conv -> BN -> act as one kernel)
  *   dgrad: dx = conv_transpose(dy, w) * [mask > 0] + accum        (mask, accum optional; the epilogue of dynmm_conv2d_dgrad)
  * x / dy / ut 16-byte aligned, y / dx / residual / mask / accum 8-byte aligned, else DYNMM_EUNSUPPORTED. */
 int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g);
 size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW);
-int dynmm_wino_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, int dgrad, void* stream);
+int dynmm_wino_pack(const float* w, float* ut, const float* scale /* [Co] or NULL, forward only: ut = transform(scale[co] * w) */,
+                    int Co, int Ci, int KH, int KW, int dgrad, void* stream);
 int dynmm_wino_pack_multi_blocks(int Co, int Ci, int KH, int KW);
 int dynmm_wino_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
                           void* stream);

@@ -21,8 +21,8 @@ def run(N, Ci, H, W, Co, KH, KW, timing=False):
     dy = torch.randn(N, Co, H, W, device='cuda'); mask = torch.randn(N, Ci, H, W, device='cuda'); acc = torch.randn(N, Ci, H, W, device='cuda')
     nf = lib.dynmm_wino_packed_floats(Co, Ci, KH, KW)
     uf = torch.empty(nf, device='cuda'); ud = torch.empty(nf, device='cuda')
-    L.check(lib.dynmm_wino_pack(p(w), p(uf), Co, Ci, KH, KW, 0, st), 'pack f')
-    L.check(lib.dynmm_wino_pack(p(w), p(ud), Co, Ci, KH, KW, 1, st), 'pack d')
+    L.check(lib.dynmm_wino_pack(p(w), p(uf), None, Co, Ci, KH, KW, 0, st), 'pack f')
+    L.check(lib.dynmm_wino_pack(p(w), p(ud), None, Co, Ci, KH, KW, 1, st), 'pack d')
     y = torch.full((N, Co, H, W), float('nan'), device='cuda'); dx = torch.full((N, Ci, H, W), float('nan'), device='cuda')
     L.check(lib.dynmm_conv2d_wino_fwd(p(x), p(uf), p(b), p(res), p(y), C.byref(g), 1, st), 'wino fwd')
     L.check(lib.dynmm_conv2d_wino_dgrad(p(dy), p(ud), p(mask), p(acc), p(dx), C.byref(g), st), 'wino dgrad')

@@ -521,7 +521,7 @@ def test_winograd_operands_from_the_step_pack(ops):
         assert wpd is None and pw.lookup(w, True, True) is None          # the direct input-gradient layout was not requested
         for dgrad, got in ((0, utf), (1, utd)):
             ref = torch.empty(lib.dynmm_wino_packed_floats(Co, Ci, KH, KW), device='cuda')
-            L.check(lib.dynmm_wino_pack(w.data_ptr(), ref.data_ptr(), Co, Ci, KH, KW, dgrad, st), 'wino_pack')
+            L.check(lib.dynmm_wino_pack(w.data_ptr(), ref.data_ptr(), None, Co, Ci, KH, KW, dgrad, st), 'wino_pack')
             assert torch.equal(got, ref), (tuple(w.shape), dgrad)
     for bad in (L.ConvGeom(2, 64, 16, 16, 64, 8, 16, 3, 1, 2, 1, 1, 0, 64),      # strided
                 L.ConvGeom(2, 64, 16, 18, 64, 16, 18, 1, 3, 1, 1, 0, 1, 64),     # W % 4 != 0
