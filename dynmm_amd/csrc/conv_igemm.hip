@@ -1140,9 +1140,13 @@ bool wgrad_v6_shape_ok(const dynmm_conv_geom* g);
 int wgrad_v6_tco(const dynmm_conv_geom* g);
 int wgrad_v6_occupancy(const dynmm_conv_geom* g);
 void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int occ, hipStream_t st);
+// (conv_wgrad_wino_vt.hip) vertical taps in the Winograd form: the reduction runs over pair positions, 8 per step
+bool wgrad_wino_vt_on(const dynmm_conv_geom* g);
+int wgrad_wino_vt_units(const dynmm_conv_geom* g);
 
 static void plan_splits(WgradPlan& p, const dynmm_conv_geom* g, int nprob) {
-    const int total_steps = ceil_div(g->N * g->Ho * g->Wo, p.bp);
+    const int units = (p.v6 && wgrad_wino_vt_on(g)) ? wgrad_wino_vt_units(g) : g->N * g->Ho * g->Wo;
+    const int total_steps = ceil_div(units, p.bp);
     const int tiles = p.n_co_tiles * p.n_k_tiles * nprob;
     int splits = p.target / tiles;
     if (splits < 1) splits = 1;
@@ -1160,7 +1164,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
     if (allow_v6 && wgrad_v6_shape_ok(g)) {
         static const int target6 = env_int("DYNMM_WGRAD_V6_BLOCKS");
         p.v6 = 1;
-        p.bp = 16;
+        p.bp = wgrad_wino_vt_on(g) ? 8 : 16;
         p.tco = wgrad_v6_tco(g);
         p.tk = 192;
         p.n_co_tiles = g->Co / p.tco;

@@ -31,8 +31,18 @@ namespace dynmm {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
-template <int MCO, bool VT, int NST, int OCC>
+// WINO (horizontal taps): the three taps of a pixel PAIR come from FOUR contractions instead of six — the weight-gradient
+// form of the 1-D Winograd algorithm the input-gradient kernels use (conv_wino.hip): with e0, e1 the pair's dY values and
+// d0..d3 the four X values under them,
+//     m1 = e0 (d0 - d2)    m2 = (e0 + e1)(d1 + d2) / 2    m3 = (e0 - e1)(d2 - d1) / 2    m4 = e1 (d1 - d3)
+//     dW[tap -1] += m1 + m2 + m3      dW[tap 0] += m2 - m3      dW[tap +1] += m2 + m3 - m4
+// summed over the pairs: 16 instead of 24 MFMAs per wave, step and 32-row block (2/3 of the matrix work), same loads, same
+// slabs (the output transform runs on the accumulators, the halvings are exact), error vs fp64 of the class of the direct
+// fp32 sum.  Both operand transforms are one add per MFMA operand in registers.
+template <int MCO, bool VT, int NST, int OCC, bool WINO = false>
 __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs a_in, const WgradGroup grp) {
+    static_assert(!(WINO && VT), "the Winograd form is implemented for the horizontal taps");
+    constexpr int NACC = WINO ? 4 : 3;
     WgradArgs a = a_in;
     constexpr int TCO = 64 * MCO, BP = 16;
     constexpr int LDG = 20, LDX = VT ? 20 : 28;                 // row strides in floats
@@ -172,11 +182,11 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     const int rd_g = (wave_co * 32 * MCO + l31) * LDG + 8 * khalf;
     const int rd_x = (wave_k * 32 + l31) * LDX + 8 * khalf;
 
-    f32x16 acc[MCO][3];
+    f32x16 acc[MCO][NACC];
 #pragma unroll
     for (int mi = 0; mi < MCO; ++mi)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NACC; ++s)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][s][j] = 0.f;
 
@@ -256,6 +266,24 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     };
     auto mfmas = [&](auto SET) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
+        if constexpr (WINO) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {           // the lane's four pixel pairs: pixels (2j, 2j + 1) = bx[4 + 2j], bx[5 + 2j]
+                const float d0 = j == 0 ? bx[S][16] : (j == 2 ? bx[S][17] : bx[S][3 + 2 * j]);
+                const float d1 = bx[S][4 + 2 * j], d2 = bx[S][5 + 2 * j];
+                const float d3 = j == 1 ? bx[S][18] : (j == 3 ? bx[S][19] : bx[S][6 + 2 * j]);
+                const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
+#pragma unroll
+                for (int mi = 0; mi < MCO; ++mi) {
+                    const float e0 = av[S][mi][2 * j], e1 = av[S][mi][2 * j + 1];
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, v0, acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, v1, acc[mi][1], 0, 0, 0);
+                    acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, v2, acc[mi][2], 0, 0, 0);
+                    acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1, v3, acc[mi][3], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
             float b0, b1, b2;
@@ -317,7 +345,14 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int co = co0 + wave_co * 32 * MCO + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
-                out[(size_t)co * rowlen + col] = acc[mi][s][j];
+                float v;
+                if constexpr (WINO) {                // output transform (m2, m3 were accumulated without their 1/2)
+                    const float hs = 0.5f * (acc[mi][1][j] + acc[mi][2][j]);
+                    v = s == 0 ? acc[mi][0][j] + hs : (s == 1 ? 0.5f * (acc[mi][1][j] - acc[mi][2][j]) : hs - acc[mi][3][j]);
+                } else {
+                    v = acc[mi][s][j];
+                }
+                out[(size_t)co * rowlen + col] = v;
             }
     }
 }
@@ -352,13 +387,32 @@ int wgrad_v6_tco(const dynmm_conv_geom* g) { return g->Co % 128 == 0 ? 128 : 64;
 int wgrad_v6_occupancy(const dynmm_conv_geom* g) {
     static const int occ_env = env_int_v6("DYNMM_WGRAD_V6_OCC", 0);
     if (g->KH == 3) return 2;
+    static const int wino = env_int_v6("DYNMM_WGRAD_WINO", 1);
+    if (wino) return g->Co % 128 == 0 ? 2 : 3;
     if (occ_env == 2 || occ_env == 3) return occ_env;
     return g->Co % 128 == 0 ? 2 : 3;
 }
 
+bool wgrad_wino_vt_on(const dynmm_conv_geom* g);
+void launch_wgrad_wino_vt(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t st);
+
 void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int occ, hipStream_t st) {
     const bool vt = a.KH == 3;
+    {
+        dynmm_conv_geom g{};
+        g.KH = a.KH; g.KW = a.KW;
+        if (vt && wgrad_wino_vt_on(&g)) {           // conv_wgrad_wino_vt.hip (the plan sized the grid for its 8-position steps)
+            launch_wgrad_wino_vt(a, grp, grid, st);
+            return;
+        }
+    }
     const bool two = a.Co % 128 == 0;
+    static const int wino = env_int_v6("DYNMM_WGRAD_WINO", 1);
+    if (wino && !vt) {                              // horizontal taps: the Winograd form (2 workgroups per CU: 4 accumulators per block)
+        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, false, 3, 2, true>), grid, dim3(256), 0, st, a, grp);
+        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, false, 3, 3, true>), grid, dim3(256), 0, st, a, grp);
+        return;
+    }
 #define DYNMM_V6(MCO, VT, OCC) hipLaunchKernelGGL((conv_wgrad_v6_kernel<MCO, VT, 3, OCC>), grid, dim3(256), 0, st, a, grp)
 #define DYNMM_V6_O(MCO, VT) do { if (occ == 3) DYNMM_V6(MCO, VT, 3); else DYNMM_V6(MCO, VT, 2); } while (0)
     if (two) { if (vt) DYNMM_V6(2, true, 2); else DYNMM_V6_O(2, false); }

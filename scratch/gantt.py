@@ -17,7 +17,7 @@ print(f'step wall {(t1 - t0) / 1e6:.2f} ms, {len(step)} dispatches')
 def cls(n):
     n = n.lower()
     if 'wgrad' in n or 'reduce_slabs' in n: return 'wgrad'
-    if 'igemm' in n or 'conv_stem' in n or 'conv_co8' in n or 'bf16' in n: return 'conv'
+    if 'igemm' in n or 'wino' in n or 'conv_stem' in n or 'conv_co8' in n: return 'conv'
     if 'bn_' in n: return 'bn'
     return 'other'
 by_q = collections.defaultdict(float)
