@@ -368,7 +368,12 @@ def roofline_of(agg):
             'kernel': name, 'launches_per_step': launches,
             'avg_launch_us': round(1000.0 * ms / launches, 2),
             'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
+            'executed_gflop_per_launch': round(flops / launches / 1e9 * (2.0 / 3.0 if 'wino' in name else 1.0), 3),
             'algorithmic_bytes_per_launch': round(abytes / launches),
+            'note': ('achieved = ALGORITHMIC (direct-convolution) FLOP / time.  conv_wino_* and the three-tap weight gradients '
+                     '(conv_wgrad_v6<..,1x3> in the Winograd form, conv_wgrad_v6<..,3x1> = conv_wgrad_wino_vt) execute 2/3 of '
+                     'their algorithmic FLOP on the matrix cores (1-D Winograd F(2,3), fp32): their figures can exceed what a '
+                     'direct kernel could reach'),
             'all_igemm_kernels': {k: {'launches': v[0], 'ms': round(v[1], 3),
                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                                   for k, v in sorted(agg.items())}}
@@ -532,6 +537,12 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     return res
 
 
+def sub_soft(args):
+    sub = argparse.Namespace(**vars(args))
+    sub.graph = False
+    return sub
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -678,6 +689,27 @@ def main():
                            'taken subset, straight-through gate gradient from the taken stages only) — DESIGN.md')
         res['unit'] = 'images/s'
         extra['train_hard'] = res
+        # opt-in: the training FORWARD on the Winograd kernels too (DYNMM_WINO=all).  Not the default: a forward with a different
+        # rounding flips ReLU decisions at rounding-level pre-activations, and the block-level gradient tests are held to
+        # bars a single flip can exceed; the headline keeps the direct forward.
+        try:
+            saved_w = ops.WINO
+            ops.WINO = 'all'
+            st3, ts3, m3 = train_workload(sub_soft(args), device, rank, 1, False, args.branches, False)
+            for _ in range(2):
+                st3()
+            k3 = max(5, args.steps // 2)
+            el = timed(st3, k3, 2, 1, device)
+            extra['train_winograd_forward'] = {
+                'value': round(args.batch * k3 / el, 2), 'unit': 'images/s', 'ms_per_step': round(1000 * el / k3, 3),
+                'workload': 'configs[2] with DYNMM_WINO=all: forward, input and weight gradients of the three-tap convolutions '
+                            'all in the Winograd form (fp32); labelled extra, NOT the headline'}
+            del st3, ts3, m3
+            torch.cuda.empty_cache()
+        except Exception as e:
+            extra['train_winograd_forward'] = {'error': f'{type(e).__name__}: {e}'}
+        finally:
+            ops.WINO = saved_w
         try:
             extra['affect_mosei'] = measure_affect(device, max(10, args.steps))
         except Exception as e:                      # a secondary line must never take the headline line down
@@ -720,6 +752,8 @@ def main():
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
+                       'winograd': {'DYNMM_WINO': ops.WINO, 'inference_forward': ops.WINO != '0' and ops.WINO_INFER,
+                                    'weight_gradients': os.environ.get('DYNMM_WGRAD_WINO', '1') != '0'},
                        'dp': dp_info},
             'whole_step': {'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
                                   f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',

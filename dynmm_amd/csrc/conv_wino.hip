@@ -239,28 +239,45 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
     };
 
     // ---------------------------------------------------------------- K loop
-    // step s: [wait: stage s has landed; stage s+1 may be in flight] barrier [request stage s+2 into the slot stage s-1
-    // just left] [k-pairs 0..3 of stage s: fragments of q+1 are read under the MFMAs of q]
+    // Stage s = 4 k-pairs; the fragments of k-pair q + 1 are read under the 8 MFMAs of k-pair q — across the stage boundary
+    // too: after the reads of the stage's last k-pair the wave waits for stage s + 1 (stage s + 2 may still be in flight),
+    // passes the barrier (every wave has the last fragments of stage s in registers: its slot is free), requests stage s + 3
+    // into that slot and reads the first fragments of stage s + 1, all under the last 8 MFMAs of stage s.
+    static_assert(BK == 8, "four k-pairs per stage");
     issue();
     issue();
+    issue();
+    wait_vm<2 * NI>();                            // (nst >= 8: Ci >= 64)
+    __syncthreads();
     int cr = 0, cc = 0;                           // vertical tap / chunk of the stage being consumed
+    const float* Ap = As;
+    const float* Bp = Bs;
+    if constexpr (!VERT) {
+        if (!(rbits & 1u)) Bp = Zs;               // this lane's row under vertical tap 0 is outside the image: all four d are 0
+    }
+    read_frags(0, 0, Ap, Bp);
     for (int s = 0; s < nst; ++s) {
-        if (s + 1 < nst) wait_vm<NI>();
-        else wait_vm<0>();
-        __syncthreads();
-        issue();
-        const float* Ap = As + (s % S) * A_STAGE;
-        const float* Bp = Bs + (s % S) * B_STAGE;
-        if constexpr (!VERT) {
-            if (!((rbits >> cr) & 1u)) Bp = Zs;   // this lane's row under vertical tap cr is outside the image: all four d are 0
+        read_frags(1, 1, Ap, Bp);
+        mfma_set(0);
+        read_frags(0, 2, Ap, Bp);
+        mfma_set(1);
+        read_frags(1, 3, Ap, Bp);
+        mfma_set(0);
+        if (s + 1 < nst) {
+            if (s + 2 < nst) wait_vm<NI>();
+            else wait_vm<0>();
+            __syncthreads();
+            issue();
+            if (++cc == NC) { cc = 0; ++cr; }
+            const int slot = (s + 1) % S;
+            Ap = As + slot * A_STAGE;
+            Bp = Bs + slot * B_STAGE;
+            if constexpr (!VERT) {
+                if (!((rbits >> cr) & 1u)) Bp = Zs;
+            }
+            read_frags(0, 0, Ap, Bp);
         }
-        read_frags(0, 0, Ap, Bp);
-#pragma unroll
-        for (int q = 0; q < BK / 2; ++q) {
-            if (q + 1 < BK / 2) read_frags((q + 1) & 1, q + 1, Ap, Bp);
-            mfma_set(q & 1);
-        }
-        if (++cc == NC) { cc = 0; ++cr; }
+        mfma_set(1);
     }
     // ---------------------------------------------------------------- epilogue
     // output transform (lane-local), bias / residual / activation (forward) or ReLU mask / accumulated gradient (input
