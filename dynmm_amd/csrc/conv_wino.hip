@@ -53,10 +53,15 @@ struct WinoArgs {
     int n_co_tiles, n_p_tiles;
 };
 
-template <int TCO, bool VERT, bool DGRAD>
-__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
+template <int TCO, int MCO, bool VERT, bool DGRAD>
+__global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
+    // MCO: 32-channel blocks per wave.  2: a wave owns 64 co x 32 pairs x 4 transforms (128 accumulator registers, two
+    // workgroups per CU); 1: 32 co x 32 pairs x 4 (64 registers, three workgroups per CU: smaller tiles for the grids a
+    // 8192-accumulator tile quantises badly, and a third neighbour to cover a workgroup's prologue / epilogue)
     constexpr int BK = 8, S = 3;
-    constexpr int WAVES_CO = TCO / 64, WAVES_P = 4 / WAVES_CO, TP = 32 * WAVES_P;
+    constexpr int WCO = 32 * MCO;
+    constexpr int WAVES_CO = TCO / WCO, WAVES_P = 4 / WAVES_CO, TP = 32 * WAVES_P;
+    static_assert(WAVES_CO * WAVES_P == 4 && (MCO == 1 || MCO == 2), "4 waves per workgroup");
     constexpr int A_STAGE = BK * TCO * 4;                                   // floats
     constexpr int PIXW = 2 * TP + 8;                                        // horizontal: pixels per staged row
     constexpr int B_STAGE = VERT ? BK * 4 * TP : BK * PIXW;
@@ -182,14 +187,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
             }
         }
     }
-    const int a_frag = (khalf * TCO + wave_co * 64 + l31) * 4;                          // + (2q * TCO + mi * 32) * 4
+    const int a_frag = (khalf * TCO + wave_co * WCO + l31) * 4;                          // + (2q * TCO + mi * 32) * 4
     const int b_frag = VERT ? khalf * 4 * TP + lp : khalf * PIXW + 2 * lp + 2;          // + 2q * (4 TP | PIXW)
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][MCO];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MCO; ++mi)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][mi][j] = 0.f;
 
@@ -197,46 +202,50 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
         for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
     }
 
-    float4 fa[2][2];                              // [register set][mi]: U_0..U_3 of (k, co)
+    float4 fa[2][MCO];                            // [register set][mi]: U_0..U_3 of (k, co)
+    float fd[2][4];                               // [register set]: raw d0..d3 of (k, pair)
     float fv[2][4];                               // [register set][transform]: V_i of (k, pair)
-    auto read_frags = [&](int set, int q, const float* Ap, const float* Bp) {
+    // The fragment traffic of k-pair q + 1 is split in two so that no LDS wait sits between the MFMAs of k-pair q (measured
+    // with the compiler's own interleaving: MFMA-busy 0.47): read_raw issues the LDS reads BEFORE the 8 MFMAs of k-pair q,
+    // transform consumes them AFTER those MFMAs have been issued (its handful of VALU instructions runs while the last MFMA
+    // executes); scheduling barriers pin the three phases.
+    auto read_raw = [&](int set, int q, const float* Ap, const float* Bp) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MCO; ++mi)
             fa[set][mi] = *reinterpret_cast<const float4*>(Ap + a_frag + (2 * q * TCO + mi * 32) * 4);
-        float d0, d1, d2, d3;
         if constexpr (VERT) {
             const float* b = Bp + b_frag + 2 * q * 4 * TP;
-            d0 = b[0];
-            d1 = b[TP];
-            d2 = b[2 * TP];
-            d3 = b[3 * TP];
-            d2 = m2 ? d2 : 0.f;
+            fd[set][0] = b[0];
+            fd[set][1] = b[TP];
+            fd[set][2] = b[2 * TP];
+            fd[set][3] = b[3 * TP];
         } else {
             const float* b = Bp + b_frag + 2 * q * PIXW;
-            const float2 u0 = *reinterpret_cast<const float2*>(b);
             const float2 u1 = *reinterpret_cast<const float2*>(b + 2);
-            const float2 u2 = *reinterpret_cast<const float2*>(b + 4);
-            d0 = u0.y;
-            d1 = u1.x;
-            d2 = u1.y;
-            d3 = u2.x;
+            fd[set][0] = b[1];
+            fd[set][1] = u1.x;
+            fd[set][2] = u1.y;
+            fd[set][3] = b[4];
         }
-        d0 = m0 ? d0 : 0.f;
-        d3 = m3 ? d3 : 0.f;
+    };
+    auto transform = [&](int set) {
+        const float d0 = m0 ? fd[set][0] : 0.f, d1 = fd[set][1];
+        const float d2 = (VERT && !m2) ? 0.f : fd[set][2], d3 = m3 ? fd[set][3] : 0.f;
         fv[set][0] = d0 - d2;
         fv[set][1] = d1 + d2;
         fv[set][2] = d2 - d1;
         fv[set][3] = d1 - d3;
     };
     auto mfma_set = [&](int set) {
-        const float av[2][4] = {{fa[set][0].x, fa[set][0].y, fa[set][0].z, fa[set][0].w},
-                                {fa[set][1].x, fa[set][1].y, fa[set][1].z, fa[set][1].w}};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int mi = 0; mi < MCO; ++mi) {
+            const float av[4] = {fa[set][mi].x, fa[set][mi].y, fa[set][mi].z, fa[set][mi].w};
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                acc[i][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][i], fv[set][i], acc[i][mi], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+                acc[i][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fv[set][i], acc[i][mi], 0, 0, 0);
+        }
     };
+#define DYNMM_WINO_PHASE() __builtin_amdgcn_sched_barrier(0)
 
     // ---------------------------------------------------------------- K loop
     // Stage s = 4 k-pairs; the fragments of k-pair q + 1 are read under the 8 MFMAs of k-pair q — across the stage boundary
@@ -255,14 +264,28 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
     if constexpr (!VERT) {
         if (!(rbits & 1u)) Bp = Zs;               // this lane's row under vertical tap 0 is outside the image: all four d are 0
     }
-    read_frags(0, 0, Ap, Bp);
+    read_raw(0, 0, Ap, Bp);
+    transform(0);
     for (int s = 0; s < nst; ++s) {
-        read_frags(1, 1, Ap, Bp);
+        DYNMM_WINO_PHASE();
+        read_raw(1, 1, Ap, Bp);
+        DYNMM_WINO_PHASE();
         mfma_set(0);
-        read_frags(0, 2, Ap, Bp);
+        DYNMM_WINO_PHASE();
+        transform(1);
+        DYNMM_WINO_PHASE();
+        read_raw(0, 2, Ap, Bp);
+        DYNMM_WINO_PHASE();
         mfma_set(1);
-        read_frags(1, 3, Ap, Bp);
+        DYNMM_WINO_PHASE();
+        transform(0);
+        DYNMM_WINO_PHASE();
+        read_raw(1, 3, Ap, Bp);
+        DYNMM_WINO_PHASE();
         mfma_set(0);
+        DYNMM_WINO_PHASE();
+        transform(1);
+        DYNMM_WINO_PHASE();
         if (s + 1 < nst) {
             if (s + 2 < nst) wait_vm<NI>();
             else wait_vm<0>();
@@ -275,10 +298,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
             if constexpr (!VERT) {
                 if (!((rbits >> cr) & 1u)) Bp = Zs;
             }
-            read_frags(0, 0, Ap, Bp);
+            read_raw(0, 0, Ap, Bp);
         }
+        DYNMM_WINO_PHASE();
         mfma_set(1);
+        DYNMM_WINO_PHASE();
+        transform(0);                             // (after the last stage: stale registers, no consumer)
     }
+#undef DYNMM_WINO_PHASE
     // ---------------------------------------------------------------- epilogue
     // output transform (lane-local), bias / residual / activation (forward) or ReLU mask / accumulated gradient (input
     // gradient), NCHW stores: horizontal pairs as 8-byte stores (256-byte runs per half wave), vertical pairs as two rows.
@@ -293,7 +320,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
     const unsigned row_bytes = (unsigned)HW * 4u;
     const unsigned second = VERT ? (unsigned)a.W * 4u : 4u;              // byte distance of the pair's second output
     const bool y1_ok = VERT ? m2 : true;
-    const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * 64 + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
+    const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * WCO + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
     auto off_of = [&](int b, int e) {            // batch b = 2 * mi + h, element e: channel mi * 32 + (e & 3) + 8 * (2 h + (e >> 2))
         return off_base + (unsigned)((b >> 1) * 32 + (e & 3) + 8 * (2 * (b & 1) + (e >> 2))) * row_bytes;
     };
@@ -340,15 +367,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoArgs a) {
     __syncthreads();
     if (!pvalid) return;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < 2 * MCO; ++b) {
         const int mi = b >> 1, h = b & 1, set = b & 1;
-        if (b + 1 < 4 && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        if (b + 1 < 2 * MCO && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
         float v0[8], v1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int j = 8 * h + e;
             const float ma = acc[0][mi][j], mb = acc[1][mi][j], mc = acc[2][mi][j], md = acc[3][mi][j];
-            const float sh = sh_lds[wave_co * 64 + mi * 32 + 4 * khalf + (e & 3) + 8 * (2 * h + (e >> 2))];
+            const float sh = sh_lds[wave_co * WCO + mi * 32 + 4 * khalf + (e & 3) + 8 * (2 * h + (e >> 2))];
             float y0 = (ma + mb) + mc + sh;
             float y1 = (mb - mc) - md + sh;
             if (DGRAD) {
@@ -456,26 +483,40 @@ static bool wino_geom_ok(const dynmm_conv_geom* g) {
     return true;
 }
 
+static int env_int_wino(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st) {
     a.H2 = (a.H + 1) / 2;
     a.MP = vert ? a.N * a.H2 * a.W : a.N * a.H * a.W / 2;
-    const int tco = (a.Co % 128 == 0) ? 128 : 64;
-    const int tp = tco == 128 ? 64 : 128;
+    // tile: 64 co x 64 pairs with 4 accumulator blocks per wave (default), or (128 co x 64 pairs | 64 co x 128 pairs) with 8
+    // (DYNMM_WINO_TILE=1).  Measured at batch 32 (scratch/r4/wino_check.py, then in the step): the small tile is faster on
+    // every encoder shape but one — C = 256 / 512: 143-148 / 125-134 against 115-122 / 108-110 TFLOP/s algorithmic (600 / 300
+    // large tiles do not fill two rounds of 512 slots), C = 64: 91-97 against 88-93, C = 128: 116-119 against 107-122 —,
+    // equal on the 3x3 convolutions; input-gradient kernel time per step 16.2 -> 14.0 ms.
+    static const int tile_env = env_int_wino("DYNMM_WINO_TILE", 0);
+    const int big_tco = (a.Co % 128 == 0) ? 128 : 64;
+    const bool small = tile_env != 1;
+    const int tco = small ? 64 : big_tco;
+    const int tp = small ? 64 : (tco == 128 ? 64 : 128);
     a.n_co_tiles = a.Co / tco;
     a.n_p_tiles = ceil_div(a.MP, tp);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
-#define DYNMM_WINO_GO(TCO)                                                                                             \
+#define DYNMM_WINO_GO(TCO, MCO)                                                                                        \
     do {                                                                                                               \
         if (vert) {                                                                                                    \
-            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, true, true>), grid, dim3(256), 0, st, a);              \
-            else hipLaunchKernelGGL((conv_wino_kernel<TCO, true, false>), grid, dim3(256), 0, st, a);                   \
+            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, true, true>), grid, dim3(256), 0, st, a);         \
+            else hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, true, false>), grid, dim3(256), 0, st, a);              \
         } else {                                                                                                       \
-            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, false, true>), grid, dim3(256), 0, st, a);             \
-            else hipLaunchKernelGGL((conv_wino_kernel<TCO, false, false>), grid, dim3(256), 0, st, a);                  \
+            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, false, true>), grid, dim3(256), 0, st, a);        \
+            else hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, false, false>), grid, dim3(256), 0, st, a);             \
         }                                                                                                              \
     } while (0)
-    if (tco == 128) DYNMM_WINO_GO(128);
-    else DYNMM_WINO_GO(64);
+    if (small) DYNMM_WINO_GO(64, 1);
+    else if (tco == 128) DYNMM_WINO_GO(128, 2);
+    else DYNMM_WINO_GO(64, 2);
 #undef DYNMM_WINO_GO
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;

@@ -268,7 +268,7 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
     if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction
-        name = f'conv_wino_{kind}<{"128x64p" if co % 128 == 0 else "64x128p"},{g.KH}x{g.KW}>'
+        name = f'conv_wino_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}>'
     if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)
         k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
         if k5 and 5 <= g.Co <= 8 and g.Ci % 4 == 0 and g.Ci >= 16 and (g.c_split == g.Ci or g.c_split % (g.Ci // 4) == 0):

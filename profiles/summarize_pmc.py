@@ -52,10 +52,8 @@ def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr, steps_
                 'conv_wgrad_v6<co64,3x1>': ('conv_wgrad_wino_vt_kernel<1>', 2),
                 # Winograd input gradients (conv_wino.hip; 16 B/lane direct-to-LDS streams).  The 1x3 and 3x3 launches share
                 # one template instance: the record averages over both (bench.py withholds `traffic` when the launch counts differ)
-                'conv_wino_dgrad<128x64p,1x3>': ('conv_wino_kernel<128, false, true>', 2),
-                'conv_wino_dgrad<128x64p,3x1>': ('conv_wino_kernel<128, true, true>', 2),
-                'conv_wino_dgrad<64x128p,1x3>': ('conv_wino_kernel<64, false, true>', 2),
-                'conv_wino_dgrad<64x128p,3x1>': ('conv_wino_kernel<64, true, true>', 2),
+                'conv_wino_dgrad<1x3+3x3>': ('conv_wino_kernel<64, 1, false, true>', 2),
+                'conv_wino_dgrad<3x1>': ('conv_wino_kernel<64, 1, true, true>', 2),
                 # the operand-ring kernels stream 16 B/lane (global_load_lds_dwordx4): the guide's x2 correction applies
                 'conv_igemm_v5_fwd<128x64,kw3>': ('conv_igemm_v5_kernel<128, 64, 64, 32, 3, false', 2),
                 'conv_igemm_v5_fwd<128x64,kw1>': ('conv_igemm_v5_kernel<128, 64, 64, 32, 1, false', 2),
