@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     issue();
     issue();
     issue();
-    wait_vm<2 * NI>();                            // (nst >= 8: Ci >= 64)
+    wait_vm<2 * NI>();                            // (nst >= 3: the launcher requires >= 24 reduction channels)
     __syncthreads();
     int cr = 0, cc = 0;                           // vertical tap / chunk of the stage being consumed
     const float* Ap = As;
@@ -470,14 +470,17 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
     reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(g0, (g0 + g1 + g2) * 0.5f, (g0 - g1 + g2) * 0.5f, g2);
 }
 
-static bool wino_geom_ok(const dynmm_conv_geom* g) {
+// rows = output channels of the GEMM (a multiple of the 64-row tile), red = its reduction channels (8 per stage, >= 3 stages):
+// forward (Co, Ci), input gradient (Ci, Co) — e.g. the input gradient of the 40-class conv_out (model.py:295-308) qualifies
+static bool wino_geom_ok(const dynmm_conv_geom* g, bool dgrad) {
     if (!g || g->c_split != g->Ci) return false;
     if (g->SH != 1 || g->SW != 1) return false;
     const bool k13 = g->KH == 1 && g->KW == 3, k31 = g->KH == 3 && g->KW == 1, k33 = g->KH == 3 && g->KW == 3;
     if (!(k13 || k31 || k33)) return false;
     if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
     if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
-    if (g->Ci % 64 != 0 || g->Co % 64 != 0) return false;
+    const int rows = dgrad ? g->Ci : g->Co, red = dgrad ? g->Co : g->Ci;
+    if (rows % 64 != 0 || red % 8 != 0 || red < 24) return false;
     if ((long long)g->N * g->H * g->W < 256) return false;
     if ((double)g->N * (g->Ci > g->Co ? g->Ci : g->Co) * g->H * g->W >= 1073741824.0) return false;   // 32-bit byte offsets
     return true;
@@ -526,7 +529,7 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st) {
 
 using namespace dynmm;
 
-extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g) { return wino_geom_ok(g) ? 1 : 0; }
+extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) { return wino_geom_ok(g, dgrad != 0) ? 1 : 0; }
 
 extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
     if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
@@ -566,7 +569,7 @@ extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const floa
                                      const dynmm_conv_geom* g, int act, void* stream) {
     (void)hipGetLastError();
     if (!x || !ut || !y || !g) return DYNMM_EINVAL;
-    if (!wino_geom_ok(g)) return DYNMM_EUNSUPPORTED;
+    if (!wino_geom_ok(g, false)) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7u) return DYNMM_EUNSUPPORTED;
     WinoArgs a{};
@@ -581,7 +584,7 @@ extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const f
                                        const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();
     if (!dy || !ut || !dx || !g) return DYNMM_EINVAL;
-    if (!wino_geom_ok(g)) return DYNMM_EUNSUPPORTED;
+    if (!wino_geom_ok(g, true)) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(accum)) & 7u)
         return DYNMM_EUNSUPPORTED;

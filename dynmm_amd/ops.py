@@ -65,10 +65,10 @@ def _wino(g, dgrad, x2=None, infer=False):
             return False
     elif (WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad):
         return False
-    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split, bool(dgrad))
     ok = _WINO_OK.get(key)
     if ok is None:
-        ok = _WINO_OK[key] = bool(_lib().dynmm_conv2d_wino_supported(C.byref(g)))
+        ok = _WINO_OK[key] = bool(_lib().dynmm_conv2d_wino_supported(C.byref(g), int(bool(dgrad))))
     return ok
 
 

@@ -101,10 +101,11 @@ int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask
                        float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
 
 /* ---- three-tap convolutions by 1-D Winograd F(2,3) on the fp32 matrix cores (csrc/conv_wino.hip) ----
- * Stride-1, same-padded 1x3 / 3x1 / 3x3 convolutions with Ci, Co % 64 == 0 and W % 4 == 0 (the factorised convolutions
+ * Stride-1, same-padded 1x3 / 3x1 / 3x3 convolutions with W % 4 == 0 whose GEMM has rows % 64 == 0 and a reduction of a multiple
+ * of 8 (>= 24) channels — (rows, reduction) = (Co, Ci) forward, (Ci, Co) input gradient — (the factorised convolutions
  * of resnet.py:124-147 and the decoder's 3x3 convolutions, model.py:343-357): four channel contractions per output PAIR
  * along the tap axis instead of six, i.e. 2/3 of the direct convolution's matrix work, in fp32 (error vs fp64 of the same
- * class as a direct fp32 sum: 2e-7 .. 4e-7 rms).  dynmm_conv2d_wino_supported(g) = 1 when the geometry qualifies.
+ * class as a direct fp32 sum: 2e-7 .. 4e-7 rms).  dynmm_conv2d_wino_supported(g, dgrad) = 1 when that pass qualifies.
  * Operand: the filter transforms ut[KR][K][C][4] (KR = 3 for 3x3, else 1; (K, C) = (Ci, Co) forward, (Co, Ci) input
  * gradient), dynmm_wino_packed_floats floats, 16-byte aligned, written by dynmm_wino_pack or — many filters in ONE launch —
  * by dynmm_wino_pack_multi: desc (device memory) = ndesc records of 4 int64 words { src, dst : float offsets from
@@ -114,7 +115,7 @@ int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask
  *          into `scale` at pack time and `bias`: model_utils.py:11-23 conv -> BN -> act as one kernel)
  *   dgrad: dx = conv_transpose(dy, w) * [mask > 0] + accum        (mask, accum optional; the epilogue of dynmm_conv2d_dgrad)
  * x / dy / ut 16-byte aligned, y / dx / residual / mask / accum 8-byte aligned, else DYNMM_EUNSUPPORTED. */
-int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g);
+int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad);
 size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW);
 int dynmm_wino_pack(const float* w, float* ut, const float* scale /* [Co] or NULL, forward only: ut = transform(scale[co] * w) */,
                     int Co, int Ci, int KH, int KW, int dgrad, void* stream);

@@ -15,7 +15,7 @@ def geom(N, Ci, H, W, Co, KH, KW):
 
 def run(N, Ci, H, W, Co, KH, KW, timing=False):
     g = geom(N, Ci, H, W, Co, KH, KW)
-    assert lib.dynmm_conv2d_wino_supported(C.byref(g)), (N, Ci, H, W, Co, KH, KW)
+    assert lib.dynmm_conv2d_wino_supported(C.byref(g), 0), (N, Ci, H, W, Co, KH, KW)
     x = torch.randn(N, Ci, H, W, device='cuda'); w = torch.randn(Co, Ci, KH, KW, device='cuda') * (2.0 / (Ci * KH * KW)) ** 0.5
     b = torch.randn(Co, device='cuda'); res = torch.randn(N, Co, H, W, device='cuda')
     dy = torch.randn(N, Co, H, W, device='cuda'); mask = torch.randn(N, Ci, H, W, device='cuda'); acc = torch.randn(N, Ci, H, W, device='cuda')
