@@ -1,0 +1,500 @@
+// Input gradients of the stride-1 three-tap / 3x3 convolutions by the 1-D Winograd algorithm F(4,3) on the fp32 matrix cores:
+// FOUR neighbouring outputs of a three-tap filter from SIX multiplications (direct: twelve; F(2,3), conv_wino.hip: eight), i.e.
+// half of the direct convolution's matrix work.  With d0..d5 the six inputs under an output quad and g the (flipped) filter:
+//     V = B^T d :  4d0-5d2+d4 | (d4-4d2)+(d3-4d1) | (d4-4d2)-(d3-4d1) | (d4-d2)+2(d3-d1) | (d4-d2)-2(d3-d1) | 4d1-5d3+d5
+//     U = G g   :  g0/4 | -(g0+g1+g2)/6 | -(g0-g1+g2)/6 | g0/24+g1/12+g2/6 | g0/24-g1/12+g2/6 | g2
+//     y = A^T m :  m0+m1+m2+m3+m4 | (m1-m2)+2(m3-m4) | (m1+m2)+4(m3+m4) | (m1-m2)+8(m3-m4)+m5          (m_i = U_i V_i)
+// over the channels: six GEMMs per output QUAD.  The price is arithmetic error: the transforms carry factors up to 8 and 1/24;
+// measured against fp64 (scratch/r4/wino43_numerics.py; tests/test_hip_ops.py on the GPU) the result is 1.7e-6 .. 2.8e-6 from
+// the truth in max-norm where a direct fp32 sum is 2e-7 .. 3e-7.  That is why this form serves the BACKWARD only — an input
+// gradient is compared with its fp64 value at 2e-4 (GTOL) and enters a gradient whose fp32 conditioning noise is 1e-2 (DESIGN.md
+// section 1); forward passes (training: direct; inference: F(2,3)) never see it.
+//
+// Structure = conv_wino.hip's small tile: 64 co x 64 quads per workgroup, a wave owns 32 co x 32 quads x 6 transforms = 6
+// accumulator blocks (96 registers, two workgroups per CU); operands by direct global -> LDS loads into a 3-slot ring (8 channels
+// per stage), fragments of k-pair q + 1 read under the 6 MFMAs of k-pair q (across stage boundaries too), phases pinned.
+//   * filter operand: two planes [tap row][ci][co][4] (U0..U3) and [tap row][ci][co][2] (U4, U5): one ds_read_b128 + one
+//     ds_read_b64 per k-pair;
+//   * horizontal taps: raw tile [8 channels][4 * quads + 8] pixels (16-byte quads, 4-pixel halo either side), a lane reads
+//     d0 | (d1..d4) | d5; vertical taps: [8 channels][6 input rows][quads] — six rows per four output rows (1.5 per row);
+//   * zero padding by lane-constant selects on the raw values (a row / column outside the image; an H that is no multiple of 4
+//     leaves the last quad with dead output rows), a whole vertical tap of a 3x3 filter outside the image reads a zero slot;
+//   * epilogue: output transform, ReLU mask of the producer, accumulated residual gradient; horizontal quads are 16-byte
+//     stores; the epilogue operands of batch b + 1 (4 channels x 4 outputs) are requested before batch b is stored.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_igemm.h"
+
+namespace dynmm {
+
+struct Wino43Args {
+    const float* x;         // input [N, Ci, H, W] (the convolution's dy: Ci = its Co)
+    const float* ut4;       // filter transforms U0..U3  [KR][Ci][Co][4]
+    const float* ut2;       //                   U4, U5  [KR][Ci][Co][2]
+    const float* residual;  // like y or nullptr: added after the mask
+    const float* mask;      // like y or nullptr: y = mask > 0 ? y : 0
+    float* y;               // [N, Co, H, W]
+    int N, Ci, Co, H, W;
+    int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
+    int MQ;                 // output quads
+    int H4;                 // vertical taps: row quads per image, (H + 3) / 4
+    int n_co_tiles, n_q_tiles;
+};
+
+template <bool VERT>
+__global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a) {
+    constexpr int BK = 8, S = 3, TCO = 64, TQ = 64, NT = 6;
+    constexpr int A4_STAGE = BK * TCO * 4, A2_STAGE = BK * TCO * 2;         // floats
+    constexpr int PIXW = 4 * TQ + 8;
+    constexpr int B_STAGE = VERT ? BK * 6 * TQ : BK * PIXW;
+    constexpr int QPR = VERT ? TQ / 4 : PIXW / 4;
+    constexpr int QB = B_STAGE / 4, QPW = QB / 4;
+    constexpr int NIB = (QPW + 63) / 64;
+    constexpr int NI = 3 + NIB;                                             // per wave and stage: 2 rows of U0..3, 2 rows of U4,5, the tile
+    static_assert(QB % 4 == 0 && NI < 32, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float A4s[S * A4_STAGE];
+    __shared__ __attribute__((aligned(16))) float A2s[S * A2_STAGE];
+    __shared__ __attribute__((aligned(16))) float Bs[S * B_STAGE];
+    __shared__ __attribute__((aligned(16))) float Zs[VERT ? 4 : B_STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave_co = wave >> 1, wave_q = wave & 1;
+    const int khalf = lane >> 5, l31 = lane & 31;
+
+    const int nblk = a.n_co_tiles * a.n_q_tiles;
+    const int lin = xcd_remap((int)blockIdx.x, nblk);
+    const int co0 = (lin % a.n_co_tiles) * TCO;
+    const int q0 = (lin / a.n_co_tiles) * TQ;
+    const int HW = a.H * a.W;
+    const int NC = a.Ci / BK;
+    const int nst = a.KR * NC;
+    auto dh_of = [&](int r) { return a.KR == 3 ? 1 - r : 0; };       // (input gradient: the vertical taps run the other way)
+
+    // ---------------------------------------------------------------- loader state
+    unsigned b_off[NIB];
+    unsigned b_rows = 0;
+    bool b_act[NIB];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int ql = i * 64 + lane;
+        b_act[i] = ql < QPW;
+        const int q = wave * QPW + (b_act[i] ? ql : 0);
+        if constexpr (VERT) {
+            const int k = q / (6 * QPR), j = (q / QPR) % 6, gq = q % QPR;
+            int p = q0 + 4 * gq;
+            p = p > a.MQ - 4 ? a.MQ - 4 : p;
+            const int per = a.H4 * a.W;
+            const int n = p / per, rr = p - n * per;
+            const int r4 = rr / a.W, w = rr - r4 * a.W;
+            const int row = 4 * r4 - 1 + j;
+            const int rowc = (row >= 0 && row < a.H) ? row : 4 * r4;
+            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)(rowc * a.W + w)) * 4u;
+        } else {
+            const int k = q / QPR, quad = q - k * QPR;
+            const int M = 4 * a.MQ;
+            int m = 4 * q0 - 4 + 4 * quad;
+            m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
+            const int n = m / HW, rem = m - n * HW;
+            const int h = rem / a.W;
+            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
+            for (int r = 0; r < a.KR; ++r) {
+                const int hh = h + dh_of(r);
+                b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
+            }
+        }
+    }
+    const unsigned a4_voff = (unsigned)lane * 16u;
+    const unsigned a2_voff = (unsigned)((lane >> 5) * a.Co * 8 + (lane & 31) * 16);      // two 512-byte rows per instruction
+    const unsigned lds_a4 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)A4s);
+    const unsigned lds_a2 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)A2s);
+    const unsigned lds_b = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Bs);
+    int l_t = 0, l_r = 0, l_c = 0;
+    auto issue = [&]() {
+        if (l_t < nst) {
+            const int slot = l_t % S;
+            const size_t row0 = (size_t)(l_r * a.Ci + l_c * BK + 2 * wave);
+            const float* a4 = a.ut4 + (row0 * a.Co + co0) * 4;
+            const unsigned a4dst = lds_a4 + (unsigned)((slot * A4_STAGE + 2 * wave * TCO * 4) * 4);
+            dma16(a4, a4_voff, a4dst);
+            dma16(a4 + (size_t)a.Co * 4, a4_voff, a4dst + 1024u);
+            dma16(a.ut2 + (row0 * a.Co + co0) * 2, a2_voff, lds_a2 + (unsigned)((slot * A2_STAGE + 2 * wave * TCO * 2) * 4));
+            const float* bbase = a.x + (size_t)(l_c * BK) * HW;
+            const unsigned bdst = lds_b + (unsigned)((slot * B_STAGE + wave * QPW * 4) * 4);
+            const int shift = dh_of(l_r) * a.W * 4;
+#pragma unroll
+            for (int i = 0; i < NIB; ++i) {
+                unsigned voff = b_off[i];
+                if constexpr (!VERT) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? (unsigned)shift : 0u;
+                if (b_act[i]) dma16(bbase, voff, bdst + (unsigned)i * 1024u);
+            }
+            ++l_t;
+            if (++l_c == NC) { l_c = 0; ++l_r; }
+        }
+    };
+
+    // ---------------------------------------------------------------- consumer state
+    const int lq = wave_q * 32 + l31;             // quad of this lane inside the tile
+    const int qg = q0 + lq;
+    const bool qvalid = qg < a.MQ;
+    int pn, prem;                                 // image and pixel offset of the quad's first output
+    bool dv[6];                                   // d_j lies inside the image
+    bool ov[4];                                   // output j exists (vertical taps: H % 4 != 0)
+    unsigned rbits = 7u;
+    {
+        const int pc = qvalid ? qg : 0;
+        if constexpr (VERT) {
+            const int per = a.H4 * a.W;
+            pn = pc / per;
+            const int rr = pc - pn * per;
+            const int r4 = rr / a.W, w = rr - r4 * a.W;
+            prem = 4 * r4 * a.W + w;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dv[j] = (unsigned)(4 * r4 - 1 + j) < (unsigned)a.H;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = 4 * r4 + j < a.H;
+        } else {
+            const int m = 4 * pc;
+            pn = m / HW;
+            prem = m - pn * HW;
+            const int h = prem / a.W, w = prem - h * a.W;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dv[j] = true;
+            dv[0] = w > 0;
+            dv[5] = w + 4 < a.W;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = true;
+            if (a.KR == 3) {
+                rbits = 0;
+                for (int r = 0; r < 3; ++r) {
+                    const int hh = h + dh_of(r);
+                    rbits |= (hh >= 0 && hh < a.H) ? (1u << r) : 0u;
+                }
+            }
+        }
+    }
+    const int a4_frag = (khalf * TCO + wave_co * 32 + l31) * 4;            // + 2q * TCO * 4
+    const int a2_frag = (khalf * TCO + wave_co * 32 + l31) * 2;            // + 2q * TCO * 2
+    const int b_frag = VERT ? khalf * 6 * TQ + lq : khalf * PIXW + 4 * lq + 3;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    if constexpr (!VERT) {
+        for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
+    }
+
+    float4 fa4[2];
+    float2 fa2[2];
+    float fd[2][6], fv[2][6];
+    auto read_raw = [&](int set, int q, const float* A4p, const float* A2p, const float* Bp) {
+        fa4[set] = *reinterpret_cast<const float4*>(A4p + a4_frag + 2 * q * TCO * 4);
+        fa2[set] = *reinterpret_cast<const float2*>(A2p + a2_frag + 2 * q * TCO * 2);
+        if constexpr (VERT) {
+            const float* b = Bp + b_frag + 2 * q * 6 * TQ;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) fd[set][j] = b[j * TQ];
+        } else {
+            const float* b = Bp + b_frag + 2 * q * PIXW;
+            const float4 u = *reinterpret_cast<const float4*>(b + 1);
+            fd[set][0] = b[0];
+            fd[set][1] = u.x; fd[set][2] = u.y; fd[set][3] = u.z; fd[set][4] = u.w;
+            fd[set][5] = b[5];
+        }
+    };
+    auto transform = [&](int set) {
+        float d[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[j] = dv[j] ? fd[set][j] : 0.f;
+        const float p = fmaf(-4.f, d[2], d[4]), q_ = fmaf(-4.f, d[1], d[3]);
+        const float c = d[4] - d[2], e = d[3] - d[1];
+        fv[set][0] = fmaf(-5.f, d[2], fmaf(4.f, d[0], d[4]));
+        fv[set][1] = p + q_;
+        fv[set][2] = p - q_;
+        fv[set][3] = fmaf(2.f, e, c);
+        fv[set][4] = fmaf(-2.f, e, c);
+        fv[set][5] = fmaf(-5.f, d[3], fmaf(4.f, d[1], d[5]));
+    };
+    auto mfma_set = [&](int set) {
+        const float av[6] = {fa4[set].x, fa4[set].y, fa4[set].z, fa4[set].w, fa2[set].x, fa2[set].y};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fv[set][i], acc[i], 0, 0, 0);
+    };
+#define DYNMM_W43_PHASE() __builtin_amdgcn_sched_barrier(0)
+
+    // ---------------------------------------------------------------- K loop (conv_wino.hip's)
+    issue();
+    issue();
+    issue();
+    wait_vm<2 * NI>();
+    __syncthreads();
+    int cr = 0, cc = 0;
+    const float* A4p = A4s;
+    const float* A2p = A2s;
+    const float* Bp = Bs;
+    if constexpr (!VERT) {
+        if (!(rbits & 1u)) Bp = Zs;
+    }
+    read_raw(0, 0, A4p, A2p, Bp);
+    transform(0);
+    for (int s = 0; s < nst; ++s) {
+        DYNMM_W43_PHASE();
+        read_raw(1, 1, A4p, A2p, Bp);
+        DYNMM_W43_PHASE();
+        mfma_set(0);
+        DYNMM_W43_PHASE();
+        transform(1);
+        DYNMM_W43_PHASE();
+        read_raw(0, 2, A4p, A2p, Bp);
+        DYNMM_W43_PHASE();
+        mfma_set(1);
+        DYNMM_W43_PHASE();
+        transform(0);
+        DYNMM_W43_PHASE();
+        read_raw(1, 3, A4p, A2p, Bp);
+        DYNMM_W43_PHASE();
+        mfma_set(0);
+        DYNMM_W43_PHASE();
+        transform(1);
+        DYNMM_W43_PHASE();
+        if (s + 1 < nst) {
+            if (s + 2 < nst) wait_vm<NI>();
+            else wait_vm<0>();
+            __syncthreads();
+            issue();
+            if (++cc == NC) { cc = 0; ++cr; }
+            const int slot = (s + 1) % S;
+            A4p = A4s + slot * A4_STAGE;
+            A2p = A2s + slot * A2_STAGE;
+            Bp = Bs + slot * B_STAGE;
+            if constexpr (!VERT) {
+                if (!((rbits >> cr) & 1u)) Bp = Zs;
+            }
+            read_raw(0, 0, A4p, A2p, Bp);
+        }
+        DYNMM_W43_PHASE();
+        mfma_set(1);
+        DYNMM_W43_PHASE();
+        transform(0);
+    }
+#undef DYNMM_W43_PHASE
+
+    // ---------------------------------------------------------------- epilogue
+    const float* __restrict__ res_p = a.residual;
+    const float* __restrict__ mask_p = a.mask;
+    float* __restrict__ y_p = a.y;
+    const bool has_res = res_p != nullptr, has_mask = mask_p != nullptr;
+    const unsigned row_bytes = (unsigned)HW * 4u;
+    const unsigned step_bytes = VERT ? (unsigned)a.W * 4u : 4u;          // byte distance between the quad's outputs
+    const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * 32 + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
+    auto off_of = [&](int b, int e) {            // batch b: channels 8 b + 4 khalf + e, e = 0..3
+        return off_base + (unsigned)(8 * b + e) * row_bytes;
+    };
+    float kk[2][4][4], rr[2][4][4];               // [set][channel e][output j]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kk[0][e][j] = kk[1][e][j] = 1.f;
+            rr[0][e][j] = rr[1][e][j] = 0.f;
+        }
+    auto load_batch = [&](int set, int b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned off = off_of(b, e);
+            if (!qvalid) continue;
+            if constexpr (VERT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (has_mask && ov[j]) kk[set][e][j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off + j * step_bytes);
+                    if (has_res && ov[j]) rr[set][e][j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off + j * step_bytes);
+                }
+            } else {
+                if (has_mask) {
+                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mask_p) + off);
+                    kk[set][e][0] = v.x; kk[set][e][1] = v.y; kk[set][e][2] = v.z; kk[set][e][3] = v.w;
+                }
+                if (has_res) {
+                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(res_p) + off);
+                    rr[set][e][0] = v.x; rr[set][e][1] = v.y; rr[set][e][2] = v.z; rr[set][e][3] = v.w;
+                }
+            }
+        }
+    };
+    if (has_mask || has_res) load_batch(0, 0);
+    if (!qvalid) return;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int set = b & 1;
+        if (b + 1 < 4 && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        float yo[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j16 = 4 * b + e;
+            const float m0 = acc[0][j16], m1 = acc[1][j16], m2 = acc[2][j16], m3 = acc[3][j16], m4 = acc[4][j16], m5 = acc[5][j16];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            float y[4];
+            y[0] = (m0 + s12) + s34;
+            y[1] = fmaf(2.f, d34, d12);
+            y[2] = fmaf(4.f, s34, s12);
+            y[3] = fmaf(8.f, d34, d12) + m5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = y[j];
+                if (has_mask) v = kk[set][e][j] > 0.f ? v : 0.f;
+                yo[e][j] = v + rr[set][e][j];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned off = off_of(b, e);
+            if constexpr (VERT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ov[j]) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + j * step_bytes) = yo[e][j];
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(y_p) + off) = make_float4(yo[e][0], yo[e][1], yo[e][2], yo[e][3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Filter transforms of the input gradient: w [Co][Ci][KH][KW] -> ut4 [KR][Co][Ci][4], ut2 [KR][Co][Ci][2] (reduction = the
+// convolution's Co, rows = its Ci; the taps run the other way along the Winograd axis).
+__device__ __forceinline__ void wino43_u(float g0, float g1, float g2, float4& u4, float2& u2) {
+    const float s = g0 + g2;
+    u4 = make_float4(g0 * 0.25f, -(s + g1) * (1.f / 6.f), -(s - g1) * (1.f / 6.f),
+                     fmaf(g1, 1.f / 12.f, fmaf(g0, 1.f / 24.f, g2 * (1.f / 6.f))));
+    u2 = make_float2(fmaf(-g1, 1.f / 12.f, fmaf(g0, 1.f / 24.f, g2 * (1.f / 6.f))), g2);
+}
+
+struct Wino43PackDesc {
+    long long src, dst;      // float offsets from the two bases (dst: the record's ut4; its ut2 follows the ut4 block)
+    int Co, Ci, kk, blk0;    // kk = KH | KW << 8
+};
+
+__global__ void __launch_bounds__(256) wino43_pack_multi_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                                const Wino43PackDesc* __restrict__ desc, int ndesc) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const Wino43PackDesc d = desc[lo];
+    const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff;
+    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
+    const size_t total = (size_t)KR * d.Co * d.Ci;
+    const size_t o = (size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int ci = (int)(o % d.Ci);
+    const int co = (int)((o / d.Ci) % d.Co);
+    const int r = (int)(o / ((size_t)d.Ci * d.Co));
+    const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    float4 u4;
+    float2 u2;
+    wino43_u(g[2], g[1], g[0], u4, u2);           // flipped taps
+    reinterpret_cast<float4*>(dst_base + d.dst)[o] = u4;
+    reinterpret_cast<float2*>(dst_base + d.dst + total * 4)[o] = u2;
+}
+
+__global__ void __launch_bounds__(256) wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ ut, int Co, int Ci, int KH,
+                                                          int KW) {
+    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
+    const size_t total = (size_t)KR * Co * Ci;
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int ci = (int)(o % Ci);
+    const int co = (int)((o / Ci) % Co);
+    const int r = (int)(o / ((size_t)Ci * Co));
+    const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    float4 u4;
+    float2 u2;
+    wino43_u(g[2], g[1], g[0], u4, u2);
+    reinterpret_cast<float4*>(ut)[o] = u4;
+    reinterpret_cast<float2*>(ut + total * 4)[o] = u2;
+}
+
+static bool wino43_geom_ok(const dynmm_conv_geom* g) {
+    if (!g || g->c_split != g->Ci) return false;
+    if (g->SH != 1 || g->SW != 1) return false;
+    const bool k13 = g->KH == 1 && g->KW == 3, k31 = g->KH == 3 && g->KW == 1, k33 = g->KH == 3 && g->KW == 3;
+    if (!(k13 || k31 || k33)) return false;
+    if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
+    if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
+    if (g->Ci % 64 != 0 || g->Co % 8 != 0 || g->Co < 24) return false;       // rows = Ci (64-row tile), reduction = Co
+    if ((long long)g->N * g->H * g->W < 256) return false;
+    if ((double)g->N * (g->Ci > g->Co ? g->Ci : g->Co) * ((g->H + 3) / 4 * 4) * g->W >= 1073741824.0) return false;
+    return true;
+}
+
+}  // namespace dynmm
+
+using namespace dynmm;
+
+extern "C" int dynmm_conv2d_wino43_supported(const dynmm_conv_geom* g) { return wino43_geom_ok(g) ? 1 : 0; }
+
+extern "C" size_t dynmm_wino43_packed_floats(int Co, int Ci, int KH, int KW) {
+    if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
+    return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * Co * Ci * 6;
+}
+
+extern "C" int dynmm_wino43_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, void* stream) {
+    (void)hipGetLastError();
+    if (!w || !ut || Co <= 0 || Ci <= 0) return DYNMM_EINVAL;
+    if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
+    const size_t total = dynmm_wino43_packed_floats(Co, Ci, KH, KW) / 6;
+    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ut, Co, Ci,
+                       KH, KW);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_wino43_pack_multi_blocks(int Co, int Ci, int KH, int KW) {
+    return (int)ceil_div_sz(dynmm_wino43_packed_floats(Co, Ci, KH, KW) / 6, 256);
+}
+
+extern "C" int dynmm_wino43_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
+                                       void* stream) {
+    (void)hipGetLastError();
+    if (!src_base || !dst_base || !desc || ndesc <= 0 || total_blocks <= 0) return DYNMM_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dst_base) & 15u) return DYNMM_EINVAL;
+    static_assert(sizeof(Wino43PackDesc) == 32, "descriptor layout is part of the ABI (4 x int64 words)");
+    hipLaunchKernelGGL(wino43_pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, src_base, dst_base,
+                       (const Wino43PackDesc*)desc, ndesc);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_conv2d_wino43_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
+                                         const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (!dy || !ut || !dx || !g) return DYNMM_EINVAL;
+    if (!wino43_geom_ok(g)) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(dx) |
+         reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(accum)) & 15u)
+        return DYNMM_EUNSUPPORTED;
+    const int KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
+    const bool vert = g->KW == 1;
+    Wino43Args a{};
+    a.x = dy; a.ut4 = ut; a.ut2 = ut + (size_t)KR * g->Co * g->Ci * 4; a.residual = accum; a.mask = mask; a.y = dx;
+    a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;          // the roles of the channel counts swap
+    a.KR = KR;
+    a.H4 = (a.H + 3) / 4;
+    a.MQ = vert ? a.N * a.H4 * a.W : a.N * a.H * a.W / 4;
+    a.n_co_tiles = a.Co / 64;
+    a.n_q_tiles = ceil_div(a.MQ, 64);
+    dim3 grid((unsigned)(a.n_co_tiles * a.n_q_tiles));
+    if (vert) hipLaunchKernelGGL((conv_wino43_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_wino43_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}

@@ -56,6 +56,12 @@ SIGNATURES = {
     'dynmm_wino_pack_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     'dynmm_conv2d_wino_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_wino_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
+    'dynmm_conv2d_wino43_supported': (c_i, [_GP]),
+    'dynmm_wino43_packed_floats': (c_sz, [c_i, c_i, c_i, c_i]),
+    'dynmm_wino43_pack': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_wino43_pack_multi_blocks': (c_i, [c_i] * 4),
+    'dynmm_wino43_pack_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_conv2d_wino43_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wgrad_workspace_bytes': (c_sz, [_GP]),
     'dynmm_conv2d_wgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, _GP, c_f]),
     'dynmm_conv2d_wgrad_groupable': (c_i, [_GP]),

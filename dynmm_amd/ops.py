@@ -53,7 +53,28 @@ WINO = _os.environ.get('DYNMM_WINO', 'dgrad')
 WINO_INFER = _os.environ.get('DYNMM_WINO_INFER', '1') != '0'
 if WINO not in ('0', 'dgrad', 'fwd', 'all'):
     raise ValueError(f'DYNMM_WINO={WINO!r}: expected 0 | dgrad | fwd | all')
+# Input gradients: F(2,3) ('23', conv_wino.hip: 2/3 of the direct matrix work, error class of a direct fp32 sum) or F(4,3)
+# (conv_wino43.hip: 1/2 of the work, 1e-6 .. 4e-6 from fp64) — '43' everywhere it fits, '43h' (default) for the horizontal-tap
+# filters 1x3 / 3x3 only.  Measured (alternating runs on one box, scratch/r4/ab.sh): 71.95 ms with '23', 71.63 with '43h', 72.37
+# with '43' — the vertical form stages six input rows per four output rows through b32 reads and loses more to that than it
+# gains; the horizontal form's isolated launches are no faster either (6.9 vs 6.2 ms per step: transform + epilogue overhead at
+# two workgroups per CU), the step gains because the backward's three streams share one matrix pipe.
+WINO_DGRAD = _os.environ.get('DYNMM_WINO_DGRAD', '43h')
+if WINO_DGRAD not in ('23', '43', '43h'):
+    raise ValueError(f'DYNMM_WINO_DGRAD={WINO_DGRAD!r}: expected 23 | 43 | 43h')
 _WINO_OK = {}
+_WINO43_OK = {}
+
+
+def _wino43(g):
+    """input gradient of this convolution on the F(4,3) kernel?  (only consulted where _wino(g, True) holds)"""
+    if WINO_DGRAD == '23' or (WINO_DGRAD == '43h' and g.KW != 3):
+        return False
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
+    ok = _WINO43_OK.get(key)
+    if ok is None:
+        ok = _WINO43_OK[key] = bool(_lib().dynmm_conv2d_wino43_supported(C.byref(g)))
+    return ok
 
 
 def _wino(g, dgrad, x2=None, infer=False):
@@ -268,7 +289,7 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
     if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction
-        name = f'conv_wino_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}>'
+        name = f'conv_wino{"43" if wino == 43 else ""}_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}>'
     if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)
         k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
         if k5 and 5 <= g.Co <= 8 and g.Ci % 4 == 0 and g.Ci >= 16 and (g.c_split == g.Ci or g.c_split % (g.Ci // 4) == 0):
@@ -341,17 +362,17 @@ class PackedWeights:
     invalidate() only (the optimizer rewrites the weights after the body)."""
 
     def __init__(self):
-        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_fwd, need_dgrad, wino_fwd, wino_dgrad]
-        self.slots = {}          # id(weight) -> (wp, wpd, utf, utd), None where not needed
-        self.arena = self.desc = self.wdesc = None
-        self.blocks = self.wblocks = self.nwino = 0
+        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad]
+        self.slots = {}          # id(weight) -> (wp, wpd, utf, utd, utd43), None where not needed
+        self.arena = self.desc = self.wdesc = self.w43desc = None
+        self.blocks = self.wblocks = self.nwino = self.w43blocks = self.nw43 = 0
         self.valid = False
         self.dirty = False       # registrations since the arena was laid out
 
-    def register(self, weight, g, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False):
+    def register(self, weight, g, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False):
         if not isinstance(weight, torch.nn.Parameter):
             return
-        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), bool(wino_dgrad)]
+        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), bool(wino_dgrad), bool(wino43_dgrad)]
         e = self.reg.get(id(weight))
         if e is None:
             self.reg[id(weight)] = [weight, g.Co, g.Ci, g.KH, g.KW] + flags
@@ -362,13 +383,13 @@ class PackedWeights:
                     e[5 + i] = True
                     self.dirty = True
 
-    def lookup(self, weight, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False):
+    def lookup(self, weight, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False):
         if not self.valid:
             return None
         s = self.slots.get(id(weight))
         if s is None:
             return None
-        for need, t in zip((need_fwd, need_dgrad, wino_fwd, wino_dgrad), s):
+        for need, t in zip((need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad), s):
             if need and t is None:
                 return None
         return s
@@ -378,11 +399,11 @@ class PackedWeights:
         ents = list(self.reg.values())
         dev = ents[0][0].device
         base = min(e[0].data_ptr() for e in ents)
-        off, blk, wblk, rows, wrows = 0, 0, 0, [], []
+        off, blk, wblk, w43blk, rows, wrows, w43rows = 0, 0, 0, 0, [], [], []
         spans = {}
-        for w, Co, Ci, KH, KW, nf_, nd, wf, wd in ents:
+        for w, Co, Ci, KH, KW, nf_, nd, wf, wd, wd43 in ents:
             src = (w.data_ptr() - base) // 4
-            span = [None] * 4
+            span = [None] * 5
             # the multi-tensor pack always writes the forward layout; the input-gradient layout only where a direct
             # kernel reads it (dynmm_pack_weight_multi's descriptor: dst_dgrad = -1 otherwise)
             nf = lib.dynmm_packed_weight_floats(Co, Ci, KH, KW, 0)
@@ -403,12 +424,19 @@ class PackedWeights:
                     span[slot] = (off, nu)
                     off += nu                    # a multiple of 4 floats
                     wblk += lib.dynmm_wino_pack_multi_blocks(Co, Ci, KH, KW)
+            if wd43:
+                nu43 = lib.dynmm_wino43_packed_floats(Co, Ci, KH, KW)
+                w43rows.append([src, off, Co | (Ci << 32), KH | (KW << 8) | (w43blk << 32)])
+                span[4] = (off, nu43)
+                off += (nu43 + 3) & ~3
+                w43blk += lib.dynmm_wino43_pack_multi_blocks(Co, Ci, KH, KW)
             spans[id(w)] = span
         self.arena = torch.empty(off, device=dev, dtype=torch.float32)
         self.desc = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
         self.wdesc = torch.tensor(wrows, dtype=torch.int64).to(dev) if wrows else None
-        self.ndesc, self.nwino = len(rows), len(wrows)
-        self.base, self.blocks, self.wblocks = base, blk, wblk
+        self.w43desc = torch.tensor(w43rows, dtype=torch.int64).to(dev) if w43rows else None
+        self.ndesc, self.nwino, self.nw43 = len(rows), len(wrows), len(w43rows)
+        self.base, self.blocks, self.wblocks, self.w43blocks = base, blk, wblk, w43blk
         self.slots = {k: tuple(self.arena[sp[0]:sp[0] + sp[1]] if sp is not None else None for sp in span)
                       for k, span in spans.items()}
         self.dirty = False
@@ -428,6 +456,9 @@ class PackedWeights:
         if self.wdesc is not None:
             L.check(_lib().dynmm_wino_pack_multi(C.c_void_p(self.base), _p(self.arena), self.wdesc.data_ptr(), self.nwino,
                                                  self.wblocks, _stream()), 'wino_pack_multi')
+        if self.w43desc is not None:
+            L.check(_lib().dynmm_wino43_pack_multi(C.c_void_p(self.base), _p(self.arena), self.w43desc.data_ptr(), self.nw43,
+                                                   self.w43blocks, _stream()), 'wino43_pack_multi')
         self.valid = True
 
     def invalidate(self):
@@ -449,13 +480,15 @@ class _Conv2d(Function):
         # (the Winograd kernels read their input with 16-byte loads; an input off that grid takes the direct kernels)
         wino_f = _wino(g, False, x2) and x.data_ptr() % 16 == 0
         wino_d = need_dx and _wino(g, True, x2)
-        need_wp, need_wpd = not wino_f, need_dx and not wino_d
+        wino_d43 = wino_d and _wino43(g)
+        wino_d = wino_d and not wino_d43
+        need_wp, need_wpd = not wino_f, need_dx and not (wino_d or wino_d43)
         # (a Linear / Conv1d weight arrives as a [Co, Ci, 1, 1] alias of its parameter: same memory, so the parameter keys the pack)
         wkey = w_owner if w_owner is not None else weight
-        wp = wpd = utf = utd = None
-        pre = PREPACK.lookup(wkey, need_wp, need_wpd, wino_f, wino_d) if PREPACK is not None else None
+        wp = wpd = utf = utd = utd43 = None
+        pre = PREPACK.lookup(wkey, need_wp, need_wpd, wino_f, wino_d, wino_d43) if PREPACK is not None else None
         if pre is not None:
-            wp, wpd, utf, utd = pre                  # packed by the step's multi-tensor launches
+            wp, wpd, utf, utd, utd43 = pre           # packed by the step's multi-tensor launches
         else:
             if need_wp or need_wpd:
                 wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=x.device,
@@ -470,8 +503,11 @@ class _Conv2d(Function):
             if wino_d:
                 utd = torch.empty(nu, device=x.device, dtype=torch.float32)
                 L.check(lib.dynmm_wino_pack(_p(weight), _p(utd), None, g.Co, g.Ci, g.KH, g.KW, 1, st), 'wino_pack')
+            if wino_d43:
+                utd43 = torch.empty(lib.dynmm_wino43_packed_floats(g.Co, g.Ci, g.KH, g.KW), device=x.device, dtype=torch.float32)
+                L.check(lib.dynmm_wino43_pack(_p(weight), _p(utd43), g.Co, g.Ci, g.KH, g.KW, st), 'wino43_pack')
             if PREPACK is not None:
-                PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d)
+                PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d, wino_d43)
         if wino_f:
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd(_p(x), _p(utf), _p(bias), None, _p(y), C.byref(g), act, st),
                            wino=True), 'conv2d_wino_fwd')
@@ -482,11 +518,12 @@ class _Conv2d(Function):
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_x2 = x2 is not None
-        ctx.wino_d = wino_d
+        ctx.wino_d = 43 if wino_d43 else (23 if wino_d else 0)
         ctx.mask_input = mask_input       # x is a ReLU output: apply [x > 0] in the dgrad epilogue
         ctx.defer_mask = defer_mask       # our own ReLU backward is applied by the consumer's dgrad
         ctx.link = link
-        ctx.save_for_backward(x, x2, utd if wino_d else wpd, y if (act != L.ACT_NONE and not defer_mask) else None)
+        ctx.save_for_backward(x, x2, utd43 if wino_d43 else (utd if wino_d else wpd),
+                              y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
         # w_owner: the nn.Parameter that `weight` is a reshaped view of (Linear / Conv1d weights used as 1x1 convs): its
         # `.grad` has the same memory layout, so the in-place gradient protocol can write straight into it
@@ -535,10 +572,10 @@ class _Conv2d(Function):
                 # 16-byte loads of gy, 8-byte accesses to the epilogue operands: tensors off that grid (views handed in by the
                 # caller) are copied into fresh allocations first
                 gyw = gy if gy.data_ptr() % 16 == 0 else gy.clone()
-                mask, accum = (t if (t is None or t.data_ptr() % 8 == 0) else t.clone() for t in (mask, accum))
-                L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_wino_dgrad(_p(gyw), _p(wpd), _p(mask), _p(accum), _p(dx),
-                                                                               C.byref(g), st), extra=extra, wino=True),
-                        'conv2d_wino_dgrad')
+                mask, accum = (t if (t is None or t.data_ptr() % 16 == 0) else t.clone() for t in (mask, accum))
+                fn = lib.dynmm_conv2d_wino43_dgrad if ctx.wino_d == 43 else lib.dynmm_conv2d_wino_dgrad
+                L.check(_timed('dgrad', g, lambda: fn(_p(gyw), _p(wpd), _p(mask), _p(accum), _p(dx), C.byref(g), st),
+                               extra=extra, wino=ctx.wino_d), 'conv2d_wino_dgrad')
             else:
                 L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
                                                                           _p(dx2), C.byref(g), st), extra=extra), 'conv2d_dgrad')

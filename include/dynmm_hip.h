@@ -127,6 +127,23 @@ int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, co
 int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
                             const dynmm_conv_geom* g, void* stream);
 
+/* ---- input gradients by 1-D Winograd F(4,3) (csrc/conv_wino43.hip): four neighbouring outputs of a three-tap filter from six
+ * multiplications — HALF of the direct convolution's matrix work (F(2,3) above: 2/3).  The transforms carry factors up to 8 and
+ * 1/24: 1.7e-6 .. 2.8e-6 from fp64 in max-norm (direct fp32: 2e-7 .. 3e-7), which is why only the BACKWARD uses it.
+ * Same convolutions as above with Ci % 64 == 0, Co % 8 == 0 >= 24, N*H*W >= 256 (dynmm_conv2d_wino43_supported); every tensor
+ * 16-byte aligned.  Operand ut (dynmm_wino43_packed_floats floats): U0..U3 [KR][Co][Ci][4] followed by U4, U5 [KR][Co][Ci][2],
+ * written by dynmm_wino43_pack or, for many filters in ONE launch, dynmm_wino43_pack_multi (descriptor as dynmm_wino_pack_multi's,
+ * without the dgrad bit).
+ *   dx = conv_transpose(dy, w) * [mask > 0] + accum */
+int dynmm_conv2d_wino43_supported(const dynmm_conv_geom* g);
+size_t dynmm_wino43_packed_floats(int Co, int Ci, int KH, int KW);
+int dynmm_wino43_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, void* stream);
+int dynmm_wino43_pack_multi_blocks(int Co, int Ci, int KH, int KW);
+int dynmm_wino43_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
+                            void* stream);
+int dynmm_conv2d_wino43_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
+                              const dynmm_conv_geom* g, void* stream);
+
 /* dw[Co,Ci,KH,KW] = sum_{n,oh,ow} dy * x(window).  Split over the pixel range into partial slabs in
  * `workspace` (>= dynmm_conv2d_wgrad_workspace_bytes), reduced deterministically.
  * dbias (optional, [Co]) = sum_{n,oh,ow} dy: the bias gradient of the same conv, produced from the dy tiles

@@ -458,7 +458,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize('mode', ['dgrad', 'all'])
+@pytest.mark.parametrize('mode', ['dgrad', 'all', 'dgrad43'])
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_conv2d_winograd(ops, mode, case):
     """csrc/conv_wino.hip (1-D Winograd F(2,3), fp32 MFMA) through ops.conv2d: the forward (mode 'all') and the input gradient
@@ -475,8 +475,12 @@ def test_conv2d_winograd(ops, mode, case):
     dres = rnd(N, Ci, H, W, seed=5)
     y_ref.backward(gy.double())
     dx_ref = xr.grad * (x > 0) + dres.double()
-    old = ops.WINO
-    ops.WINO = mode
+    old, old_d = ops.WINO, ops.WINO_DGRAD
+    # 'dgrad43': the input gradient by F(4,3) (csrc/conv_wino43.hip: half of the direct matrix work, 1e-6 .. 4e-6 from fp64 — held
+    # to the same GTOL) wherever the geometry fits; the other two modes pin F(2,3)
+    f43 = mode == 'dgrad43'
+    ops.WINO, ops.WINO_DGRAD = ('dgrad' if f43 else mode), ('43' if f43 else '23')
+    mode = 'dgrad' if f43 else mode
     calls = []
     lib = ops._lib()
     try:
@@ -490,11 +494,11 @@ def test_conv2d_winograd(ops, mode, case):
         link.dres = dres.cuda()
         y.backward(gy.cuda())
     finally:
-        ops.WINO = old
+        ops.WINO, ops.WINO_DGRAD = old, old_d
         ops.PROFILE = None
     torch.cuda.synchronize()
     names = [c[0] for c in calls]
-    assert any(n.startswith('conv_wino_dgrad') for n in names), names
+    assert any(n.startswith('conv_wino43_dgrad' if f43 else 'conv_wino_dgrad') for n in names), names
     assert any(n.startswith('conv_wino_fwd') for n in names) == (mode == 'all' and Co % 64 == 0), names
     assert rel(y, y_ref) < TOL
     assert rel(xg.grad, dx_ref) < GTOL
@@ -513,13 +517,16 @@ def test_winograd_operands_from_the_step_pack(ops):
     for w in ws:
         Co, Ci, KH, KW = w.shape
         g = L.ConvGeom(2, Ci, 16, 16, Co, 16, 16, KH, KW, 1, 1, KH // 2, KW // 2, Ci)
-        pw.register(w, g, True, False, True, True)
+        pw.register(w, g, True, False, True, True, True)
     pw.pack()
     torch.cuda.synchronize()
     for w in ws:
         Co, Ci, KH, KW = w.shape
-        wp, wpd, utf, utd = pw.lookup(w, True, False, True, True)
+        wp, wpd, utf, utd, utd43 = pw.lookup(w, True, False, True, True, True)
         assert wpd is None and pw.lookup(w, True, True) is None          # the direct input-gradient layout was not requested
+        ref43 = torch.empty(lib.dynmm_wino43_packed_floats(Co, Ci, KH, KW), device='cuda')
+        L.check(lib.dynmm_wino43_pack(w.data_ptr(), ref43.data_ptr(), Co, Ci, KH, KW, st), 'wino43_pack')
+        assert torch.equal(utd43, ref43), tuple(w.shape)
         for dgrad, got in ((0, utf), (1, utd)):
             ref = torch.empty(lib.dynmm_wino_packed_floats(Co, Ci, KH, KW), device='cuda')
             L.check(lib.dynmm_wino_pack(w.data_ptr(), ref.data_ptr(), None, Co, Ci, KH, KW, dgrad, st), 'wino_pack')
