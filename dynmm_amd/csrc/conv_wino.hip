@@ -51,10 +51,19 @@ struct WinoArgs {
     int MP;                 // output pairs
     int H2;                 // vertical taps: row pairs per image, (H + 1) / 2
     int n_co_tiles, n_p_tiles;
+    int Hin, Win;           // input image (== H, W except for the stride-2 input gradients below)
 };
 
-template <int TCO, int MCO, bool VERT, bool DGRAD>
+// S2 (input gradient only): the same pair machinery for the STRIDE-2 three-tap convolutions that open stages 2-4 (resnet.py:
+// 104-107 with stride (2,1) / (1,2)).  Along the strided axis an output pair of dx is fed by two neighbouring dy values e0, e1:
+//     dx[2j] = W1^T e0          dx[2j+1] = W2^T e0 + W0^T e1
+// — three contractions per pair, none of them on a zero (the polyphase form; not a Winograd saving, the direct count).  A pair
+// = one dy position, the raw tile holds dy itself (horizontal: [8 ch][pairs + 8], vertical: 2 rows), the filter operand
+// carries (W1, W2, W0, 0), M1 and M2 share an accumulator.  It replaces the round-2 tile kernel's parity-class enumeration
+// (4-byte stores at stride 8, 71 TFLOP/s) with the pair kernel's 8-byte stores and operand ring.
+template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false>
 __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
+    static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
     // MCO: 32-channel blocks per wave.  2: a wave owns 64 co x 32 pairs x 4 transforms (128 accumulator registers, two
     // workgroups per CU); 1: 32 co x 32 pairs x 4 (64 registers, three workgroups per CU: smaller tiles for the grids a
     // 8192-accumulator tile quantises badly, and a third neighbour to cover a workgroup's prologue / epilogue)
@@ -63,8 +72,9 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     constexpr int WAVES_CO = TCO / WCO, WAVES_P = 4 / WAVES_CO, TP = 32 * WAVES_P;
     static_assert(WAVES_CO * WAVES_P == 4 && (MCO == 1 || MCO == 2), "4 waves per workgroup");
     constexpr int A_STAGE = BK * TCO * 4;                                   // floats
-    constexpr int PIXW = 2 * TP + 8;                                        // horizontal: pixels per staged row
-    constexpr int B_STAGE = VERT ? BK * 4 * TP : BK * PIXW;
+    constexpr int PIXW = (S2 ? TP : 2 * TP) + 8;                            // horizontal: pixels per staged row
+    constexpr int NP = S2 ? 2 : 4;                                          // vertical: input rows per pair
+    constexpr int B_STAGE = VERT ? BK * NP * TP : BK * PIXW;
     constexpr int QPR = VERT ? TP / 4 : PIXW / 4;                           // quads per (channel[, input row])
     constexpr int QB = B_STAGE / 4, QPW = QB / 4;                           // quads per stage / per wave
     constexpr int NIB = (QPW + 63) / 64;
@@ -88,6 +98,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     const int co0 = (lin % a.n_co_tiles) * TCO;
     const int p0 = (lin / a.n_co_tiles) * TP;
     const int HW = a.H * a.W;
+    const int HWin = a.Hin * a.Win;
     const int NC = a.Ci / BK;
     const int nst = a.KR * NC;
 
@@ -103,23 +114,23 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         b_act[i] = ql < QPW;
         const int q = wave * QPW + (b_act[i] ? ql : 0);
         if constexpr (VERT) {
-            const int k = q / (4 * QPR), j = (q / QPR) & 3, gq = q % QPR;
+            const int k = q / (NP * QPR), j = (q / QPR) % NP, gq = q % QPR;
             int p = p0 + 4 * gq;
             p = p > a.MP - 4 ? a.MP - 4 : p;       // quads past the tensor: any mapped address (never used)
             const int per = a.H2 * a.W;
             const int n = p / per, rr = p - n * per;
             const int r2 = rr / a.W, w = rr - r2 * a.W;
-            const int row = 2 * r2 - 1 + j;
-            const int rowc = (row >= 0 && row < a.H) ? row : 2 * r2;
-            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)(rowc * a.W + w)) * 4u;
+            const int row = S2 ? r2 + j : 2 * r2 - 1 + j;
+            const int rowc = (row >= 0 && row < a.Hin) ? row : (S2 ? r2 : 2 * r2);
+            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HWin + (unsigned)(rowc * a.Win + w)) * 4u;
         } else {
             const int k = q / QPR, quad = q - k * QPR;
-            const int M = 2 * a.MP;
-            int m = 2 * p0 - 4 + 4 * quad;
+            const int M = S2 ? a.MP : 2 * a.MP;    // input pixels
+            int m = (S2 ? p0 : 2 * p0) - 4 + 4 * quad;
             m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
-            const int n = m / HW, rem = m - n * HW;
-            const int h = rem / a.W;
-            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
+            const int n = m / HWin, rem = m - n * HWin;
+            const int h = rem / a.Win;
+            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HWin + (unsigned)rem) * 4u;
             for (int r = 0; r < a.KR; ++r) {
                 const int hh = h + dh_of(r);
                 b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
@@ -138,7 +149,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 #pragma unroll
             for (int i = 0; i < NIA; ++i)
                 dma16(abase + ((size_t)(i / IPR) * a.Co + 64 * (i % IPR)) * 4, a_voff, adst + (unsigned)i * 1024u);
-            const float* bbase = a.x + (size_t)(l_c * BK) * HW;
+            const float* bbase = a.x + (size_t)(l_c * BK) * HWin;
             const unsigned bdst = lds_b + (unsigned)((slot * B_STAGE + wave * QPW * 4) * 4);
             const int shift = dh_of(l_r) * a.W * 4;
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             prem = 2 * r2 * a.W + w;
             m0 = r2 > 0;
             m2 = 2 * r2 + 1 < a.H;
-            m3 = 2 * r2 + 2 < a.H;
+            m3 = S2 ? r2 + 1 < a.Hin : 2 * r2 + 2 < a.H;          // (S2: e1, the next dy row, exists)
         } else {
             const int m = 2 * pc;
             pn = m / HW;
@@ -177,7 +188,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             const int h = prem / a.W, w = prem - h * a.W;
             m0 = w > 0;
             m2 = true;
-            m3 = w + 2 < a.W;
+            m3 = S2 ? (w >> 1) + 1 < a.Win : w + 2 < a.W;         // (S2: e1, the next dy column, exists)
             if (a.KR == 3) {
                 rbits = 0;
                 for (int r = 0; r < 3; ++r) {
@@ -188,7 +199,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         }
     }
     const int a_frag = (khalf * TCO + wave_co * WCO + l31) * 4;                          // + (2q * TCO + mi * 32) * 4
-    const int b_frag = VERT ? khalf * 4 * TP + lp : khalf * PIXW + 2 * lp + 2;          // + 2q * (4 TP | PIXW)
+    const int b_frag = VERT ? khalf * NP * TP + lp : (S2 ? khalf * PIXW + 4 + lp : khalf * PIXW + 2 * lp + 2);   // + 2q * (NP TP | PIXW)
 
     f32x16 acc[4][MCO];
 #pragma unroll
@@ -213,7 +224,12 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi)
             fa[set][mi] = *reinterpret_cast<const float4*>(Ap + a_frag + (2 * q * TCO + mi * 32) * 4);
-        if constexpr (VERT) {
+        if constexpr (S2) {
+            const float* b = Bp + b_frag + 2 * q * (VERT ? NP * TP : PIXW);
+            fd[set][0] = b[0];
+            fd[set][1] = b[VERT ? TP : 1];
+            fd[set][2] = fd[set][3] = 0.f;
+        } else if constexpr (VERT) {
             const float* b = Bp + b_frag + 2 * q * 4 * TP;
             fd[set][0] = b[0];
             fd[set][1] = b[TP];
@@ -229,6 +245,12 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         }
     };
     auto transform = [&](int set) {
+        if constexpr (S2) {                           // V = (e0, e0, e1): no arithmetic, the zero past the last row / column
+            fv[set][0] = fv[set][1] = fd[set][0];
+            fv[set][2] = m3 ? fd[set][1] : 0.f;
+            fv[set][3] = 0.f;
+            return;
+        }
         const float d0 = m0 ? fd[set][0] : 0.f, d1 = fd[set][1];
         const float d2 = (VERT && !m2) ? 0.f : fd[set][2], d3 = m3 ? fd[set][3] : 0.f;
         fv[set][0] = d0 - d2;
@@ -240,6 +262,12 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
             const float av[4] = {fa[set][mi].x, fa[set][mi].y, fa[set][mi].z, fa[set][mi].w};
+            if constexpr (S2) {                       // M0 -> y0; M1 and M2 -> y1 (one accumulator)
+                acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], fv[set][0], acc[0][mi], 0, 0, 0);
+                acc[1][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], fv[set][1], acc[1][mi], 0, 0, 0);
+                acc[1][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], fv[set][2], acc[1][mi], 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fv[set][i], acc[i][mi], 0, 0, 0);
@@ -376,8 +404,8 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             const int j = 8 * h + e;
             const float ma = acc[0][mi][j], mb = acc[1][mi][j], mc = acc[2][mi][j], md = acc[3][mi][j];
             const float sh = sh_lds[wave_co * WCO + mi * 32 + 4 * khalf + (e & 3) + 8 * (2 * h + (e >> 2))];
-            float y0 = (ma + mb) + mc + sh;
-            float y1 = (mb - mc) - md + sh;
+            float y0 = S2 ? ma + sh : (ma + mb) + mc + sh;
+            float y1 = S2 ? mb + sh : (mb - mc) - md + sh;
             if (DGRAD) {
                 if (has_mask) {
                     y0 = k0[set][e] > 0.f ? y0 : 0.f;
@@ -430,6 +458,10 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict_
     const int co = dgrad ? k : c, ci = dgrad ? c : k;
     const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
     float g0 = g[0], g1 = g[1], g2 = g[2];
+    if (dgrad == 2) {                             // stride-2 input gradient (polyphase): (W1, W2, W0, 0), no transform
+        ut[o] = make_float4(g1, g2, g0, 0.f);
+        return;
+    }
     if (dgrad) { const float tmp = g0; g0 = g2; g2 = tmp; }
     if (scale) {                                  // inference: an eval-mode BatchNorm's per-channel factor folded into the filter
         const float sc = scale[co];
@@ -454,7 +486,7 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
         else hi = mid - 1;
     }
     const WinoPackDesc d = desc[lo];
-    const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff, dgrad = (d.kk >> 16) & 1;
+    const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff, dgrad = (d.kk >> 16) & 3;
     const int KR = (KH == 3 && KW == 3) ? 3 : 1;
     const int K = dgrad ? d.Co : d.Ci, Cc = dgrad ? d.Ci : d.Co;
     const size_t total = (size_t)KR * K * Cc;
@@ -466,6 +498,10 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
     const int co = dgrad ? k : c, ci = dgrad ? c : k;
     const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
     float g0 = g[0], g1 = g[1], g2 = g[2];
+    if (dgrad == 2) {
+        reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(g1, g2, g0, 0.f);
+        return;
+    }
     if (dgrad) { const float tmp = g0; g0 = g2; g2 = tmp; }
     reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(g0, (g0 + g1 + g2) * 0.5f, (g0 - g1 + g2) * 0.5f, g2);
 }
@@ -486,12 +522,41 @@ static bool wino_geom_ok(const dynmm_conv_geom* g, bool dgrad) {
     return true;
 }
 
+// the stride-2 three-tap convolutions whose INPUT gradient takes the polyphase pair form (S2): 3x1 stride (2,1) pad (1,0) or
+// 1x3 stride (1,2) pad (0,1) on even extents
+static bool wino_s2_geom_ok(const dynmm_conv_geom* g) {
+    if (!g || g->c_split != g->Ci) return false;
+    const bool v = g->KH == 3 && g->KW == 1 && g->SH == 2 && g->SW == 1 && g->PH == 1 && g->PW == 0;
+    const bool h = g->KH == 1 && g->KW == 3 && g->SH == 1 && g->SW == 2 && g->PH == 0 && g->PW == 1;
+    if (!v && !h) return false;
+    if (v && (g->H % 2 != 0 || g->Ho * 2 != g->H || g->Wo != g->W)) return false;
+    if (h && (g->W % 2 != 0 || g->Wo * 2 != g->W || g->Ho != g->H)) return false;
+    if (g->W % 4 != 0 || g->Wo % 4 != 0 || g->Wo < 4 || g->Ho < 1) return false;
+    if (g->Ci % 64 != 0 || g->Co % 8 != 0 || g->Co < 24) return false;
+    if ((long long)g->N * g->Ho * g->Wo < 256) return false;
+    if ((double)g->N * (g->Ci > g->Co ? g->Ci : g->Co) * g->H * g->W >= 1073741824.0) return false;
+    return true;
+}
+
 static int env_int_wino(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
-static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st) {
+static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool s2 = false) {
+    if (s2) {                                      // pairs = dy positions; a.Hin / a.Win were set by the caller
+        a.H2 = a.Hin;
+        a.MP = a.N * a.Hin * a.Win;
+        a.n_co_tiles = a.Co / 64;
+        a.n_p_tiles = ceil_div(a.MP, 64);
+        dim3 grid2((unsigned)(a.n_co_tiles * a.n_p_tiles));
+        if (vert) hipLaunchKernelGGL((conv_wino_kernel<64, 1, true, true, true>), grid2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, true, true>), grid2, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
+    a.Hin = a.H;
+    a.Win = a.W;
     a.H2 = (a.H + 1) / 2;
     a.MP = vert ? a.N * a.H2 * a.W : a.N * a.H * a.W / 2;
     // tile: 64 co x 64 pairs with 4 accumulator blocks per wave (default), or (128 co x 64 pairs | 64 co x 128 pairs) with 8
@@ -529,7 +594,10 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st) {
 
 using namespace dynmm;
 
-extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) { return wino_geom_ok(g, dgrad != 0) ? 1 : 0; }
+extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) {
+    if (wino_geom_ok(g, dgrad != 0)) return 1;
+    return (dgrad && wino_s2_geom_ok(g)) ? 2 : 0;
+}
 
 extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
     if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
@@ -539,12 +607,13 @@ extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
 extern "C" int dynmm_wino_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int KH, int KW, int dgrad,
                                void* stream) {
     (void)hipGetLastError();
-    if (!w || !ut || Co <= 0 || Ci <= 0 || (scale && dgrad)) return DYNMM_EINVAL;
+    if (!w || !ut || Co <= 0 || Ci <= 0 || (scale && dgrad) || dgrad < 0 || dgrad > 2) return DYNMM_EINVAL;
+    if (dgrad == 2 && KH == 3 && KW == 3) return DYNMM_EUNSUPPORTED;
     if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
     const size_t total = dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<float4*>(ut), scale, Co, Ci, KH, KW, dgrad ? 1 : 0);
+                       reinterpret_cast<float4*>(ut), scale, Co, Ci, KH, KW, dgrad);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -584,7 +653,8 @@ extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const f
                                        const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();
     if (!dy || !ut || !dx || !g) return DYNMM_EINVAL;
-    if (!wino_geom_ok(g, true)) return DYNMM_EUNSUPPORTED;
+    const bool s2 = !wino_geom_ok(g, true) && wino_s2_geom_ok(g);
+    if (!s2 && !wino_geom_ok(g, true)) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(accum)) & 7u)
         return DYNMM_EUNSUPPORTED;
@@ -593,5 +663,6 @@ extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const f
     a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;         // the roles of the channel counts swap
     a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = DYNMM_ACT_NONE;
-    return launch_wino(a, g->KW == 1, true, (hipStream_t)stream);
+    a.Hin = g->Ho; a.Win = g->Wo;                                             // (stride 2: dy is half as high / wide as dx)
+    return launch_wino(a, g->KW == 1, true, (hipStream_t)stream, s2);
 }

@@ -89,7 +89,8 @@ def _wino(g, dgrad, x2=None, infer=False):
     key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split, bool(dgrad))
     ok = _WINO_OK.get(key)
     if ok is None:
-        ok = _WINO_OK[key] = bool(_lib().dynmm_conv2d_wino_supported(C.byref(g), int(bool(dgrad))))
+        # 1: stride-1 three-tap / 3x3 (Winograd); 2 (input gradient only): stride-2 three-tap (polyphase form of the same kernel)
+        ok = _WINO_OK[key] = int(_lib().dynmm_conv2d_wino_supported(C.byref(g), int(bool(dgrad))))
     return ok
 
 
@@ -289,7 +290,7 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
     if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction
-        name = f'conv_wino{"43" if wino == 43 else ""}_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}>'
+        name = f'conv_wino{"43" if wino == 43 else ""}_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}{"s2" if g.SH * g.SW > 1 else ""}>'
     if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)
         k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
         if k5 and 5 <= g.Co <= 8 and g.Ci % 4 == 0 and g.Ci >= 16 and (g.c_split == g.Ci or g.c_split % (g.Ci // 4) == 0):
@@ -372,7 +373,7 @@ class PackedWeights:
     def register(self, weight, g, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False):
         if not isinstance(weight, torch.nn.Parameter):
             return
-        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), bool(wino_dgrad), bool(wino43_dgrad)]
+        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), int(wino_dgrad), bool(wino43_dgrad)]     # wino_dgrad: 0 | 1 | 2
         e = self.reg.get(id(weight))
         if e is None:
             self.reg[id(weight)] = [weight, g.Co, g.Ci, g.KH, g.KW] + flags
@@ -418,7 +419,7 @@ class PackedWeights:
                 span[1] = (dstd, ndg) if nd else None
                 blk += lib.dynmm_pack_weight_multi_blocks(Co, Ci, KH, KW, int(nd))
             nu = lib.dynmm_wino_packed_floats(Co, Ci, KH, KW)
-            for slot, dgrad, on in ((2, 0, wf), (3, 1, wd)):
+            for slot, dgrad, on in ((2, 0, wf), (3, 2 if wd == 2 else 1, wd)):     # (wd == 2: stride-2 polyphase operand)
                 if on:
                     wrows.append([src, off, Co | (Ci << 32), KH | (KW << 8) | (dgrad << 16) | (wblk << 32)])
                     span[slot] = (off, nu)
@@ -481,7 +482,7 @@ class _Conv2d(Function):
         wino_f = _wino(g, False, x2) and x.data_ptr() % 16 == 0
         wino_d = need_dx and _wino(g, True, x2)
         wino_d43 = wino_d and _wino43(g)
-        wino_d = wino_d and not wino_d43
+        wino_d = 0 if wino_d43 else int(wino_d or 0)          # 0 | 1 (stride 1) | 2 (stride 2: polyphase form)
         need_wp, need_wpd = not wino_f, need_dx and not (wino_d or wino_d43)
         # (a Linear / Conv1d weight arrives as a [Co, Ci, 1, 1] alias of its parameter: same memory, so the parameter keys the pack)
         wkey = w_owner if w_owner is not None else weight
@@ -502,7 +503,7 @@ class _Conv2d(Function):
                 L.check(lib.dynmm_wino_pack(_p(weight), _p(utf), None, g.Co, g.Ci, g.KH, g.KW, 0, st), 'wino_pack')
             if wino_d:
                 utd = torch.empty(nu, device=x.device, dtype=torch.float32)
-                L.check(lib.dynmm_wino_pack(_p(weight), _p(utd), None, g.Co, g.Ci, g.KH, g.KW, 1, st), 'wino_pack')
+                L.check(lib.dynmm_wino_pack(_p(weight), _p(utd), None, g.Co, g.Ci, g.KH, g.KW, int(wino_d), st), 'wino_pack')
             if wino_d43:
                 utd43 = torch.empty(lib.dynmm_wino43_packed_floats(g.Co, g.Ci, g.KH, g.KW), device=x.device, dtype=torch.float32)
                 L.check(lib.dynmm_wino43_pack(_p(weight), _p(utd43), g.Co, g.Ci, g.KH, g.KW, st), 'wino43_pack')

@@ -105,11 +105,14 @@ int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask
  * of 8 (>= 24) channels — (rows, reduction) = (Co, Ci) forward, (Ci, Co) input gradient — (the factorised convolutions
  * of resnet.py:124-147 and the decoder's 3x3 convolutions, model.py:343-357): four channel contractions per output PAIR
  * along the tap axis instead of six, i.e. 2/3 of the direct convolution's matrix work, in fp32 (error vs fp64 of the same
- * class as a direct fp32 sum: 2e-7 .. 4e-7 rms).  dynmm_conv2d_wino_supported(g, dgrad) = 1 when that pass qualifies.
+ * class as a direct fp32 sum: 2e-7 .. 4e-7 rms).  dynmm_conv2d_wino_supported(g, dgrad) = 1 when that pass qualifies;
+ * = 2 (dgrad only) for the STRIDE-2 three-tap convolutions — 3x1 stride (2,1) / 1x3 stride (1,2), resnet.py:104-107 in the first block
+ * of stages 2-4 — whose input gradient runs on the same pair kernel in polyphase form (dx[2j] = W1^T dy[j], dx[2j+1] = W2^T dy[j] +
+ * W0^T dy[j+1]: the direct operation count, 8-byte stores); their operand is dynmm_wino_pack(..., dgrad = 2) = (W1, W2, W0, 0).
  * Operand: the filter transforms ut[KR][K][C][4] (KR = 3 for 3x3, else 1; (K, C) = (Ci, Co) forward, (Co, Ci) input
  * gradient), dynmm_wino_packed_floats floats, 16-byte aligned, written by dynmm_wino_pack or — many filters in ONE launch —
  * by dynmm_wino_pack_multi: desc (device memory) = ndesc records of 4 int64 words { src, dst : float offsets from
- * src_base / dst_base (dst % 4 == 0) ; Co | Ci << 32 ; KH | KW << 8 | dgrad << 16 | first_workgroup << 32 }, first
+ * src_base / dst_base (dst % 4 == 0) ; Co | Ci << 32 ; KH | KW << 8 | dgrad (0, 1, 2) << 16 | first_workgroup << 32 }, first
  * workgroups being the running sum of dynmm_wino_pack_multi_blocks.
  *   fwd  : y = act(conv(x, w) + bias + residual)                  (bias, residual optional; an eval-mode BatchNorm folds
  *          into `scale` at pack time and `bias`: model_utils.py:11-23 conv -> BN -> act as one kernel)

@@ -505,6 +505,37 @@ def test_conv2d_winograd(ops, mode, case):
     assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL
 
 
+@pytest.mark.parametrize('case', [(3, 64, 16, 24, 128, (3, 1), (2, 1), (1, 0)), (3, 128, 16, 24, 128, (1, 3), (1, 2), (0, 1)),
+                                  (2, 128, 30, 40, 256, (3, 1), (2, 1), (1, 0)), (4, 64, 9, 16, 40, (1, 3), (1, 2), (0, 1))])
+def test_conv2d_stride2_input_gradient_on_the_pair_kernel(ops, case):
+    """The stride-2 three-tap convolutions that open stages 2-4 (resnet.py:104-107): their input gradient in polyphase form on
+    csrc/conv_wino.hip's pair kernel (dx[2j] = W1^T dy[j], dx[2j+1] = W2^T dy[j] + W0^T dy[j+1]), with ReLU mask and residual
+    gradient, vs float64; forward and weight gradient (unchanged kernels) ride along."""
+    N, Ci, H, W, Co, k, st_, p = case
+    x, w = rnd(N, Ci, H, W, seed=1).relu_(), rnd(Co, Ci, *k, seed=2, scale=(Ci * 3) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.conv2d(xr, wr, br, st_, p)
+    gy = rnd(*y_ref.shape, seed=4)
+    dres = rnd(N, Ci, H, W, seed=5)
+    y_ref.backward(gy.double())
+    dx_ref = xr.grad * (x > 0) + dres.double()
+    calls = []
+    try:
+        xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+        link = ops.GradLink()
+        ops.PROFILE = calls
+        y = ops.conv2d(xg, wg, bg, st_, p, None, mask_input=True, link=link)
+        link.dres = dres.cuda()
+        y.backward(gy.cuda())
+    finally:
+        ops.PROFILE = None
+    torch.cuda.synchronize()
+    assert any(n.startswith('conv_wino_dgrad') and n.endswith('s2>') for n in (c[0] for c in calls)), [c[0] for c in calls]
+    assert rel(y, y_ref) < TOL and rel(xg.grad, dx_ref) < GTOL
+    assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL
+
+
 def test_winograd_operands_from_the_step_pack(ops):
     """ops.PackedWeights: the filter transforms written by the ONE dynmm_wino_pack_multi launch of a step equal the per-conv
     packs bit for bit, for both directions and all three filter shapes; geometries outside the kernel's rules are refused."""
@@ -531,7 +562,9 @@ def test_winograd_operands_from_the_step_pack(ops):
             ref = torch.empty(lib.dynmm_wino_packed_floats(Co, Ci, KH, KW), device='cuda')
             L.check(lib.dynmm_wino_pack(w.data_ptr(), ref.data_ptr(), None, Co, Ci, KH, KW, dgrad, st), 'wino_pack')
             assert torch.equal(got, ref), (tuple(w.shape), dgrad)
-    for bad in (L.ConvGeom(2, 64, 16, 16, 64, 8, 16, 3, 1, 2, 1, 1, 0, 64),      # strided
+    strided = L.ConvGeom(2, 64, 16, 16, 64, 8, 16, 3, 1, 2, 1, 1, 0, 64)          # stride 2: input gradient only (polyphase form)
+    assert lib.dynmm_conv2d_wino_supported(C.byref(strided), 0) == 0 and lib.dynmm_conv2d_wino_supported(C.byref(strided), 1) == 2
+    for bad in (L.ConvGeom(2, 64, 16, 16, 64, 8, 8, 3, 3, 2, 2, 1, 1, 64),        # 3x3 stride 2
                 L.ConvGeom(2, 64, 16, 18, 64, 16, 18, 1, 3, 1, 1, 0, 1, 64),     # W % 4 != 0
                 L.ConvGeom(2, 20, 16, 16, 60, 16, 16, 1, 3, 1, 1, 0, 1, 20),     # neither channel count fits a 64-row tile
                 L.ConvGeom(2, 64, 16, 16, 64, 16, 16, 1, 1, 1, 1, 0, 0, 64)):    # 1x1
