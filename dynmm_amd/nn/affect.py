@@ -23,12 +23,59 @@ in_proj_weight`, ...), so `expert.state_dict()` of a trained MultiBench module l
 stream of its own (ops.manual_seed; torch's generator cannot be reproduced bit for bit, the tests inject the keep flags
 on both sides); `.eval()` switches it off as in torch.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops_seq as S
 
 FEATURES = {'visual': 35, 'audio': 74, 'text': 300}      # CMU-MOSEI (affect/count_flop.py:52)
+
+# The gate transformer and the experts' encoders are independent until the mixture: each runs on a HIP stream of its own
+# (five 5-layer transformers on 50-token sequences are chains of ~10-100 us kernels that do not fill 256 CUs one at a time).
+# Autograd replays a node on its forward stream, so the backward is concurrent too; a captured step keeps the branches as
+# parallel paths of the hipGraph.  DYNMM_AFFECT_STREAMS=0: one stream.
+BRANCH_STREAMS = os.environ.get('DYNMM_AFFECT_STREAMS', '1') != '0'
+_POOL, _ALL = [], []
+
+
+def run_branches(fns):
+    """[f() for f in fns], fns[1:] each on a side stream forked from / joined to the current one."""
+    if not (BRANCH_STREAMS and len(fns) > 1 and torch.cuda.is_available()):
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    taken = []
+    for _ in fns[1:]:
+        if not _POOL:
+            _POOL.append(torch.cuda.Stream())
+            _ALL.append(_POOL[-1])
+        taken.append(_POOL.pop())
+    first = fns[0]()                               # host order = list order (the injected-mask tests count calls)
+    outs = []
+    for st, f in zip(taken, fns[1:]):
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            outs.append(f())
+    capturing = torch.cuda.is_current_stream_capturing()
+    for st, o in zip(taken, outs):
+        main.wait_stream(st)
+        if not capturing:
+            for t in (o if isinstance(o, (list, tuple)) else [o]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)          # allocated on the side stream, consumed on `main`
+    _POOL.extend(taken)
+    return [first] + outs
+
+
+def join_branches():
+    """After a backward pass: the calling stream waits for every branch stream (their nodes ran there)."""
+    from .. import ops
+    ops.flush_wgrad_groups()                       # queued weight-gradient groups go out on their branch's stream
+    if _ALL:
+        main = torch.cuda.current_stream()
+        for st in _ALL:
+            main.wait_stream(st)
 
 
 def encoder_layer(h, layer, heads):
@@ -99,11 +146,12 @@ class MMDL(nn.Module):
         self.fuse, self.head, self.has_padding = fusion, head, has_padding
 
     def forward(self, inputs):
+        return self.head(self.fuse(run_branches(self.branch_fns(inputs))))
+
+    def branch_fns(self, inputs):
         if self.has_padding:
-            outs = [enc([inputs[0][i], inputs[1][i]]) for i, enc in enumerate(self.encoders)]
-        else:
-            outs = [enc(inputs[i]) for i, enc in enumerate(self.encoders)]
-        return self.head(self.fuse(outs))
+            return [lambda i=i, enc=enc: enc([inputs[0][i], inputs[1][i]]) for i, enc in enumerate(self.encoders)]
+        return [lambda i=i, enc=enc: enc(inputs[i]) for i, enc in enumerate(self.encoders)]
 
 
 def late_fusion_transformer():
@@ -173,8 +221,15 @@ class DynMMNetV2(_GatedMixture):
     def experts(self, inputs):
         return [self.text_head(self.text_encoder([inputs[0][2], inputs[1][2]])), self.branch2(inputs)]
 
+    def gate_and_experts(self, inputs):
+        """(gate logits, [expert predictions]) with the five transformers side by side."""
+        b2 = self.branch2
+        enc = run_branches([lambda: self.gate_logits(inputs), lambda: self.text_encoder([inputs[0][2], inputs[1][2]])]
+                           + b2.branch_fns(inputs))
+        return enc[0], [self.text_head(enc[1]), b2.head(b2.fuse(enc[2:]))]
+
     def forward(self, inputs):
-        return self._mix(self.gate_logits(inputs), self.experts(inputs))
+        return self._mix(*self.gate_and_experts(inputs))
 
     def weight_stat(self):
         tmp = torch.mean(self.weight_list, dim=0)
@@ -198,8 +253,13 @@ class DynMMNet(_GatedMixture):
     def experts(self, inputs):
         return [self.heads[i](self.encoders[i]([inputs[0][i], inputs[1][i]])) for i in range(3)]
 
+    def gate_and_experts(self, inputs):
+        outs = run_branches([lambda: self.gate_logits(inputs)]
+                            + [lambda i=i: self.heads[i](self.encoders[i]([inputs[0][i], inputs[1][i]])) for i in range(3)])
+        return outs[0], outs[1:]
+
     def forward(self, inputs):
-        return self._mix(self.gate_logits(inputs), self.experts(inputs))
+        return self._mix(*self.gate_and_experts(inputs))
 
 
 class AffectTrainStep:
@@ -239,9 +299,9 @@ class AffectTrainStep:
         try:
             with engine.direct_gradients(False):     # kernels write parameter gradients straight into flat_g
                 ops.touched_reset()
-                logits = m.gate_logits(inputs)
-                preds = m.experts(inputs)
+                logits, preds = m.gate_and_experts(inputs)
                 self.last = S.moe_loss_backward(logits, preds, target, m.temp, m.hard_gate, self.lossw)
+                join_branches()
         finally:
             self.prepack.invalidate()                # the optimizer below rewrites the weights
             ops.PREPACK = prev

@@ -149,11 +149,18 @@ def _age_wgrad_queues():
 
 
 def _queue_wgrad(g, x, gy, w_param, b_param):
-    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, b_param is not None)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream())              # gy is produced on this stream
+    st = torch.cuda.current_stream()                    # gy is produced on this stream
+    use_async = ASYNC_WGRAD and PROFILE is None
+    # without the weight-gradient streams a group is launched on the stream its members were produced on: one queue per
+    # stream, no events (the branches of the ModalityDynMM step each run on their own stream)
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, b_param is not None,
+           0 if use_async else st.cuda_stream)
+    ev = None
+    if use_async:
+        ev = torch.cuda.Event()
+        ev.record(st)
     q = _WGRAD_QUEUES.setdefault(key, [])
-    q.append((g, x, gy, w_param, b_param, ev))
+    q.append((g, x, gy, w_param, b_param, ev, st))
     _WGRAD_LAST[key] = _WGRAD_TICK[0]
     if len(q) >= WGRAD_GROUP:
         _flush_wgrad_queue(key)
@@ -168,9 +175,12 @@ def _flush_wgrad_queue(key):
     g = q[0][0]
     n = len(q)
     use_async = ASYNC_WGRAD and PROFILE is None
-    stream = _wgrad_stream() if use_async else torch.cuda.current_stream()
+    stream = _wgrad_stream() if use_async else q[0][6]
     for item in q:
-        stream.wait_event(item[5])
+        if item[5] is not None:
+            stream.wait_event(item[5])
+        elif item[6] != stream:
+            stream.wait_stream(item[6])
     # parameters registered by the backward that triggered this flush belong to ITS streams: set them aside
     held = _PENDING[:]
     del _PENDING[:]
