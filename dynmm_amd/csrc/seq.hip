@@ -87,11 +87,14 @@ __device__ __forceinline__ float ln_group_sum(float v, float (*sh)[kLnTok], int 
     return s;
 }
 
+// `nparts` > 1 / `xbias`: x arrives as partial sums (the hidden-unit split of ffn_kernel) plus a per-channel bias; the sum is
+// formed once, in slab order, written to `xsum` (the backward's `x`) and used from there.
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int B, int D,
-                                                     int T, float eps, const DropSpec spec) {
+                                                     int T, float eps, const DropSpec spec, int nparts, size_t pstride,
+                                                     const float* __restrict__ xbias, float* __restrict__ xsum) {
     __shared__ float sh[kLnGrp][kLnTok];
     const DropState ds(spec);
     const int tl = threadIdx.x & (kLnTok - 1), grp = threadIdx.x / kLnTok;
@@ -99,18 +102,25 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
     const bool ok = tok < B * T;
     const int b = ok ? tok / T : 0, t = ok ? tok - b * T : 0;
     const size_t base = (size_t)b * D * T + t;
+    const float* xs = xsum ? xsum : x;
     float s = 0.f;
     if (ok)
         for (int c = grp; c < D; c += kLnGrp) {
             const size_t i = base + (size_t)c * T;
-            s += x[i] * ds(i) + (res ? res[i] : 0.f);
+            float xv = x[i];
+            if (xsum) {
+                for (int k = 1; k < nparts; ++k) xv += x[(size_t)k * pstride + i];
+                if (xbias) xv += xbias[c];
+                xsum[i] = xv;
+            }
+            s += xv * ds(i) + (res ? res[i] : 0.f);
         }
     const float mu = ln_group_sum(s, sh, tl, grp) / (float)D;
     float v = 0.f;
     if (ok)
         for (int c = grp; c < D; c += kLnGrp) {
             const size_t i = base + (size_t)c * T;
-            const float d = x[i] * ds(i) + (res ? res[i] : 0.f) - mu;
+            const float d = xs[i] * ds(i) + (res ? res[i] : 0.f) - mu;
             v += d * d;
         }
     const float rs = rsqrtf(ln_group_sum(v, sh, tl, grp) / (float)D + eps);
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
     }
     for (int c = grp; c < D; c += kLnGrp) {
         const size_t i = base + (size_t)c * T;
-        const float sv = x[i] * ds(i) + (res ? res[i] : 0.f);
+        const float sv = xs[i] * ds(i) + (res ? res[i] : 0.f);
         y[i] = (sv - mu) * rs * gamma[c] + beta[c];
     }
 }
@@ -475,7 +485,18 @@ extern "C" int dynmm_layernorm_drop_fwd(const float* x, const float* res, const 
     (void)hipGetLastError();
     if (!x || !gamma || !beta || !y || B <= 0 || D <= 0 || T <= 0 || !drop_ok(drop)) return DYNMM_EINVAL;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, x, res, gamma, beta, y, mean, rstd,
-                       B, D, T, eps, drop_spec(drop));
+                       B, D, T, eps, drop_spec(drop), 1, (size_t)0, (const float*)nullptr, (float*)nullptr);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
+}
+
+extern "C" int dynmm_layernorm_parts_fwd(const float* parts, int nparts, const float* xbias, float* xsum, const float* res,
+                                         const float* gamma, const float* beta, float* y, float* mean, float* rstd, int B,
+                                         int D, int T, float eps, const dynmm_dropout* drop, void* stream) {
+    (void)hipGetLastError();
+    if (!parts || nparts <= 0 || !xsum || !gamma || !beta || !y || B <= 0 || D <= 0 || T <= 0 || !drop_ok(drop)) return DYNMM_EINVAL;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, kLnTok)), dim3(256), 0, ST, parts, res, gamma, beta, y, mean, rstd,
+                       B, D, T, eps, drop_spec(drop), nparts, (size_t)B * D * T, xbias, xsum);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

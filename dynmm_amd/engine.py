@@ -22,14 +22,17 @@ from . import lib as L
 class FlatParameters:
     """Re-home the given parameters into one contiguous fp32 buffer (views keep state_dict,
     load_state_dict and autograd working unchanged).  Layout = reverse parameter order, the order in
-    which dp.GradBucketReducer lays out the flat gradient buffer."""
+    which dp.GradBucketReducer lays out the flat gradient buffer.  align > 1 (elements): every parameter starts on a multiple
+    of `align` (zero padding between them; kernels that stage weights with 16-byte loads — csrc/seq_ffn.hip — need align = 4)."""
 
-    def __init__(self, params):
+    def __init__(self, params, align=1):
         self.params = list(params)
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(total, device=dev, dtype=torch.float32)
+        align = max(1, int(align))
+        total = sum(-(-p.numel() // align) * align for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.span = {}                      # id(param) -> (lo, hi) element range in the flat buffers
+        self.pspan = {}                     # the same with hi rounded up to the next parameter's start (what an optimizer walks)
         off = 0
         with torch.no_grad():
             for p in reversed(self.params):
@@ -37,7 +40,8 @@ class FlatParameters:
                 self.flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + n].view_as(p)
                 self.span[id(p)] = (off, off + n)
-                off += n
+                off += -(-n // align) * align
+                self.pspan[id(p)] = (self.span[id(p)][0], off)
 
 
     def refresh(self):
@@ -103,7 +107,7 @@ class _FlatOptimizer:
         ids = self._all if touched is None else [i for i in self._all if i in touched]
         per = {}
         for i in ids:
-            per.setdefault(self.group_of[i], []).append(self.fp.span[i])
+            per.setdefault(self.group_of[i], []).append(self.fp.pspan[i])
         return [(gi, _merge(sp)) for gi, sp in sorted(per.items())]
 
     grad_scale = 1.0           # multiplies every gradient inside the update kernel (data parallel: 1/world of the SUM)

@@ -129,6 +129,11 @@ SIGNATURES = {
     'dynmm_dropout_apply': (c_i, [c_f, c_f, c_sz, _DP, c_f]),
     'dynmm_layernorm_drop_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_i, c_fl, _DP, c_f]),
     'dynmm_layernorm_drop_bwd': (c_i, [c_f] * 10 + [c_i, c_i, c_i, _DP, c_f]),
+    'dynmm_layernorm_parts_fwd': (c_i, [c_f, c_i] + [c_f] * 8 + [c_i, c_i, c_i, c_fl, _DP, c_f]),
+    'dynmm_ffn_supported': (c_i, [c_i] * 4),
+    'dynmm_ffn_nsplit': (c_i, [c_i] * 4),
+    'dynmm_ffn_fwd': (c_i, [c_f] * 6 + [c_i] * 5 + [_DP, c_f]),
+    'dynmm_ffn_bwd_data': (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl, c_f]),
     'dynmm_mha_drop_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, _DP, c_f]),
     'dynmm_mha_drop_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, _DP, c_f]),
     'dynmm_moe_head': (c_i, [c_f, _PP, c_i, c_f, c_fl, c_i, c_fl, c_f, c_f, c_f, _PP, c_f, c_i, c_f]),

@@ -94,6 +94,9 @@ def encoder_layer(h, layer, heads):
     a = S.mha_core(qkv, heads, drop=(p_att, site, 'attn'))
     o = S.linear_bdt(a, sa.out_proj.weight, sa.out_proj.bias)
     h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h, drop=(p1, site + 1, 'dropout1'))
+    if S.ffn_fused_ok(h1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias):
+        # linear1 -> ReLU -> dropout -> linear2 -> dropout2 -> + h1 -> norm2: two launches (csrc/seq_ffn.hip)
+        return S.ffn_block(h1, layer, (pf, site + 2, 'dropout'), (p2, site + 3, 'dropout2'))
     if pf > 0:
         f = S.linear_bdt(h1, layer.linear1.weight, layer.linear1.bias, act='relu')
         f = S.dropout_bdt(f, pf, site + 2, 'dropout')
@@ -271,7 +274,7 @@ class AffectTrainStep:
         from .. import engine
         self.model = model
         params = [p for p in model.parameters() if p.requires_grad]
-        self.flatp = engine.FlatParameters(params)
+        self.flatp = engine.FlatParameters(params, align=4)      # 16-byte aligned weights for the fused feed-forward kernel
         self.flat_g = torch.zeros_like(self.flatp.flat)
         for p in params:
             lo, hi = self.flatp.span[id(p)]

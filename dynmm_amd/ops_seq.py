@@ -6,6 +6,7 @@ added for this path live in csrc/seq.hip.  As everywhere in dynmm_amd there is n
 """
 import ctypes as C
 import itertools
+import os as _os
 
 import torch
 from torch.autograd import Function
@@ -163,6 +164,113 @@ def layernorm_bdt(x, gamma, beta, eps=1e-5, residual=None, drop=None):
     """LayerNorm over D of (dropout(x) + residual), x [B, D, T]; drop = (p, site, name) or None."""
     d = Drop(drop[0], drop[1], drop[2], x.shape, x.device) if drop is not None and drop[0] > 0 else None
     return _LayerNormBDT.apply(x, residual, gamma, beta, eps, d)
+
+
+FFN_FUSED = _os.environ.get('DYNMM_FFN_FUSED', '1') != '0'
+
+
+def ffn_fused_ok(x, w1, b1, w2, b2):
+    """the one-launch feed-forward block (csrc/seq_ffn.hip) serves this layer"""
+    if not (FFN_FUSED and x.dim() == 3 and b1 is not None and b2 is not None):
+        return False
+    B, D, T = x.shape
+    return bool(_lib().dynmm_ffn_supported(B, D, T, w1.shape[0])) and \
+        all(t.data_ptr() % 16 == 0 and t.is_contiguous() for t in (w1, b1, w2))
+
+
+def _wgrad_1x1(x3, gy3, w_param, b_param):
+    """weight (+ bias) gradient of a Linear over the channel axis of x3 [B, Ci, T] given gy3 [B, Co, T]: queued for a grouped
+    launch under the in-place gradient protocol, launched at once otherwise.  Returns (dw, db) for autograd (None = written in
+    place)."""
+    lib = _lib()
+    B, Ci, T = x3.shape
+    Co = gy3.shape[1]
+    g = L.ConvGeom(B, Ci, 1, T, Co, 1, T, 1, 1, 1, 1, 0, 0, Ci)
+    if (ops.DIRECT_GRAD and ops.WGRAD_GROUP > 1 and ops._direct_ok(w_param) and ops._direct_ok(b_param) and
+            bool(lib.dynmm_conv2d_wgrad_groupable(C.byref(g)))):
+        ops._queue_wgrad(g, x3, gy3, w_param, b_param)
+        return None, None
+    dw, dw_ret = _grad_dst(w_param)
+    db, db_ret = _grad_dst(b_param)
+    nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
+    ws = torch.empty(max(nbytes // 4, 1), device=x3.device, dtype=torch.float32)
+    L.check(lib.dynmm_conv2d_wgrad(_p(x3), None, _p(gy3), _p(dw), _p(db), _p(ws), nbytes, C.byref(g), _stream()), 'conv2d_wgrad')
+    _grads_enqueued()
+    return dw_ret, db_ret
+
+
+class _FFNBlock(Function):
+    """LayerNorm(h + dropout2(linear2(dropout(relu(linear1(h)))))): the second half of a post-norm encoder layer.  Forward =
+    ffn_kernel + ln_fwd_kernel; backward = LayerNorm backward, ffn_kernel<BWD>, two (queued) weight-gradient problems and one
+    ordered sum of the residual branch's gradient with the partial sums of the feed-forward branch's."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2, gamma, beta, eps, drop_f, drop2):
+        lib = _lib()
+        h = _chk(h, 'x')
+        B, D, T = h.shape
+        F = w1.shape[0]
+        ns = lib.dynmm_ffn_nsplit(B, D, T, F)
+        hidden = torch.empty((B, F, T), device=h.device, dtype=torch.float32)
+        parts = torch.empty((ns, B, D, T), device=h.device, dtype=torch.float32)
+        L.check(lib.dynmm_ffn_fwd(_p(h), _p(w1), _p(b1), _p(w2), _p(hidden), _p(parts), B, D, T, F, ns, _drop_arg(drop_f),
+                                  _stream()), 'ffn_fwd')
+        y, xsum = torch.empty_like(h), torch.empty_like(h)
+        mean = torch.empty(B * T, device=h.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        L.check(lib.dynmm_layernorm_parts_fwd(_p(parts), ns, _p(b2), _p(xsum), _p(h), _p(gamma), _p(beta), _p(y), _p(mean),
+                                              _p(rstd), B, D, T, float(eps), _drop_arg(drop2), _stream()), 'layernorm_parts_fwd')
+        ctx.drop_f, ctx.drop2, ctx.ns = drop_f, drop2, ns
+        ctx.save_for_backward(h, hidden, xsum, mean, rstd, w1, w2, gamma)
+        ctx.params = (w1, b1, w2, b2, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        h, hidden, xsum, mean, rstd, w1, w2, gamma = ctx.saved_tensors
+        pw1, pb1, pw2, pb2, pgamma, pbeta = ctx.params
+        g = _chk(g, 'grad')
+        B, D, T = h.shape
+        F, ns = w1.shape[0], ctx.ns
+        st = _stream()
+        need_w = ctx.needs_input_grad[1]
+        dropping2 = ctx.drop2 is not None and ctx.drop2.p > 0
+        # slab ns = the residual branch's gradient, slabs 0 .. ns-1 = the feed-forward branch's partial sums
+        slabs = torch.empty((ns + 1, B, D, T), device=h.device, dtype=torch.float32)
+        dres = slabs[ns]
+        dout = torch.empty_like(h) if dropping2 else dres
+        dg = dg_ret = db = db_ret = None
+        if ctx.needs_input_grad[5]:
+            dg, dg_ret = _grad_dst(pgamma)
+            db, db_ret = _grad_dst(pbeta)
+        L.check(lib.dynmm_layernorm_drop_bwd(_p(g), _p(xsum), _p(h), _p(gamma), _p(mean), _p(rstd),
+                                             _p(dout) if dropping2 else None, _p(dres), _p(dg), _p(db), B, D, T,
+                                             _drop_arg(ctx.drop2), st), 'layernorm_bwd')
+        _grads_enqueued()
+        dhid = torch.empty_like(hidden)
+        pf = ctx.drop_f.p if ctx.drop_f is not None else 0.0
+        L.check(lib.dynmm_ffn_bwd_data(_p(dout), _p(hidden), _p(w1), _p(w2), _p(dhid), _p(slabs), B, D, T, F, ns, float(pf), st),
+                'ffn_bwd_data')
+        dw1 = db1 = dw2 = db2 = None
+        if need_w:
+            dw2, db2 = _wgrad_1x1(hidden, dout, pw2, pb2)
+            dw1, db1 = _wgrad_1x1(h, dhid, pw1, pb1)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(h)
+            L.check(lib.dynmm_reduce_slabs(_p(slabs), _p(dh), h.numel(), ns + 1, st), 'reduce_slabs')
+        return dh, dw1, db1, dw2, db2, dg_ret, db_ret, None, None, None
+
+
+def ffn_block(h, layer, drop_f, drop2):
+    """norm2(h + dropout2(linear2(dropout(relu(linear1(h)))))) of an nn.TransformerEncoderLayer; drop_* = (p, site, name)."""
+    B, D, T = h.shape
+    F = layer.linear1.weight.shape[0]
+    df = Drop(drop_f[0], drop_f[1], drop_f[2], (B, F, T), h.device) if drop_f[0] > 0 else None
+    d2 = Drop(drop2[0], drop2[1], drop2[2], h.shape, h.device) if drop2[0] > 0 else None
+    return _FFNBlock.apply(h, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                           layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, df, d2)
 
 
 class _MHACore(Function):

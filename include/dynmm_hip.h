@@ -466,6 +466,27 @@ int dynmm_layernorm_drop_fwd(const float* x, const float* res, const float* gamm
 int dynmm_layernorm_drop_bwd(const float* g, const float* x, const float* res, const float* gamma, const float* mean,
                              const float* rstd, float* dx, float* dres, float* dgamma, float* dbeta, int B, int D, int T,
                              const dynmm_dropout* drop, void* stream);
+/* The same forward for an x that arrives as `nparts` partial sums ([nparts][B, D, T], added in slab order) plus an optional
+ * per-channel bias `xbias` — what dynmm_ffn_fwd leaves behind; `xsum` [B, D, T] receives the assembled x (the `x` of
+ * dynmm_layernorm_drop_bwd). */
+int dynmm_layernorm_parts_fwd(const float* parts, int nparts, const float* xbias, float* xsum, const float* res,
+                              const float* gamma, const float* beta, float* y, float* mean, float* rstd, int B, int D, int T,
+                              float eps, const dynmm_dropout* drop, void* stream);
+/* ---- the feed-forward block of nn.TransformerEncoderLayer (torch/nn/modules/transformer.py `_ff_block`:
+ * linear2(dropout(relu(linear1(x)))), the experts of ModalityDynMM/affect/affect_dyn.py:107-175) on [B, D, T], one launch ----
+ * supported: D <= 128, F % 32 == 0, 16-byte aligned weights.  nsplit = dynmm_ffn_nsplit(...) ways of splitting the
+ * hidden units over workgroups (a divisor of F / 32).
+ * fwd: hidden [B, F, T] = dropout(relu(w1 x + b1)) (kept for the backward), out_parts [nsplit][B, D, T] = partial sums of
+ *      w2 . hidden WITHOUT b2 (dynmm_layernorm_parts_fwd adds them and b2).  drop: indices over hidden's layout; with the
+ *      generator one Philox call serves eight hidden units of a token (16 bits each: P(keep) = 1 - round(65536 p) / 65536).
+ * bwd_data: dhidden = (w2^T dout) * (hidden > 0) / (1 - p), dx_parts [nsplit][B, D, T] = partial sums of w1^T dhidden.  The
+ *      weight / bias gradients are 1x1-convolution weight gradients of (hidden, dout) and (x, dhidden): dynmm_conv2d_wgrad. */
+int dynmm_ffn_supported(int B, int D, int T, int F);
+int dynmm_ffn_nsplit(int B, int D, int T, int F);
+int dynmm_ffn_fwd(const float* x, const float* w1, const float* b1, const float* w2, float* hidden, float* out_parts, int B,
+                  int D, int T, int F, int nsplit, const dynmm_dropout* drop, void* stream);
+int dynmm_ffn_bwd_data(const float* dout, const float* hidden, const float* w1, const float* w2, float* dhidden,
+                       float* dx_parts, int B, int D, int T, int F, int nsplit, float p, void* stream);
 /* attention with dropout on the probabilities (indices over probs' [B*heads, T, T] layout); probs holds the
  * probabilities BEFORE dropout, which is what the backward needs together with the regenerated keep flags. */
 int dynmm_mha_drop_fwd(const float* qkv, float* out, float* probs, int B, int D, int T, int heads,

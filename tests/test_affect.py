@@ -193,6 +193,95 @@ def test_dropout_generator_statistics_and_replay():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,D,T,F,heads,p', [(6, 120, 50, 2048, 5, 0.1), (3, 60, 50, 2048, 5, 0.1), (5, 120, 50, 2048, 5, 0.0),
+                                              (2, 20, 7, 64, 5, 0.2), (3, 124, 11, 96, 4, 0.1), (9, 10, 50, 2048, 5, 0.1), (4, 35, 13, 64, 5, 0.1), (70, 120, 50, 256, 5, 0.1)])
+def test_fused_feed_forward_block_equals_the_layer_by_layer_path(B, D, T, F, heads, p):
+    """csrc/seq_ffn.hip (linear1 -> ReLU -> dropout -> linear2 in one launch, hidden-unit split summed inside norm2; backward:
+    one launch for both data gradients) against the same encoder layer run as separate linear / dropout / LayerNorm launches,
+    with the same injected keep flags: output, input gradient, every parameter gradient — under plain autograd and under the
+    in-place gradient protocol of the training step (queued weight gradients)."""
+    from dynmm_amd import engine, ops, ops_seq as S
+    from dynmm_amd.nn import affect as A
+    torch.manual_seed(B * 1000 + D)
+    layer = torch.nn.TransformerEncoderLayer(d_model=D, nhead=heads, dim_feedforward=F, dropout=p).cuda().train()
+    h0 = torch.randn(B, D, T, device='cuda')
+    gy = torch.randn(B, D, T, device='cuda')
+    assert S.ffn_fused_ok(h0, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias)
+
+    def run(fused, direct):
+        S.FFN_FUSED = fused
+        S.MASKS = _Masks(p, 5, 'cuda') if p > 0 else None
+        layer._dynmm_sites = None
+        for q in layer.parameters():
+            q.grad = torch.zeros_like(q) if direct else None
+        h = h0.clone().requires_grad_(True)
+        try:
+            if direct:
+                with engine.direct_gradients(False):
+                    ops.touched_reset()
+                    y = A.encoder_layer(h, layer, heads)
+                    y.backward(gy)
+                    ops.flush_wgrad_groups()
+            else:
+                y = A.encoder_layer(h, layer, heads)
+                y.backward(gy)
+            torch.cuda.synchronize()
+        finally:
+            S.FFN_FUSED, S.MASKS = True, None
+        return y.detach(), h.grad, {n: q.grad.clone() for n, q in layer.named_parameters()}
+
+    y0, dh0, g0 = run(False, False)
+    for direct in (False, True):
+        y1, dh1, g1 = run(True, direct)
+        assert _rel(y1, y0) < 2e-5 and _rel(dh1, dh0) < 1e-4, (direct, _rel(y1, y0), _rel(dh1, dh0))
+        for n in g0:
+            assert _rel(g1[n], g0[n]) < 2e-4, (direct, n, _rel(g1[n], g0[n]))
+
+
+@pytest.mark.gpu
+def test_fused_feed_forward_dropout_generator():
+    """The Philox path of the fused block (one call per four hidden units): with W1 = 0, b1 = 1 the stored hidden activation
+    IS the keep pattern.  Keep rate, values in {0, 1/(1-p)}, new decisions per step, the same decisions for the same
+    (seed, site, step), no repetition along any axis, and a backward that masks exactly the dropped units."""
+    from dynmm_amd import ops, ops_seq as S
+    ops.manual_seed(99)
+    B, D, T, F, p = 8, 120, 50, 2048, 0.1
+    layer = torch.nn.TransformerEncoderLayer(d_model=D, nhead=5, dim_feedforward=F, dropout=p).cuda().train()
+    with torch.no_grad():
+        layer.linear1.weight.zero_()
+        layer.linear1.bias.fill_(1.0)
+    h = torch.randn(B, D, T, device='cuda')
+    lib = S._lib()
+    ns = lib.dynmm_ffn_nsplit(B, D, T, F)
+
+    def hidden(site):
+        hid = torch.empty(B, F, T, device='cuda')
+        parts = torch.empty(ns, B, D, T, device='cuda')
+        d = S.Drop(p, site, 'dropout', (B, F, T), h.device)
+        S.L.check(lib.dynmm_ffn_fwd(h.data_ptr(), layer.linear1.weight.data_ptr(), layer.linear1.bias.data_ptr(),
+                                    layer.linear2.weight.data_ptr(), hid.data_ptr(), parts.data_ptr(), B, D, T, F, ns,
+                                    S._drop_arg(d), torch.cuda.current_stream().cuda_stream), 'ffn_fwd')
+        torch.cuda.synchronize()
+        ref = torch.einsum('df,bft->bdt', layer.linear2.weight.detach().double(), hid.double())
+        assert _rel(parts.double().sum(0), ref) < 1e-5
+        return hid
+    k0 = hidden(3)
+    vals = torch.unique(k0)
+    assert vals.numel() == 2 and vals[0].item() == 0 and abs(vals[1].item() - 1 / (1 - p)) < 1e-6
+    keep = k0 > 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.002                    # 819 200 draws: sigma = 0.0003
+    assert torch.equal(hidden(3) > 0, keep)
+    assert 0.7 < ((hidden(4) > 0) == keep).float().mean().item() < 0.9          # independent sites agree on 0.82
+    S.advance_dropout_step(h.device)
+    assert 0.7 < ((hidden(3) > 0) == keep).float().mean().item() < 0.9
+    for dims in ((0, 1), (0, 2), (1, 2)):
+        assert keep.float().mean(dims).std().item() > 0
+    # the four units of a Philox call are independent of each other
+    q = keep.view(B, F // 4, 4, T).float()
+    assert abs((q[:, :, 0] * q[:, :, 1]).mean().item() - (1 - p) ** 2) < 0.003
+
+
+@pytest.mark.gpu
 def test_dynmm_affect_training_mode_matches_oracle_with_injected_dropout():
     """DynMMNetV2 in training mode (p = 0.1 at 4 sites x 5 layers x 5 transformers = 100 dropout sites), keep flags injected on
     both sides: forward, objective and every gradient."""
