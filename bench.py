@@ -340,6 +340,15 @@ def kernel_timing(step_fn, model):
     return agg
 
 
+def executed_fraction(name):
+    """matrix-core FLOP executed per algorithmic (direct-convolution) FLOP of a launch"""
+    if 'wino43' in name:
+        return 0.5
+    if 'wino' in name or (name.startswith('conv_wgrad_v6') and os.environ.get('DYNMM_WGRAD_WINO', '1') != '0'):
+        return 2.0 / 3.0
+    return 1.0
+
+
 def roofline_of(agg):
     if not agg:
         return None
@@ -368,12 +377,14 @@ def roofline_of(agg):
             'kernel': name, 'launches_per_step': launches,
             'avg_launch_us': round(1000.0 * ms / launches, 2),
             'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
-            'executed_gflop_per_launch': round(flops / launches / 1e9 * (2.0 / 3.0 if 'wino' in name else 1.0), 3),
+            'executed_gflop_per_launch': round(flops / launches / 1e9 * executed_fraction(name), 3),
+            'executed_frac': round(achieved * executed_fraction(name) / FP32_MFMA_PEAK_TFLOPS, 4),
             'algorithmic_bytes_per_launch': round(abytes / launches),
-            'note': ('achieved = ALGORITHMIC (direct-convolution) FLOP / time.  conv_wino_* and the three-tap weight gradients '
-                     '(conv_wgrad_v6<..,1x3> in the Winograd form, conv_wgrad_v6<..,3x1> = conv_wgrad_wino_vt) execute 2/3 of '
-                     'their algorithmic FLOP on the matrix cores (1-D Winograd F(2,3), fp32): their figures can exceed what a '
-                     'direct kernel could reach'),
+            'note': ('achieved / frac = ALGORITHMIC (direct-convolution) FLOP / time.  conv_wino_* and the three-tap weight '
+                     'gradients (conv_wgrad_v6<..,1x3> in the Winograd form, conv_wgrad_v6<..,3x1> = conv_wgrad_wino_vt) execute '
+                     '2/3 of their algorithmic FLOP on the matrix cores (1-D Winograd F(2,3), fp32), conv_wino43_* 1/2 (F(4,3)): '
+                     'their algorithmic figures can exceed what a direct kernel could reach; executed_frac = the share of the '
+                     'fp32 MFMA peak the launch actually keeps busy'),
             'all_igemm_kernels': {k: {'launches': v[0], 'ms': round(v[1], 3),
                                       'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                                   for k, v in sorted(agg.items())}}
@@ -689,25 +700,22 @@ def main():
                            'taken subset, straight-through gate gradient from the taken stages only) — DESIGN.md')
         res['unit'] = 'images/s'
         extra['train_hard'] = res
-        # opt-in: the training FORWARD on the Winograd kernels too (DYNMM_WINO=all).  Not the default: a forward with a different
-        # rounding flips ReLU decisions at rounding-level pre-activations, and the block-level gradient tests are held to
-        # bars a single flip can exceed; the headline keeps the direct forward.
+        # A/B: the same step with the training FORWARD on the direct operand-ring kernels (DYNMM_WINO=dgrad, the default until the
+        # end of round 4); the headline runs it in the Winograd form like the input and weight gradients.
         try:
             saved_w = ops.WINO
-            ops.WINO = 'all'
+            ops.WINO = 'dgrad'
             st3, ts3, m3 = train_workload(sub_soft(args), device, rank, 1, False, args.branches, False)
-            for _ in range(2):
-                st3()
-            k3 = max(5, args.steps // 2)
-            el = timed(st3, k3, 2, 1, device)
-            extra['train_winograd_forward'] = {
+            k3 = max(10, args.steps // 2)
+            el = timed(st3, k3, 5, 1, device)
+            extra['train_direct_forward'] = {
                 'value': round(args.batch * k3 / el, 2), 'unit': 'images/s', 'ms_per_step': round(1000 * el / k3, 3),
-                'workload': 'configs[2] with DYNMM_WINO=all: forward, input and weight gradients of the three-tap convolutions '
-                            'all in the Winograd form (fp32); labelled extra, NOT the headline'}
+                'workload': 'configs[2] with DYNMM_WINO=dgrad: training forward of the three-tap convolutions on the direct '
+                            'operand-ring kernels (input / weight gradients unchanged); labelled extra, NOT the headline'}
             del st3, ts3, m3
             torch.cuda.empty_cache()
         except Exception as e:
-            extra['train_winograd_forward'] = {'error': f'{type(e).__name__}: {e}'}
+            extra['train_direct_forward'] = {'error': f'{type(e).__name__}: {e}'}
         finally:
             ops.WINO = saved_w
         try:

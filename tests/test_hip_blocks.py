@@ -1,6 +1,8 @@
 """GPU: block-level parity (forward, input gradient and every parameter gradient) of the HIP
 modules against the oracle's functional restatement, at the shapes where the blocks run in the
 96x128 / 480x640 models."""
+import contextlib
+
 import pytest
 import torch
 
@@ -36,22 +38,71 @@ def rnd(*shape, seed=0):
     return torch.randn(*shape, generator=g)
 
 
+@contextlib.contextmanager
+def hip_relu_decisions(trace, tau=1e-5):
+    """Run the oracle with the ReLU decisions the HIP pass took — but only where the oracle's own pre-activation lies within
+    `tau` (relative to the tensor's maximum) of zero.  There two correct fp32 evaluations of the same sums decide differently
+    (scratch/r4/flip_probe.py: over 12 seeds of the decoder module the direct kernels differ from the fp64 decision in 6, the
+    Winograd kernels in 5, and ONE such flip moves a BatchNorm parameter gradient of these small maps by 5e-3 ... 1.2e-1), and a
+    gradient is only comparable at equal decisions.  Everywhere else the HIP decision must EQUAL the oracle's
+    (`outside_band` is asserted to be 0 by the caller: a wrong mask, tap or residual shows up there), and every traced decision
+    must be consumed (the k-th ReLU of a shape on one side is the k-th of that shape on the other)."""
+    queues = {}
+    for y in trace:
+        queues.setdefault(tuple(y.shape), []).append((y > 0).cpu())
+    census = {'sites': 0, 'imposed': 0, 'outside_band': 0, 'queues': queues}
+    orig = O.F.relu
+
+    def relu(v, inplace=False):
+        q = queues.get(tuple(v.shape))
+        if not q:
+            return orig(v)
+        hip = q.pop(0)
+        vd = v.detach()
+        own = vd > 0
+        band = vd.abs() <= tau * vd.abs().max()
+        dis = own != hip
+        census['sites'] += 1
+        census['imposed'] += int((dis & band).sum())
+        census['outside_band'] += int((dis & ~band).sum())
+        return v * torch.where(band, hip, own).to(v.dtype)
+    O.F.relu = relu
+    try:
+        yield census
+    finally:
+        O.F.relu = orig
+
+
 def run_pair(module, ref_fn, inputs, training=True, prefix='m'):
-    """module: HIP nn.Module (CPU-constructed); ref_fn(sd, *inputs, training) -> tensor or tuple."""
+    """module: HIP nn.Module (CPU-constructed); ref_fn(sd, *inputs, training) -> tensor or tuple.  The oracle runs in fp64
+    (the truth both fp32 implementations approximate) with the HIP pass's ReLU decisions at its near-ties."""
+    from dynmm_amd import ops
     synth.fill_state_dict(module.state_dict(), seed=3)
-    sd = {f'{prefix}.{k}': v.detach().clone() for k, v in module.state_dict().items()}
+    sd = {f'{prefix}.{k}': (v.detach().clone().double() if v.dtype.is_floating_point else v.detach().clone())
+          for k, v in module.state_dict().items()}
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
-    xs_ref = [x.clone().requires_grad_(True) for x in inputs]
-    out_ref = ref_fn(sd, *xs_ref, training)
-    outs_ref = [o for o in (out_ref if isinstance(out_ref, tuple) else (out_ref,)) if o is not None]
-    gs = [rnd(*o.shape, seed=11 + i) for i, o in enumerate(outs_ref)]
-    torch.autograd.backward(outs_ref, gs)
 
     module = module.cuda().train(training)
     xs = [x.clone().cuda().requires_grad_(True) for x in inputs]
-    out = module(*xs)
+    ops.ACT_TRACE = []
+    try:
+        out = module(*xs)
+    finally:
+        trace, ops.ACT_TRACE = ops.ACT_TRACE, None
     outs = [o for o in (out if isinstance(out, tuple) else (out,)) if o is not None]
+
+    xs_ref = [x.clone().double().requires_grad_(True) for x in inputs]
+    with hip_relu_decisions(trace) as census:
+        out_ref = ref_fn(sd, *xs_ref, training)
+    outs_ref = [o for o in (out_ref if isinstance(out_ref, tuple) else (out_ref,)) if o is not None]
+    assert census['outside_band'] == 0, f'{census["outside_band"]} ReLU decisions differ from the fp64 oracle away from zero'
+    assert not any(census['queues'].values()), 'traced HIP ReLU outputs the oracle never matched'
+    gs = [rnd(*o.shape, seed=11 + i) for i, o in enumerate(outs_ref)]
+    torch.autograd.backward(outs_ref, [g.double() for g in gs])
     torch.autograd.backward(outs, [g.cuda() for g in gs])
+    if census['imposed']:
+        print(f'[ties] {census["imposed"]} ReLU decisions of {census["sites"]} traced activations taken from the HIP pass '
+              '(oracle pre-activation within 1e-5 of zero)')
     report = []
     for i, (a, b) in enumerate(zip(outs, outs_ref)):
         report.append((rel(a, b), f'out{i}', TOL))
@@ -101,11 +152,22 @@ def test_strided_block_with_downsample(blk):
     run_pair(m, lambda sd, x, tr: fn(sd, 'm', x, tr, 2), [rnd(2, 64, 24, 32)])
 
 
-def test_decoder_module():
+@pytest.mark.parametrize('forward', ['all', 'dgrad'])
+@pytest.mark.parametrize('seed', [0, 1, 6, 9])
+def test_decoder_module(seed, forward):
+    """Four input draws x both training-forward kernels (Winograd F(2,3) = the default, direct operand-ring).  Against the
+    fp64 oracle taken at face value, each of these draws has a ReLU tie that one or both fp32 forwards resolve the other way
+    (scratch/r4/flip_probe.py: seed 0 direct, seed 1 Winograd, seeds 6 and 9 both) and a worst parameter-gradient error of
+    2e-2 ... 1.2e-1; with the HIP decisions imposed at the oracle's near-ties every gradient meets the strict bar."""
+    from dynmm_amd import ops
     from dynmm_amd.nn.decoder import DecoderModule
     m = DecoderModule(128, 128, 3, 40)
-    run_pair(m, lambda sd, x, skip, tr: O.decoder_module(sd, 'm', x, skip, tr, 3),
-             [rnd(3, 128, 12, 16), rnd(3, 128, 24, 32, seed=5)])
+    saved, ops.WINO = ops.WINO, forward
+    try:
+        run_pair(m, lambda sd, x, skip, tr: O.decoder_module(sd, 'm', x, skip, tr, 3),
+                 [rnd(3, 128, 12, 16, seed=seed), rnd(3, 128, 24, 32, seed=5 + seed)])
+    finally:
+        ops.WINO = saved
 
 
 def test_pyramid_pooling():
