@@ -342,6 +342,8 @@ def kernel_timing(step_fn, model):
 
 def executed_fraction(name):
     """matrix-core FLOP executed per algorithmic (direct-convolution) FLOP of a launch"""
+    if 's2' in name:                 # polyphase stride-2 input gradients on the pair kernel: no Winograd arithmetic
+        return 1.0
     if 'wino43' in name:
         return 0.5
     if 'wino' in name or (name.startswith('conv_wgrad_v6') and os.environ.get('DYNMM_WGRAD_WINO', '1') != '0'):
@@ -349,10 +351,27 @@ def executed_fraction(name):
     return 1.0
 
 
+def kernel_instance(name):
+    """The compiled kernel (template instance) a launch label runs on: the Winograd kernels serve every channel count, and the
+    horizontal form the 3x3 filters too, from ONE instance — the unit rocprofv3 reports and the roofline is quoted for."""
+    import re
+    m = re.match(r'conv_wino(43)?_(fwd|dgrad)<co\d+,(\d)x(\d)(s2)?>', name)
+    if not m:
+        return name
+    f43, kind, kh, kw, s2 = m.groups()
+    return f"conv_wino{f43 or ''}_{kind}<{'vertical' if kw == '1' else 'horizontal'}{',s2' if s2 else ''}>"
+
+
 def roofline_of(agg):
     if not agg:
         return None
-    name, (launches, ms, flops, abytes) = max(agg.items(), key=lambda kv: kv[1][1])
+    inst = {}
+    for k, v in agg.items():
+        a = inst.setdefault(kernel_instance(k), [0, 0.0, 0.0, 0.0, []])
+        for i in range(4):
+            a[i] += v[i]
+        a[4].append(k)
+    name, (launches, ms, flops, abytes, members) = max(inst.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12
     # HBM traffic per launch: rocprofv3 PMC record of the SAME step (profiles/pmc_dominant_kernel.json, written by
     # profiles/r03_recipe.sh).  It is a like-for-like figure only if it was taken over the same launch set: same kernel
@@ -374,7 +393,7 @@ def roofline_of(agg):
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
             'traffic_note': TRAFFIC_NOTE if traffic is not None else traffic_why,
-            'kernel': name, 'launches_per_step': launches,
+            'kernel': name, 'launch_labels': sorted(members), 'launches_per_step': launches,
             'avg_launch_us': round(1000.0 * ms / launches, 2),
             'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
             'executed_gflop_per_launch': round(flops / launches / 1e9 * executed_fraction(name), 3),
@@ -700,24 +719,6 @@ def main():
                            'taken subset, straight-through gate gradient from the taken stages only) — DESIGN.md')
         res['unit'] = 'images/s'
         extra['train_hard'] = res
-        # A/B: the same step with the training FORWARD on the direct operand-ring kernels (DYNMM_WINO=dgrad, the default until the
-        # end of round 4); the headline runs it in the Winograd form like the input and weight gradients.
-        try:
-            saved_w = ops.WINO
-            ops.WINO = 'dgrad'
-            st3, ts3, m3 = train_workload(sub_soft(args), device, rank, 1, False, args.branches, False)
-            k3 = max(10, args.steps // 2)
-            el = timed(st3, k3, 5, 1, device)
-            extra['train_direct_forward'] = {
-                'value': round(args.batch * k3 / el, 2), 'unit': 'images/s', 'ms_per_step': round(1000 * el / k3, 3),
-                'workload': 'configs[2] with DYNMM_WINO=dgrad: training forward of the three-tap convolutions on the direct '
-                            'operand-ring kernels (input / weight gradients unchanged); labelled extra, NOT the headline'}
-            del st3, ts3, m3
-            torch.cuda.empty_cache()
-        except Exception as e:
-            extra['train_direct_forward'] = {'error': f'{type(e).__name__}: {e}'}
-        finally:
-            ops.WINO = saved_w
         try:
             extra['affect_mosei'] = measure_affect(device, max(10, args.steps))
         except Exception as e:                      # a secondary line must never take the headline line down

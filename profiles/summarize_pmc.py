@@ -52,8 +52,15 @@ def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr, steps_
                 'conv_wgrad_v6<co64,3x1>': ('conv_wgrad_wino_vt_kernel<1>', 2),
                 # Winograd input gradients (conv_wino.hip; 16 B/lane direct-to-LDS streams).  The 1x3 and 3x3 launches share
                 # one template instance: the record averages over both (bench.py withholds `traffic` when the launch counts differ)
-                'conv_wino_dgrad<1x3+3x3>': ('conv_wino_kernel<64, 1, false, true>', 2),
-                'conv_wino_dgrad<3x1>': ('conv_wino_kernel<64, 1, true, true>', 2),
+                # keys = bench.py's kernel_instance(): one compiled instance per tap axis / direction / stride class
+                'conv_wino_fwd<horizontal>': ('conv_wino_kernel<64, 1, false, false, false>', 2),
+                'conv_wino_fwd<vertical>': ('conv_wino_kernel<64, 1, true, false, false>', 2),
+                'conv_wino_dgrad<horizontal>': ('conv_wino_kernel<64, 1, false, true, false>', 2),
+                'conv_wino_dgrad<vertical>': ('conv_wino_kernel<64, 1, true, true, false>', 2),
+                'conv_wino_dgrad<horizontal,s2>': ('conv_wino_kernel<64, 1, false, true, true>', 2),
+                'conv_wino_dgrad<vertical,s2>': ('conv_wino_kernel<64, 1, true, true, true>', 2),
+                'conv_wino43_dgrad<horizontal>': ('conv_wino43_kernel<false>', 2),
+                'conv_wino43_dgrad<vertical>': ('conv_wino43_kernel<true>', 2),
                 # the operand-ring kernels stream 16 B/lane (global_load_lds_dwordx4): the guide's x2 correction applies
                 'conv_igemm_v5_fwd<128x64,kw3>': ('conv_igemm_v5_kernel<128, 64, 64, 32, 3, false', 2),
                 'conv_igemm_v5_fwd<128x64,kw1>': ('conv_igemm_v5_kernel<128, 64, 64, 32, 1, false', 2),
