@@ -46,6 +46,7 @@ struct WinoArgs {
     const float* mask;      // like y or nullptr (input gradient): y = mask > 0 ? y : 0
     float* y;               // [N, Co, H, W]
     int N, Ci, Co, H, W;
+    int CoS;                // row stride of `ut` (Co rounded up to the 64-row tile: the pack writes zero rows)
     int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
     int act;
     int MP;                 // output pairs
@@ -61,9 +62,12 @@ struct WinoArgs {
 // = one dy position, the raw tile holds dy itself (horizontal: [8 ch][pairs + 8], vertical: 2 rows), the filter operand
 // carries (W1, W2, W0, 0), M1 and M2 share an accumulator.  It replaces the round-2 tile kernel's parity-class enumeration
 // (4-byte stores at stride 8, 71 TFLOP/s) with the pair kernel's 8-byte stores and operand ring.
-template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false>
+// TAIL (forward only): Co is not a multiple of the 64-row tile (the 40-class conv_out, model.py:286): the filter operand is packed
+// with zero rows up to the tile, the epilogue skips the channels past Co.
+template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false>
 __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
+    static_assert(!TAIL || (!DGRAD && MCO == 1), "channel tails exist in the forward's small tile only");
     // MCO: 32-channel blocks per wave.  2: a wave owns 64 co x 32 pairs x 4 transforms (128 accumulator registers, two
     // workgroups per CU); 1: 32 co x 32 pairs x 4 (64 registers, three workgroups per CU: smaller tiles for the grids a
     // 8192-accumulator tile quantises badly, and a third neighbour to cover a workgroup's prologue / epilogue)
@@ -144,11 +148,11 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     auto issue = [&]() {
         if (l_t < nst) {
             const int slot = l_t % S;
-            const float* abase = a.ut + ((size_t)(l_r * a.Ci + l_c * BK + 2 * wave) * a.Co + co0) * 4;
+            const float* abase = a.ut + ((size_t)(l_r * a.Ci + l_c * BK + 2 * wave) * a.CoS + co0) * 4;
             const unsigned adst = lds_a + (unsigned)((slot * A_STAGE + 2 * wave * TCO * 4) * 4);
 #pragma unroll
             for (int i = 0; i < NIA; ++i)
-                dma16(abase + ((size_t)(i / IPR) * a.Co + 64 * (i % IPR)) * 4, a_voff, adst + (unsigned)i * 1024u);
+                dma16(abase + ((size_t)(i / IPR) * a.CoS + 64 * (i % IPR)) * 4, a_voff, adst + (unsigned)i * 1024u);
             const float* bbase = a.x + (size_t)(l_c * BK) * HWin;
             const unsigned bdst = lds_b + (unsigned)((slot * B_STAGE + wave * QPW * 4) * 4);
             const int shift = dh_of(l_r) * a.W * 4;
@@ -352,6 +356,8 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     auto off_of = [&](int b, int e) {            // batch b = 2 * mi + h, element e: channel mi * 32 + (e & 3) + 8 * (2 h + (e >> 2))
         return off_base + (unsigned)((b >> 1) * 32 + (e & 3) + 8 * (2 * (b & 1) + (e >> 2))) * row_bytes;
     };
+    const int co_lim = a.Co - (co0 + wave_co * WCO + 4 * khalf);          // TAIL: channels of this lane below this are real
+    auto live = [&](int b, int e) { return !TAIL || (b >> 1) * 32 + (e & 3) + 8 * (2 * (b & 1) + (e >> 2)) < co_lim; };
     float k0[2][8], k1[2][8], r0[2][8], r1[2][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {                 // (launches without epilogue operands never load: neutral values)
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             const unsigned off = off_of(b, e);
             r0[set][e] = r1[set][e] = 0.f;
             k0[set][e] = k1[set][e] = 1.f;
-            if (!pvalid) continue;
+            if (!pvalid || !live(b, e)) continue;
             if constexpr (VERT) {
                 if (has_mask) {
                     k0[set][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off);
@@ -391,7 +397,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     if (has_mask || has_res) load_batch(0, 0);
     __syncthreads();                               // every wave is done with the rings: As is reused below
     float* const sh_lds = As;
-    for (int i = t; i < TCO; i += 256) sh_lds[i] = a.shift ? a.shift[co0 + i] : 0.f;
+    for (int i = t; i < TCO; i += 256) sh_lds[i] = (a.shift && (!TAIL || co0 + i < a.Co)) ? a.shift[co0 + i] : 0.f;
     __syncthreads();
     if (!pvalid) return;
 #pragma unroll
@@ -430,6 +436,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned off = off_of(b, e);
+            if (!live(b, e)) continue;
             if constexpr (VERT) {
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off) = v0[e];
                 if (y1_ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + second) = v1[e];
@@ -448,13 +455,17 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict_
                                                         const float* __restrict__ scale, int Co, int Ci, int KH, int KW,
                                                         int dgrad) {
     const int KR = (KH == 3 && KW == 3) ? 3 : 1;
-    const int K = dgrad ? Co : Ci, Cc = dgrad ? Ci : Co;
+    const int K = dgrad ? Co : Ci, Cr = dgrad ? Ci : Co, Cc = (Cr + 63) & ~63;      // rows padded to the 64-row tile (zeros)
     const size_t total = (size_t)KR * K * Cc;
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= total) return;
     const int c = (int)(o % Cc);
     const int k = (int)((o / Cc) % K);
     const int r = (int)(o / ((size_t)Cc * K));
+    if (c >= Cr) {
+        ut[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int co = dgrad ? k : c, ci = dgrad ? c : k;
     const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
     float g0 = g[0], g1 = g[1], g2 = g[2];
@@ -488,13 +499,17 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
     const WinoPackDesc d = desc[lo];
     const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff, dgrad = (d.kk >> 16) & 3;
     const int KR = (KH == 3 && KW == 3) ? 3 : 1;
-    const int K = dgrad ? d.Co : d.Ci, Cc = dgrad ? d.Ci : d.Co;
+    const int K = dgrad ? d.Co : d.Ci, Cr = dgrad ? d.Ci : d.Co, Cc = (Cr + 63) & ~63;
     const size_t total = (size_t)KR * K * Cc;
     const size_t o = (size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
     if (o >= total) return;
     const int c = (int)(o % Cc);
     const int k = (int)((o / Cc) % K);
     const int r = (int)(o / ((size_t)Cc * K));
+    if (c >= Cr) {
+        reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int co = dgrad ? k : c, ci = dgrad ? c : k;
     const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
     float g0 = g[0], g1 = g[1], g2 = g[2];
@@ -507,7 +522,8 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
 }
 
 // rows = output channels of the GEMM (a multiple of the 64-row tile), red = its reduction channels (8 per stage, >= 3 stages):
-// forward (Co, Ci), input gradient (Ci, Co) — e.g. the input gradient of the 40-class conv_out (model.py:295-308) qualifies
+// forward (Co, Ci), input gradient (Ci, Co) — e.g. the input gradient of the 40-class conv_out (model.py:295-308) qualifies; the
+// FORWARD also takes row counts that are not multiples of the tile (>= 24, % 8 == 0: conv_out's 40 — TAIL instantiations)
 static bool wino_geom_ok(const dynmm_conv_geom* g, bool dgrad) {
     if (!g || g->c_split != g->Ci) return false;
     if (g->SH != 1 || g->SW != 1) return false;
@@ -516,7 +532,7 @@ static bool wino_geom_ok(const dynmm_conv_geom* g, bool dgrad) {
     if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
     if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
     const int rows = dgrad ? g->Ci : g->Co, red = dgrad ? g->Co : g->Ci;
-    if (rows % 64 != 0 || red % 8 != 0 || red < 24) return false;
+    if ((dgrad ? rows % 64 != 0 : (rows % 8 != 0 || rows < 24)) || red % 8 != 0 || red < 24) return false;
     if ((long long)g->N * g->H * g->W < 256) return false;
     if ((double)g->N * (g->Ci > g->Co ? g->Ci : g->Co) * g->H * g->W >= 1073741824.0) return false;   // 32-bit byte offsets
     return true;
@@ -566,12 +582,19 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool 
     // equal on the 3x3 convolutions; input-gradient kernel time per step 16.2 -> 14.0 ms.
     static const int tile_env = env_int_wino("DYNMM_WINO_TILE", 0);
     const int big_tco = (a.Co % 128 == 0) ? 128 : 64;
-    const bool small = tile_env != 1;
+    const bool tail = a.Co % 64 != 0;
+    const bool small = tile_env != 1 || tail;
     const int tco = small ? 64 : big_tco;
     const int tp = small ? 64 : (tco == 128 ? 64 : 128);
-    a.n_co_tiles = a.Co / tco;
+    a.n_co_tiles = ceil_div(a.Co, tco);
     a.n_p_tiles = ceil_div(a.MP, tp);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
+    if (tail) {
+        if (vert) hipLaunchKernelGGL((conv_wino_kernel<64, 1, true, false, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, false, false, true>), grid, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
 #define DYNMM_WINO_GO(TCO, MCO)                                                                                        \
     do {                                                                                                               \
         if (vert) {                                                                                                    \
@@ -601,7 +624,9 @@ extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) 
 
 extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
     if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
-    return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * Co * Ci * 4;
+    // either operand: [KR][K][rows rounded up to 64][4]
+    const size_t fwd = (size_t)Ci * ((Co + 63) & ~63), dg = (size_t)Co * ((Ci + 63) & ~63);
+    return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * (fwd > dg ? fwd : dg) * 4;
 }
 
 extern "C" int dynmm_wino_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int KH, int KW, int dgrad,
@@ -644,6 +669,7 @@ extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const floa
     WinoArgs a{};
     a.x = x; a.ut = ut; a.shift = bias; a.residual = residual; a.mask = nullptr; a.y = y;
     a.N = g->N; a.Ci = g->Ci; a.Co = g->Co; a.H = g->H; a.W = g->W;
+    a.CoS = (g->Co + 63) & ~63;
     a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = act;
     return launch_wino(a, g->KW == 1, false, (hipStream_t)stream);
@@ -661,6 +687,7 @@ extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const f
     WinoArgs a{};
     a.x = dy; a.ut = ut; a.shift = nullptr; a.residual = accum; a.mask = mask; a.y = dx;
     a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;         // the roles of the channel counts swap
+    a.CoS = (a.Co + 63) & ~63;
     a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = DYNMM_ACT_NONE;
     a.Hin = g->Ho; a.Win = g->Wo;                                             // (stride 2: dy is half as high / wide as dx)
