@@ -47,7 +47,7 @@ def _chk(t, name='tensor'):
 #   'all'   (default) forward — training and inference — and input gradients.  The training forward in this form is closer to
 #           the fp64 result than the direct kernels on every shape tried (1.0e-6 vs 1.35e-6 on the decoder module's outputs)
 #           and takes ReLU decisions at rounding-level pre-activations differently from them about as often as either differs
-#           from fp64 (scratch/r4/flip_probe.py: 12 draws, direct 6 flips, Winograd 5); step 71.8 -> 67.9 ms;
+#           from fp64 (tests/flip_probe.py: 12 draws, direct 6 flips, Winograd 5); step 71.8 -> 67.9 ms;
 #   'dgrad' the input gradients only (the training forward on the direct operand-ring kernels: the round's earlier default);
 #   'fwd'   forward only;   '0' off (operand-ring kernels everywhere).
 WINO = _os.environ.get('DYNMM_WINO', 'all')

@@ -1,10 +1,10 @@
 """Is the decoder-module failure of the Winograd training forward a ReLU tie?  Run the module twice (direct / Winograd forward),
-hook every submodule output, and list where (out > 0) differs and how large the values are there."""
+hook every submodule output, and list where (out > 0) differs and how large the values are there; both against the fp64
+oracle.  A diagnostic, not a test (pytest does not collect it): python tests/flip_probe.py [draws]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from dynmm_amd import ops, synth  # noqa: E402
 from dynmm_amd.nn.decoder import DecoderModule  # noqa: E402

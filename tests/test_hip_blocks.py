@@ -42,7 +42,7 @@ def rnd(*shape, seed=0):
 def hip_relu_decisions(trace, tau=1e-5):
     """Run the oracle with the ReLU decisions the HIP pass took — but only where the oracle's own pre-activation lies within
     `tau` (relative to the tensor's maximum) of zero.  There two correct fp32 evaluations of the same sums decide differently
-    (scratch/r4/flip_probe.py: over 12 seeds of the decoder module the direct kernels differ from the fp64 decision in 6, the
+    (tests/flip_probe.py: over 12 seeds of the decoder module the direct kernels differ from the fp64 decision in 6, the
     Winograd kernels in 5, and ONE such flip moves a BatchNorm parameter gradient of these small maps by 5e-3 ... 1.2e-1), and a
     gradient is only comparable at equal decisions.  Everywhere else the HIP decision must EQUAL the oracle's
     (`outside_band` is asserted to be 0 by the caller: a wrong mask, tap or residual shows up there), and every traced decision
@@ -157,7 +157,7 @@ def test_strided_block_with_downsample(blk):
 def test_decoder_module(seed, forward):
     """Four input draws x both training-forward kernels (Winograd F(2,3) = the default, direct operand-ring).  Against the
     fp64 oracle taken at face value, each of these draws has a ReLU tie that one or both fp32 forwards resolve the other way
-    (scratch/r4/flip_probe.py: seed 0 direct, seed 1 Winograd, seeds 6 and 9 both) and a worst parameter-gradient error of
+    (tests/flip_probe.py: seed 0 direct, seed 1 Winograd, seeds 6 and 9 both) and a worst parameter-gradient error of
     2e-2 ... 1.2e-1; with the HIP decisions imposed at the oracle's near-ties every gradient meets the strict bar."""
     from dynmm_amd import ops
     from dynmm_amd.nn.decoder import DecoderModule
