@@ -141,7 +141,7 @@ SIGNATURES = {
     'dynmm_clip_grad_norm': (c_i, [c_f, c_sz, c_fl, c_f, c_f, c_f]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
