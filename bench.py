@@ -78,6 +78,8 @@ def parse():
                     help='skip the single full-batch oracle step (report the small-sample rate)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary lines (configs[1] fwd-only, hard-gate)')
+    ap.add_argument('--affect-only', action='store_true',
+                    help='print the ModalityDynMM (configs[4]) secondary line alone: what the main run starts as a child process')
     return ap.parse_args()
 
 
@@ -567,6 +569,22 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
     return res
 
 
+def measure_affect_isolated(steps):
+    """measure_affect() in a process of its own.  It is the one leg that captures and replays hipGraphs (five branch streams,
+    ~500 nodes); a fault inside the runtime's capture path is not a Python exception, and a secondary line must never take the
+    headline line down with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--affect-only', '--steps', str(int(steps))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return {'error': f'child exited with {r.returncode}: {(r.stderr or r.stdout)[-300:]}'}
+        return json.loads(lines[-1])
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
 def sub_soft(args):
     sub = argparse.Namespace(**vars(args))
     sub.graph = False
@@ -623,6 +641,9 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)           # before the process group: RCCL binds the communicator to the current device
     device = torch.device('cuda', local_rank)
+    if args.affect_only:
+        print(json.dumps(measure_affect(device, max(10, args.steps))))
+        return
     if world > 1:
         # nccl == RCCL on ROCm.  DYNMM_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a
         # single-GPU box (ranks then share device 0).
@@ -719,10 +740,7 @@ def main():
                            'taken subset, straight-through gate gradient from the taken stages only) — DESIGN.md')
         res['unit'] = 'images/s'
         extra['train_hard'] = res
-        try:
-            extra['affect_mosei'] = measure_affect(device, max(10, args.steps))
-        except Exception as e:                      # a secondary line must never take the headline line down
-            extra['affect_mosei'] = {'error': f'{type(e).__name__}: {e}'}
+        extra['affect_mosei'] = measure_affect_isolated(max(10, args.steps))
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -450,7 +450,7 @@ class TrainStep:
         if self.prepack is not None and self.prepack.reg and self.prepack.dirty:
             self.prepack._layout()           # the warm-up registered the weights: lay the arena out before capturing
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with ops.capture_scope(), torch.cuda.graph(graph):
             self._body(*static)
             if self.reducer.world == 1:
                 self.opt.step(self._touched, self.last['total'])

@@ -334,8 +334,9 @@ class AffectTrainStep:
                 t.copy_(c)
             if self.prepack.reg and self.prepack.dirty:
                 self.prepack._layout()                       # the warm-up registered the weights: lay the arena out before capturing
+            from .. import ops
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with ops.capture_scope(), torch.cuda.graph(graph):
                 self._body(static_in, static_y)
             entry = (graph, static_in, static_y, self.last)
             self._graphs[key] = entry

@@ -5,6 +5,7 @@ every FLOP and every byte moved on the hot path is done by the kernels in libdyn
 functions require contiguous fp32 tensors on a HIP device and raise otherwise — there is no eager
 fallback.
 """
+import contextlib
 import ctypes as C
 import os as _os
 
@@ -139,6 +140,7 @@ def join_async():
 WGRAD_GROUP = int(_os.environ.get('DYNMM_WGRAD_GROUP', '4'))
 WGRAD_GROUP_AGE = int(_os.environ.get('DYNMM_WGRAD_GROUP_AGE', '4'))
 _WGRAD_QUEUES = {}
+_CAPTURE_EVENTS = []       # events recorded while a stream capture was in progress (kept alive: see _queue_wgrad)
 _WGRAD_TICK = [0]          # conv backward calls seen; a queue that got nothing for WGRAD_GROUP_AGE of them is flushed
 _WGRAD_LAST = {}           # (the backward has left the run of layers with that geometry: do not hold its gradients back)
 
@@ -162,6 +164,11 @@ def _queue_wgrad(g, x, gy, w_param, b_param):
     if use_async:
         ev = torch.cuda.Event()
         ev.record(st)
+        if torch.cuda.is_current_stream_capturing():
+            # an event recorded into a capture must outlive the capture: torch destroys an Event object the moment its last
+            # reference goes (here: when its group is flushed, still inside the capture), and hipStreamEndCapture then
+            # intermittently faults on the freed node (seen as a segfault in capture_end, order- and timing-dependent)
+            _CAPTURE_EVENTS.append(ev)
     q = _WGRAD_QUEUES.setdefault(key, [])
     q.append((g, x, gy, w_param, b_param, ev, st))
     _WGRAD_LAST[key] = _WGRAD_TICK[0]
@@ -263,6 +270,23 @@ def _grads_enqueued(*streams):
     for prm in _PENDING:
         _TOUCHED.add(id(prm))
     _PENDING.clear()
+
+
+@contextlib.contextmanager
+def capture_scope():
+    """Around a stream capture: Python's cyclic collector is switched off.  torch.cuda.graph() collects BEFORE capture_begin, but
+    a generation-0 collection can still start at any allocation inside the captured step, and what it finalises (Event / Stream
+    / CUDAGraph objects of earlier steps, captures and tests) calls into the HIP runtime in the middle of the capture — seen as
+    an intermittent segfault in hipStreamEndCapture whose frequency depended on how much garbage the process had accumulated."""
+    import gc
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 # Tests (tests/test_hip_blocks.py): when ACT_TRACE is a list, every ReLU output of conv2d / batch_norm_act is appended to it in

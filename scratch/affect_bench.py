@@ -8,4 +8,4 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-print(json.dumps(bench.measure_affect(torch.device('cuda', 0), steps)))
+print(json.dumps(bench.measure_affect(torch.device("cuda", 0), steps)))
