@@ -234,7 +234,6 @@ class _FFNBlock(Function):
         B, D, T = h.shape
         F, ns = w1.shape[0], ctx.ns
         st = _stream()
-        need_w = ctx.needs_input_grad[1]
         dropping2 = ctx.drop2 is not None and ctx.drop2.p > 0
         # slab ns = the residual branch's gradient, slabs 0 .. ns-1 = the feed-forward branch's partial sums
         slabs = torch.empty((ns + 1, B, D, T), device=h.device, dtype=torch.float32)
@@ -252,10 +251,13 @@ class _FFNBlock(Function):
         pf = ctx.drop_f.p if ctx.drop_f is not None else 0.0
         L.check(lib.dynmm_ffn_bwd_data(_p(dout), _p(hidden), _p(w1), _p(w2), _p(dhid), _p(slabs), B, D, T, F, ns, float(pf), st),
                 'ffn_bwd_data')
+        # (a layer's weight and bias gradients come out of one weight-gradient problem: either of the pair asks for it)
         dw1 = db1 = dw2 = db2 = None
-        if need_w:
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             dw2, db2 = _wgrad_1x1(hidden, dout, pw2, pb2)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw1, db1 = _wgrad_1x1(h, dhid, pw1, pb1)
+        dw1, db1, dw2, db2 = (t if need else None for t, need in zip((dw1, db1, dw2, db2), ctx.needs_input_grad[1:5]))
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(h)
