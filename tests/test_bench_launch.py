@@ -56,3 +56,29 @@ def test_single_rank_does_not_spawn():
 def test_world_size_mismatch_is_refused():
     r = _run(['--gpus', '4'], extra_env={'WORLD_SIZE': '1', 'RANK': '0', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29533'})
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_roofline_kernel_names_match_the_pmc_summary():
+    """bench.py quotes the roofline per compiled kernel instance (kernel_instance) and looks its HBM traffic up under that name in
+    profiles/pmc_dominant_kernel.json, which profiles/summarize_pmc.py writes: the two name tables must agree, or `traffic`
+    silently becomes null."""
+    import importlib.util
+    import json
+    import os
+    import re
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'profiles', 'summarize_pmc.py')).read()
+    keys = set(re.findall(r"'(conv_[a-z0-9_]+<[^']*>)':\s*\('", src))
+    labels = ['conv_wino43_dgrad<co128,1x3>', 'conv_wino43_dgrad<co64,1x3>', 'conv_wino43_dgrad<co128,3x3>',
+              'conv_wino_fwd<co128,1x3>', 'conv_wino_fwd<co64,3x1>', 'conv_wino_fwd<co64,3x3>', 'conv_wino_dgrad<co128,3x1>',
+              'conv_wino_dgrad<co128,1x3s2>', 'conv_wino_dgrad<co64,3x1s2>', 'conv_wgrad_v6<co128,1x3>', 'conv_wgrad_v6<co64,3x1>',
+              'conv_igemm_v5_fwd<128x64,kw1>']
+    for lb in labels:
+        assert bench.kernel_instance(lb) in keys, (lb, bench.kernel_instance(lb))
+    assert bench.executed_fraction('conv_wino43_dgrad<co128,1x3>') == 0.5
+    assert abs(bench.executed_fraction('conv_wino_fwd<co64,3x3>') - 2 / 3) < 1e-12
+    assert bench.executed_fraction('conv_wino_dgrad<co128,1x3s2>') == 1.0 and bench.executed_fraction('conv_igemm_fwd<128x64>') == 1.0
+    # the committed record carries the kernel the last bench line named
+    rec = json.load(open(os.path.join(root, 'profiles', 'pmc_dominant_kernel.json')))
+    assert 'conv_wino43_dgrad<horizontal>' in rec and rec['conv_wino43_dgrad<horizontal>']['launches_per_step'] == 80
