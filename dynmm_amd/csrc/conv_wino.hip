@@ -45,6 +45,8 @@ struct WinoArgs {
     const float* residual;  // like y or nullptr.  forward: added before the activation; input gradient: added after the mask
     const float* mask;      // like y or nullptr (input gradient): y = mask > 0 ? y : 0
     float* y;               // [N, Co, H, W]
+    double* stats;          // STATS: [nslots][2][Co] running sums of y and y^2 over (N, H, W) (BatchNorm batch statistics), or nullptr
+    int nslots;             //        pixel tile p adds into slab p % nslots (4800 tiles on one address cost a C = 64 launch 18 %)
     int N, Ci, Co, H, W;
     int CoS;                // row stride of `ut` (Co rounded up to the 64-row tile: the pack writes zero rows)
     int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
@@ -55,6 +57,12 @@ struct WinoArgs {
     int Hin, Win;           // input image (== H, W except for the stride-2 input gradients below)
 };
 
+__device__ __forceinline__ float quad_sum(float v) {            // sum over the lane's quad, in every lane of it (DPP quad_perm)
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));     // lanes ^ 1
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));     // lanes ^ 2
+    return v;
+}
+
 // S2 (input gradient only): the same pair machinery for the STRIDE-2 three-tap convolutions that open stages 2-4 (resnet.py:
 // 104-107 with stride (2,1) / (1,2)).  Along the strided axis an output pair of dx is fed by two neighbouring dy values e0, e1:
 //     dx[2j] = W1^T e0          dx[2j+1] = W2^T e0 + W0^T e1
@@ -64,9 +72,14 @@ struct WinoArgs {
 // (4-byte stores at stride 8, 71 TFLOP/s) with the pair kernel's 8-byte stores and operand ring.
 // TAIL (forward only): Co is not a multiple of the 64-row tile (the 40-class conv_out, model.py:286): the filter operand is packed
 // with zero rows up to the tile, the epilogue skips the channels past Co.
-template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false>
+// STATS (forward, horizontal taps, small tile): the convolution feeds a training-mode BatchNorm (resnet.py:110,118; model_utils.py:
+// 22): per-channel sums of y and y^2 of the tile are formed in the epilogue (lane quads by DPP, the rest through LDS in a fixed
+// order) and added to a.stats with one fp64 atomic per channel and statistic — what bn_stats_kernel would produce with a launch
+// and a pass over y of its own (the same fp64 atomics finish its sums).
+template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false>
 __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
+    static_assert(!STATS || (!DGRAD && !VERT && MCO == 1 && TCO == 64 && !TAIL), "statistics: the forward's small horizontal tile");
     static_assert(!TAIL || (!DGRAD && MCO == 1), "channel tails exist in the forward's small tile only");
     // MCO: 32-channel blocks per wave.  2: a wave owns 64 co x 32 pairs x 4 transforms (128 accumulator registers, two
     // workgroups per CU); 1: 32 co x 32 pairs x 4 (64 registers, three workgroups per CU: smaller tiles for the grids a
@@ -399,7 +412,10 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     float* const sh_lds = As;
     for (int i = t; i < TCO; i += 256) sh_lds[i] = (a.shift && (!TAIL || co0 + i < a.Co)) ? a.shift[co0 + i] : 0.f;
     __syncthreads();
-    if (!pvalid) return;
+    if constexpr (!STATS) {
+        if (!pvalid) return;
+    }
+    float* const st_lds = As + TCO;               // STATS: [batch 2][wave 4][row 32 = (khalf, e, statistic)][lane quad 8]
 #pragma unroll
     for (int b = 0; b < 2 * MCO; ++b) {
         const int mi = b >> 1, h = b & 1, set = b & 1;
@@ -433,10 +449,22 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             v0[e] = y0;
             v1[e] = y1;
         }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s1 = quad_sum(pvalid ? v0[e] + v1[e] : 0.f);
+                const float s2 = quad_sum(pvalid ? fmaf(v0[e], v0[e], v1[e] * v1[e]) : 0.f);
+                if ((l31 & 3) == 0) {
+                    float* dst = st_lds + ((b * 4 + wave) * 32 + (khalf * 8 + e) * 2) * 8 + (l31 >> 2);
+                    dst[0] = s1;
+                    dst[8] = s2;
+                }
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned off = off_of(b, e);
-            if (!live(b, e)) continue;
+            if (!live(b, e) || (STATS && !pvalid)) continue;
             if constexpr (VERT) {
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off) = v0[e];
                 if (y1_ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + second) = v1[e];
@@ -445,6 +473,22 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        // thread t: batch t >> 7, (channel, statistic) row (t >> 1) & 63 = (wave_co, khalf, e, statistic), pixel half t & 1
+        const int sb = t >> 7, r = (t >> 1) & 63, wp = t & 1;
+        const int wco = r >> 5, row = r & 31;
+        const float* src = st_lds + ((sb * 4 + wco * WAVES_P + wp) * 32 + row) * 8;
+        float acc_s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc_s += src[j];
+        acc_s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc_s), 0xB1, 0xF, 0xF, true));   // + the other pixel half
+        if (wp == 0) {
+            const int kh = row >> 4, e = (row >> 1) & 7, stat = row & 1;
+            const int c = co0 + wco * WCO + 4 * kh + (e & 3) + 8 * (2 * sb + (e >> 2));
+            atomicAdd(a.stats + ((size_t)((lin / a.n_co_tiles) % a.nslots) * 2 + stat) * a.Co + c, (double)acc_s);
+        }
     }
 }
 
@@ -583,12 +627,17 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool 
     static const int tile_env = env_int_wino("DYNMM_WINO_TILE", 0);
     const int big_tco = (a.Co % 128 == 0) ? 128 : 64;
     const bool tail = a.Co % 64 != 0;
-    const bool small = tile_env != 1 || tail;
+    const bool small = tile_env != 1 || tail || a.stats != nullptr;
     const int tco = small ? 64 : big_tco;
     const int tp = small ? 64 : (tco == 128 ? 64 : 128);
     a.n_co_tiles = ceil_div(a.Co, tco);
     a.n_p_tiles = ceil_div(a.MP, tp);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
+    if (a.stats) {                                // (the entry point admitted only what this instantiation serves)
+        hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, false, false, false, true>), grid, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
     if (tail) {
         if (vert) hipLaunchKernelGGL((conv_wino_kernel<64, 1, true, false, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, false, false, true>), grid, dim3(256), 0, st, a);
@@ -673,6 +722,33 @@ extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const floa
     a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = act;
     return launch_wino(a, g->KW == 1, false, (hipStream_t)stream);
+}
+
+extern "C" int dynmm_conv2d_wino_fwd_stats_supported(const dynmm_conv_geom* g) {
+    return (wino_geom_ok(g, false) && g->KW == 3 && g->Co % 64 == 0) ? 1 : 0;
+}
+
+extern "C" int dynmm_conv2d_wino_fwd_stats_slots(const dynmm_conv_geom* g) {
+    if (!dynmm_conv2d_wino_fwd_stats_supported(g)) return 0;
+    const int tiles = ceil_div(g->N * g->H * g->W / 2, 64);           // 64-pair tiles: each adds once per channel and statistic
+    const int s = tiles / 600;
+    return s < 1 ? 1 : (s > 8 ? 8 : s);
+}
+
+extern "C" int dynmm_conv2d_wino_fwd_stats(const float* x, const float* ut, const float* bias, float* y, double* stats,
+                                           int nslots, const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !ut || !y || !stats || !g || nslots < 1 || nslots > 64) return DYNMM_EINVAL;
+    if (!dynmm_conv2d_wino_fwd_stats_supported(g)) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(stats)) & 7u) return DYNMM_EUNSUPPORTED;
+    WinoArgs a{};
+    a.x = x; a.ut = ut; a.shift = bias; a.residual = nullptr; a.mask = nullptr; a.y = y; a.stats = stats; a.nslots = nslots;
+    a.N = g->N; a.Ci = g->Ci; a.Co = g->Co; a.H = g->H; a.W = g->W;
+    a.CoS = g->Co;
+    a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
+    a.act = DYNMM_ACT_NONE;
+    return launch_wino(a, false, false, (hipStream_t)stream);
 }
 
 extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,

@@ -57,9 +57,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     if (training && num_batches_tracked && plane == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         *num_batches_tracked += 1;          // nn.BatchNorm2d's step counter, without a launch of its own
     if (training) {
+        // training = number of slabs of `sums` ([training][2][C]: a producer that spreads its atomics over several slabs —
+        // conv_wino.hip STATS — or 1), added in slab order
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < training; ++k) {
+            t1 += sums[(size_t)k * 2 * C + c];
+            t2 += sums[(size_t)k * 2 * C + C + c];
+        }
         const double M = (double)N * HW;
-        const double mu = sums[c] / M;
-        double var = sums[C + c] / M - mu * mu;
+        const double mu = t1 / M;
+        double var = t2 / M - mu * mu;
         if (var < 0.0) var = 0.0;
         mean = (float)mu;
         invstd = (float)(1.0 / sqrt(var + (double)eps));

@@ -18,7 +18,8 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False,
     if not bn.training and not torch.is_grad_enabled():
         return ops.conv2d_fused_eval(x, conv.weight, conv.bias, bn, act, residual,
                                      conv.stride, conv.padding, x2)
-    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input, link=conv_link)
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input, link=conv_link,
+                   bn_stats=bn.training)
     return ops.batch_norm_act(y, bn, act, residual, link=res_link)
 
 

@@ -57,6 +57,9 @@ WINO = _os.environ.get('DYNMM_WINO', 'all')
 WINO_INFER = _os.environ.get('DYNMM_WINO_INFER', '1') != '0'
 if WINO not in ('0', 'dgrad', 'fwd', 'all'):
     raise ValueError(f'DYNMM_WINO={WINO!r}: expected 0 | dgrad | fwd | all')
+# BatchNorm batch statistics from the epilogue of the convolution that feeds the BatchNorm (csrc/conv_wino.hip STATS: the horizontal
+# Winograd forward) instead of a bn_stats launch + a pass over the conv output: DYNMM_CONV_BN_STATS=0 switches it off.
+CONV_BN_STATS = _os.environ.get('DYNMM_CONV_BN_STATS', '1') != '0'
 # Input gradients: F(2,3) ('23', conv_wino.hip: 2/3 of the direct matrix work, error class of a direct fp32 sum) or F(4,3)
 # (conv_wino43.hip: 1/2 of the work, 1e-6 .. 4e-6 from fp64) — '43' everywhere it fits, '43h' (default) for the horizontal-tap
 # filters 1x3 / 3x3 only.  Measured (alternating runs on one box, scratch/r4/ab.sh): 71.95 ms with '23', 71.63 with '43h', 72.37
@@ -513,7 +516,7 @@ PREPACK = None
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, w_owner=None):
+    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, w_owner=None, stats=None):
         lib = _lib()
         st = _stream()
         x, x2, weight, bias = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight'), _chk(bias, 'bias')
@@ -551,7 +554,18 @@ class _Conv2d(Function):
                 L.check(lib.dynmm_wino43_pack(_p(weight), _p(utd43), g.Co, g.Ci, g.KH, g.KW, st), 'wino43_pack')
             if PREPACK is not None:
                 PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d, wino_d43)
-        if wino_f:
+        if (wino_f and stats is not None and act == L.ACT_NONE and g.KW == 3 and
+                lib.dynmm_conv2d_wino_fwd_stats_supported(C.byref(g))):
+            # the consumer is a training-mode BatchNorm: its batch statistics come out of this launch (stats: a holder the
+            # conv2d() wrapper hangs on the output tensor for batch_norm_act to find)
+            ns = lib.dynmm_conv2d_wino_fwd_stats_slots(C.byref(g))
+            sums, zeroed = _zero_sums(2 * g.Co * ns, x.device)
+            if not zeroed:
+                sums.zero_()
+            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd_stats(_p(x), _p(utf), _p(bias), _p(y), _p(sums), ns,
+                                                                             C.byref(g), st), wino=True), 'conv2d_wino_fwd_stats')
+            stats['sums'] = sums
+        elif wino_f:
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd(_p(x), _p(utf), _p(bias), None, _p(y), C.byref(g), act, st),
                            wino=True), 'conv2d_wino_fwd')
         else:
@@ -647,23 +661,28 @@ class _Conv2d(Function):
         _grads_enqueued(torch.cuda.current_stream(), ws_stream)
         if dw_ret is not None and tuple(dw_ret.shape) != ctx.wshape:
             dw_ret = dw_ret.reshape(ctx.wshape)
-        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None
+        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_input=False, defer_mask=False,
-           link=None, w_owner=None):
+           link=None, w_owner=None, bn_stats=False):
     """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable.
 
     Backward-fusion hints (set by block code that knows the dataflow; results are unchanged):
       defer_mask : this op's ReLU backward is applied by its (single) consumer — pair with
       mask_input : x is the output of a `defer_mask` op: the dgrad epilogue applies [x > 0];
-      link       : GradLink whose residual-branch gradient is added in the dgrad epilogue."""
+      link       : GradLink whose residual-branch gradient is added in the dgrad epilogue.
+    bn_stats: the output goes straight into a training-mode batch_norm_act: where the forward kernel can, it leaves the BatchNorm's
+    batch statistics with the output (`y._bn_sums`) and batch_norm_act skips its statistics pass."""
     if not torch.is_grad_enabled() and isinstance(weight, torch.nn.Parameter) and w_owner is None:
         # inference: the packed weight is cached on the parameter (conv2d_fused_eval) instead of re-laid-out per call
         # (the factorised blocks' conv -> ReLU pairs were 83 pack launches per forward of config P)
         return conv2d_fused_eval(x, weight, bias, None, act, None, stride, padding, x2)
+    holder = {} if (bn_stats and CONV_BN_STATS and x2 is None) else None
     y = _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
-                      bool(defer_mask), link, w_owner)
+                      bool(defer_mask), link, w_owner, holder)
+    if holder:
+        y._bn_sums = holder['sums']
     if ACT_TRACE is not None and ACT[act] == L.ACT_RELU:
         ACT_TRACE.append(y.detach())
     return y
@@ -800,7 +819,7 @@ def _zero_sums(n, device):
 
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt, pre_sums=None):
         lib = _lib()
         st = _stream()
         x, residual = _chk(x, 'x'), _chk(residual, 'residual')
@@ -813,15 +832,19 @@ class _BatchNormAct(Function):
             note_mutation()          # running statistics / step counter are rewritten in place below
         if training and N * HW <= 1:
             raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
-        if training:
+        if training and pre_sums is not None:
+            sums = pre_sums                      # left by the producing convolution's epilogue (conv2d(bn_stats=True))
+        elif training:
             sums, zeroed = _zero_sums(2 * Cc, dev)
             L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, zeroed, st), 'bn_stats')
         mean = torch.empty(Cc, device=dev, dtype=torch.float32)
         invstd = torch.empty(Cc, device=dev, dtype=torch.float32)
         y = torch.empty_like(x)
+        # (training = the number of slabs the sums arrive in: 1, or the slots of the producing convolution's epilogue)
+        nsl = (sums.numel() // (2 * Cc)) if training else 0
         L.check(lib.dynmm_bn_apply(_p(x), _p(sums), _p(gamma), _p(beta), _p(running_mean),
                                    _p(running_var), _p(mean), _p(invstd), _p(residual), _p(y), _p(nbt),
-                                   N, Cc, HW, eps, momentum, int(training), act, st), 'bn_apply')
+                                   N, Cc, HW, eps, momentum, nsl, act, st), 'bn_apply')
         ctx.act = act
         ctx.training = training
         ctx.link = link
@@ -858,7 +881,7 @@ class _BatchNormAct(Function):
         if ctx.link is not None and dres is not None:
             ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
         _grads_enqueued()
-        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None
+        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
@@ -868,8 +891,11 @@ def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
     nbt = bn.num_batches_tracked if training else None       # incremented inside the normalise kernel
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
         raise L.DynmmHipError('BatchNorm num_batches_tracked must be an int64 tensor on the HIP device')
+    pre = getattr(x, '_bn_sums', None) if training else None
+    if pre is not None and (pre.numel() % (2 * x.shape[1]) != 0 or pre.numel() == 0):
+        pre = None
     y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
-                            bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt)
+                            bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt, pre)
     if ACT_TRACE is not None and ACT[act] == L.ACT_RELU:
         ACT_TRACE.append(y.detach())
     return y

@@ -127,6 +127,15 @@ int dynmm_wino_pack_multi(const float* src_base, float* dst_base, const void* de
                           void* stream);
 int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y,
                           const dynmm_conv_geom* g, int act, void* stream);
+/* The forward of a convolution that feeds a training-mode BatchNorm (resnet.py:110,118 `bn1` / `bn2` after conv1x3_*;
+ * model_utils.py:11-23 ConvBNAct), horizontal taps (1x3, 3x3), Co % 64 == 0, no activation: y as dynmm_conv2d_wino_fwd, and the
+ * per-channel sums of y and y^2 over (N, H, W) ADDED to stats [nslots][2][Co] (fp64, zeroed by the caller; pixel tile p adds into
+ * slab p % nslots, nslots = dynmm_conv2d_wino_fwd_stats_slots(g): thousands of tiles on one address serialise) from the kernel's
+ * epilogue — the `sums` operand of dynmm_bn_apply (training = nslots) without a dynmm_bn_stats launch. */
+int dynmm_conv2d_wino_fwd_stats_supported(const dynmm_conv_geom* g);
+int dynmm_conv2d_wino_fwd_stats_slots(const dynmm_conv_geom* g);
+int dynmm_conv2d_wino_fwd_stats(const float* x, const float* ut, const float* bias, float* y, double* stats, int nslots,
+                                const dynmm_conv_geom* g, void* stream);
 int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
                             const dynmm_conv_geom* g, void* stream);
 
@@ -183,7 +192,8 @@ int dynmm_act_bwd_bias(const float* g, const float* y, float* g_out, float* dbia
  * launch is skipped. */
 int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, int sums_are_zero, void* stream);
 /* y = act( (x-mean)*invstd*gamma + beta + residual ).
- * training=1: mean/var from `sums` (biased var for normalisation); writes save_mean/save_invstd[C],
+ * training=k>=1: mean/var from `sums` [k][2][C] — k slabs added in slab order (1: dynmm_bn_stats; the slots of
+ *             dynmm_conv2d_wino_fwd_stats) — (biased var for normalisation); writes save_mean/save_invstd[C],
  *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and
  *             increments *num_batches_tracked (int64, optional) as nn.BatchNorm2d does.
  * training=0: uses running_mean/var; sums / save_* may be NULL. */

@@ -12,7 +12,8 @@ instead of a multiple of one draw.
 Points: (a) the reference's own N = 8 fixture (config P, 160x192; fp64 gradients = the reference's, 128-element samples),
 (b) BASELINE configs[2]'s resolution, 480x640, batch 2 (fp64 = the oracle's), (c) the small reference fixtures
 (model_<cfg>_<HxW>.npz, train modes): worst deviation of a per-parameter gradient NORM and of a stored full gradient
-tensor from the reference's fp32 values — what GRAD_NORM_TOL / GRAD_FULL_TOL of tests/test_hip_model.py are set from."""
+tensor from the reference's fp32 values — what GRAD_NORM_TOL / GRAD_FULL_TOL of tests/test_hip_model.py are set from,
+(d) the two-step training fixture (two_steps())."""
 import os
 import sys
 
@@ -105,7 +106,47 @@ def small_fixtures():
     return np.array(tags), np.array(rows)
 
 
+def two_steps():
+    """(d) tests/test_engine.py::test_two_train_steps_match_reference: the reference's two SGD-Nesterov steps at batch 2, 96x128
+    (train_steps_P_se.npz), replayed by the oracle under the evaluation orders above: worst relative deviation of a parameter
+    NORM from the reference's after the second update, for the SE-layer tensors and for all others."""
+    g = np.load(os.path.join(HERE, 'train_steps_P_se.npz'))
+    h, w, n = [int(v) for v in g['meta']]
+    lr, wd, mom, ratio, budget, temp = [float(v) for v in g['hyper']]
+    names = [str(k) for k in g['param_names']]
+    ref = g['param_norms']
+    se = np.array(['se_layer' in nm for nm in names])
+    worst = np.zeros(2)
+    for threads, mk, wino in ((8, True, False), (1, True, False), (4, True, False), (8, False, False), (1, False, False),
+                              (1, True, True), (8, True, True), (8, False, True)):
+        torch.set_num_threads(threads)
+        rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+        labels = [synth.synth_labels(n, h // s_, w // s_, seed=300 + s_) for s_ in (1, 8, 16, 32)]
+        sd = Hh.filled_state_dict(Hh.CFGS['P_se'], seed=0)
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+        opt = torch.optim.SGD(list(params.values()), lr=lr, weight_decay=wd, momentum=mom, nesterov=True)
+        with torch.backends.mkldnn.flags(enabled=mk), _form(wino):
+            for _ in range(2):
+                opt.zero_grad()
+                outs, lf = O.forward(sd, rgb, depth, Hh.CFGS['P_se'], training=True, temp=temp)
+                losses = O.cross_entropy_2d(outs, labels, torch.from_numpy(g['cw']))
+                (sum(losses) + ratio * torch.clamp(lf - budget, min=0.0)).backward()
+                opt.step()
+        norms = np.array([sd[k].detach().double().norm().item() for k in names])
+        rel = np.abs(norms - ref) / np.maximum(ref, 1e-3)
+        worst = np.maximum(worst, [rel[~se].max(), rel[se].max()])
+        print('two steps', threads, mk, wino, rel[~se].max(), rel[se].max(), flush=True)
+    return worst
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'two_steps':  # add / refresh part (d) only
+        blob = dict(np.load(os.path.join(HERE, 'grad_noise.npz')))
+        prev = blob.get('two_steps', np.zeros(2))
+        blob['two_steps'] = np.maximum(two_steps(), prev)
+        np.savez_compressed(os.path.join(HERE, 'grad_noise.npz'), **blob)
+        print('two_steps (others, SE):', blob['two_steps'])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'small':      # add / refresh part (c) only
         blob = dict(np.load(os.path.join(HERE, 'grad_noise.npz')))
         blob['small_fixtures'], blob['small'] = small_fixtures()
@@ -137,6 +178,7 @@ def main():
         draws.append(step(480, 640, 2, cw, 0.5, torch.float32, t, mk, wn))
         print('480x640', t, mk, wn, flush=True)
     blob['b2_480x640'] = summarise(draws, g64, names)
+    blob['two_steps'] = two_steps()
     blob['small_fixtures'], blob['small'] = small_fixtures()
     # multi-threaded oneDNN sums are not run-to-run reproducible: keep the worst deviation ever observed per fixture
     old = os.path.join(HERE, 'grad_noise.npz')

@@ -99,9 +99,13 @@ def test_two_train_steps_match_reference(golden_dir, use_graph):
     norms = np.array([sd[k].double().norm().item() for k in names])
     rel = np.abs(norms - g['param_norms']) / np.maximum(g['param_norms'], 1e-3)
     worst = np.argsort(-rel)[:6]
-    # two ill-conditioned updates + momentum; the SE excitation biases are the most sensitive tensors
-    # (fp32-vs-fp64 oracle gradient error ~1e-1 on them) and get a wider band
-    tol = np.array([6e-2 if 'se_layer' in nm else 1e-2 for nm in names])
+    # two ill-conditioned updates + momentum at batch 2; the SE excitation biases are the most sensitive tensors.  Bands = 1.25 x
+    # the worst deviation the CPU oracle itself shows from the reference under eight fp32 evaluation orders (threads, oneDNN /
+    # native, direct / Winograd form — tests/golden/make_grad_noise.py part (d): 0.015 for `layer1.0.conv3x1_2.bias`, 0.067 for an
+    # SE bias), never below the round-1 bands
+    noise = np.load(os.path.join(golden_dir, 'grad_noise.npz'))['two_steps']
+    tol_other, tol_se = max(1e-2, 1.25 * float(noise[0])), max(6e-2, 1.25 * float(noise[1]))
+    tol = np.array([tol_se if 'se_layer' in nm else tol_other for nm in names])
     bad = np.nonzero(rel >= tol)[0]
     assert bad.size == 0, [(names[i], norms[i], g['param_norms'][i], rel[i]) for i in list(bad) + list(worst)]
 

@@ -507,6 +507,55 @@ def test_conv2d_winograd(ops, mode, case):
     assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL
 
 
+@pytest.mark.parametrize('case', [(3, 128, 15, 20, 128, (1, 3)), (2, 64, 12, 16, 128, (3, 3)), (5, 64, 9, 12, 64, (1, 3)),
+                                  (2, 192, 8, 24, 256, (1, 3)), (3, 128, 7, 20, 128, (1, 3)), (8, 64, 120, 160, 64, (1, 3))])
+def test_conv_epilogue_batchnorm_statistics(ops, case):
+    """conv2d(bn_stats=True) -> batch_norm_act (training): the BatchNorm's batch statistics come out of the convolution's epilogue
+    (csrc/conv_wino.hip STATS) instead of a bn_stats pass.  Same output, running statistics, step counter and gradients as the
+    two-pass path; against float64 the statistics themselves to 1e-6."""
+    import torch.nn as nn
+    N, Ci, H, W, Co, k = case
+    p = (k[0] // 2, k[1] // 2)
+    torch.manual_seed(N * 100 + Co)
+    conv = nn.Conv2d(Ci, Co, k, padding=p).cuda()
+    bn = nn.BatchNorm2d(Co).cuda().train()
+    with torch.no_grad():
+        conv.bias.mul_(5.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = rnd(N, Ci, H, W, seed=1).cuda()
+    gz = rnd(N, Co, H, W, seed=2).cuda()
+    y_ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 1, p)
+    old = ops.CONV_BN_STATS
+
+    def run(flag):
+        ops.CONV_BN_STATS = flag
+        bn.reset_running_stats()
+        for q in list(conv.parameters()) + list(bn.parameters()):
+            q.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = ops.conv2d(xi, conv.weight, conv.bias, 1, p, None, bn_stats=True)
+        assert hasattr(y, '_bn_sums') == flag
+        if flag:
+            M = N * H * W
+            tot = y._bn_sums.view(-1, 2, Co).sum(0)
+            assert rel(tot[0] / M, y_ref.mean((0, 2, 3))) < 1e-6
+            assert rel(tot[1] / M, (y_ref * y_ref).mean((0, 2, 3))) < 1e-6
+        z = ops.batch_norm_act(y, bn, 'relu')
+        z.backward(gz)
+        torch.cuda.synchronize()
+        return (z.detach(), xi.grad, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked),
+                conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    try:
+        a, b = run(False), run(True)
+    finally:
+        ops.CONV_BN_STATS = old
+    assert a[4] == b[4] == 1
+    assert rel(b[0], a[0]) < 1e-5 and rel(b[2], a[2]) < 1e-6 and rel(b[3], a[3]) < 1e-6
+    for i in (1, 5, 6, 7):
+        assert rel(b[i], a[i]) < 2e-4, i
+
+
 @pytest.mark.parametrize('case', [(3, 64, 16, 24, 128, (3, 1), (2, 1), (1, 0)), (3, 128, 16, 24, 128, (1, 3), (1, 2), (0, 1)),
                                   (2, 128, 30, 40, 256, (3, 1), (2, 1), (1, 0)), (4, 64, 9, 16, 40, (1, 3), (1, 2), (0, 1))])
 def test_conv2d_stride2_input_gradient_on_the_pair_kernel(ops, case):
