@@ -46,6 +46,7 @@ struct WinoArgs {
     const float* mask;      // like y or nullptr (input gradient): y = mask > 0 ? y : 0
     float* y;               // [N, Co, H, W]
     double* stats;          // STATS: [nslots][2][Co] running sums of y and y^2 over (N, H, W) (BatchNorm batch statistics), or nullptr
+    const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;   // BNRED: the BatchNorm whose output gradient this launch produces
     int nslots;             //        pixel tile p adds into slab p % nslots (4800 tiles on one address cost a C = 64 launch 18 %)
     int N, Ci, Co, H, W;
     int CoS;                // row stride of `ut` (Co rounded up to the 64-row tile: the pack writes zero rows)
@@ -76,8 +77,13 @@ __device__ __forceinline__ float quad_sum(float v) {            // sum over the 
 // 22): per-channel sums of y and y^2 of the tile are formed in the epilogue (lane quads by DPP, the rest through LDS in a fixed
 // order) and added to a.stats with one fp64 atomic per channel and statistic — what bn_stats_kernel would produce with a launch
 // and a pass over y of its own (the same fp64 atomics finish its sums).
-template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false>
+// BNRED (input gradient, vertical taps, small tile): the launch produces the gradient g of z = relu(BN(c)) (resnet.py:131-135:
+// conv3x1_2 consumes relu(bn1(.))).  `mask` carries c, the BatchNorm's INPUT: the epilogue re-derives [BN(c) > 0] with the
+// forward's own fma, and leaves the BatchNorm backward's two reductions, sum g.[z > 0] and sum g.[z > 0].xhat, in a.stats
+// (the `sums` of dynmm_bn_bwd_apply) — bn_bwd_reduce_kernel's launch and its pass over g and c are not needed.
+template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, bool BNRED = false>
 __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
+    static_assert(!BNRED || (DGRAD && VERT && !S2 && MCO == 1 && TCO == 64 && !TAIL && !STATS), "BatchNorm reductions: vertical dgrad");
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
     static_assert(!STATS || (!DGRAD && !VERT && MCO == 1 && TCO == 64 && !TAIL), "statistics: the forward's small horizontal tile");
     static_assert(!TAIL || (!DGRAD && MCO == 1), "channel tails exist in the forward's small tile only");
@@ -412,23 +418,44 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     float* const sh_lds = As;
     for (int i = t; i < TCO; i += 256) sh_lds[i] = (a.shift && (!TAIL || co0 + i < a.Co)) ? a.shift[co0 + i] : 0.f;
     __syncthreads();
-    if constexpr (!STATS) {
+    float* const cst_lds = As + TCO;              // BNRED: per channel {gamma.invstd, beta - mean.gamma.invstd, invstd, -mean.invstd}
+    if constexpr (BNRED) {
+        if (t < TCO) {
+            const int c = co0 + t;
+            const float is = a.bn_invstd[c], mu = a.bn_mean[c], sc = a.bn_gamma[c] * is;
+            cst_lds[4 * t + 0] = sc;
+            cst_lds[4 * t + 1] = fmaf(-mu, sc, a.bn_beta[c]);      // (bn_apply_kernel's own two lines)
+            cst_lds[4 * t + 2] = is;
+            cst_lds[4 * t + 3] = -mu * is;
+        }
+        __syncthreads();
+    }
+    if constexpr (!STATS && !BNRED) {
         if (!pvalid) return;
     }
-    float* const st_lds = As + TCO;               // STATS: [batch 2][wave 4][row 32 = (khalf, e, statistic)][lane quad 8]
+    float* const st_lds = As + 5 * TCO;           // STATS / BNRED: [batch 2][wave 4][row 32 = (khalf, e, statistic)][lane quad 8]
 #pragma unroll
     for (int b = 0; b < 2 * MCO; ++b) {
         const int mi = b >> 1, h = b & 1, set = b & 1;
         if (b + 1 < 2 * MCO && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
         float v0[8], v1[8];
+        float q1[8], q2[8];                       // BNRED: this lane's contributions to the two reductions
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int j = 8 * h + e;
             const float ma = acc[0][mi][j], mb = acc[1][mi][j], mc = acc[2][mi][j], md = acc[3][mi][j];
-            const float sh = sh_lds[wave_co * WCO + mi * 32 + 4 * khalf + (e & 3) + 8 * (2 * h + (e >> 2))];
+            const int cl = wave_co * WCO + mi * 32 + 4 * khalf + (e & 3) + 8 * (2 * h + (e >> 2));
+            const float sh = sh_lds[cl];
             float y0 = S2 ? ma + sh : (ma + mb) + mc + sh;
             float y1 = S2 ? mb + sh : (mb - mc) - md + sh;
-            if (DGRAD) {
+            if constexpr (BNRED) {
+                const float4 cs = *reinterpret_cast<const float4*>(cst_lds + 4 * cl);
+                const float c0 = k0[set][e], c1 = k1[set][e];
+                y0 = (pvalid && fmaf(c0, cs.x, cs.y) > 0.f) ? y0 : 0.f;
+                y1 = (pvalid && y1_ok && fmaf(c1, cs.x, cs.y) > 0.f) ? y1 : 0.f;
+                q1[e] = y0 + y1;
+                q2[e] = fmaf(y0, fmaf(c0, cs.z, cs.w), y1 * fmaf(c1, cs.z, cs.w));
+            } else if (DGRAD) {
                 if (has_mask) {
                     y0 = k0[set][e] > 0.f ? y0 : 0.f;
                     y1 = k1[set][e] > 0.f ? y1 : 0.f;
@@ -449,11 +476,11 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             v0[e] = y0;
             v1[e] = y1;
         }
-        if constexpr (STATS) {
+        if constexpr (STATS || BNRED) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float s1 = quad_sum(pvalid ? v0[e] + v1[e] : 0.f);
-                const float s2 = quad_sum(pvalid ? fmaf(v0[e], v0[e], v1[e] * v1[e]) : 0.f);
+                const float s1 = quad_sum(BNRED ? q1[e] : (pvalid ? v0[e] + v1[e] : 0.f));
+                const float s2 = quad_sum(BNRED ? q2[e] : (pvalid ? fmaf(v0[e], v0[e], v1[e] * v1[e]) : 0.f));
                 if ((l31 & 3) == 0) {
                     float* dst = st_lds + ((b * 4 + wave) * 32 + (khalf * 8 + e) * 2) * 8 + (l31 >> 2);
                     dst[0] = s1;
@@ -464,7 +491,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned off = off_of(b, e);
-            if (!live(b, e) || (STATS && !pvalid)) continue;
+            if (!live(b, e) || ((STATS || BNRED) && !pvalid)) continue;
             if constexpr (VERT) {
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off) = v0[e];
                 if (y1_ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + second) = v1[e];
@@ -474,7 +501,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (STATS) {
+    if constexpr (STATS || BNRED) {
         __syncthreads();
         // thread t: batch t >> 7, (channel, statistic) row (t >> 1) & 63 = (wave_co, khalf, e, statistic), pixel half t & 1
         const int sb = t >> 7, r = (t >> 1) & 63, wp = t & 1;
@@ -633,6 +660,11 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool 
     a.n_co_tiles = ceil_div(a.Co, tco);
     a.n_p_tiles = ceil_div(a.MP, tp);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
+    if (a.stats && dgrad) {                       // BatchNorm backward reductions from the vertical input gradient
+        hipLaunchKernelGGL((conv_wino_kernel<64, 1, true, true, false, false, false, true>), grid, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
     if (a.stats) {                                // (the entry point admitted only what this instantiation serves)
         hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, false, false, false, true>), grid, dim3(256), 0, st, a);
         DYNMM_LAUNCH_CHECK();
@@ -722,6 +754,33 @@ extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const floa
     a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = act;
     return launch_wino(a, g->KW == 1, false, (hipStream_t)stream);
+}
+
+extern "C" int dynmm_conv2d_wino_dgrad_bnred_supported(const dynmm_conv_geom* g) {
+    // 3x1 stride-1 input gradient on the pair kernel; few enough pixel tiles that their atomics on one address do not serialise
+    return (wino_geom_ok(g, true) && g->KH == 3 && g->KW == 1 && g->Ci % 64 == 0 &&
+            ceil_div(g->N * ((g->H + 1) / 2) * g->W, 64) <= 2400) ? 1 : 0;
+}
+
+extern "C" int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, const float* bn_x, const float* bn_mean,
+                                             const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                             double* sums, float* dx, const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (!dy || !ut || !bn_x || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !sums || !dx || !g) return DYNMM_EINVAL;
+    if (!dynmm_conv2d_wino_dgrad_bnred_supported(g)) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(bn_x) | reinterpret_cast<uintptr_t>(sums)) & 7u)
+        return DYNMM_EUNSUPPORTED;
+    WinoArgs a{};
+    a.x = dy; a.ut = ut; a.shift = nullptr; a.residual = nullptr; a.mask = bn_x; a.y = dx;
+    a.stats = sums; a.nslots = 1;
+    a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_gamma = bn_gamma; a.bn_beta = bn_beta;
+    a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;
+    a.CoS = (a.Co + 63) & ~63;
+    a.KR = 1;
+    a.act = DYNMM_ACT_NONE;
+    a.Hin = g->Ho; a.Win = g->Wo;
+    return launch_wino(a, true, true, (hipStream_t)stream);
 }
 
 extern "C" int dynmm_conv2d_wino_fwd_stats_supported(const dynmm_conv_geom* g) {

@@ -9,7 +9,7 @@ import torch.nn as nn
 from .. import ops
 
 
-def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False, conv_link=None, res_link=None):
+def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False, conv_link=None, res_link=None, bwd_link=None):
     """act(BN(conv(x|x2)) + residual).
 
     inference (eval, no grad): ONE kernel — BN folded into the implicit-GEMM epilogue.
@@ -20,7 +20,7 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, x2=None, mask_input=False,
                                      conv.stride, conv.padding, x2)
     y = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, None, x2, mask_input=mask_input, link=conv_link,
                    bn_stats=bn.training)
-    return ops.batch_norm_act(y, bn, act, residual, link=res_link)
+    return ops.batch_norm_act(y, bn, act, residual, link=res_link, bwd_link=bwd_link)
 
 
 class ConvBNAct(nn.Sequential):
@@ -61,9 +61,11 @@ class NonBottleneck1D(nn.Module):
             x, xd = ops.fan_out(x, 2)            # x feeds the first conv AND the down-sample conv: one fused gradient sum
         c = self.conv3x1_1
         y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link)
-        y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd)
+        # bn1 + ReLU feed conv3x1_2 and nothing else: its input-gradient launch also does bn1's backward reductions (ops.BNLink)
+        bnl = ops.BNLink() if (fuse_bwd and self.bn1.training) else None
+        y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd, bwd_link=bnl)
         c = self.conv3x1_2
-        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd)
+        y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, bn_link=bnl)
         idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
         return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link)
 

@@ -399,6 +399,20 @@ class GradLink:
         self.dres = None
 
 
+class BNLink:
+    """Joins a training-mode BatchNorm + ReLU to the single convolution that consumes its output, for the backward pass: the
+    convolution's input-gradient launch (csrc/conv_wino.hip BNRED) also leaves the BatchNorm backward's two reductions, and the
+    BatchNorm's backward then starts at its apply pass.  batch_norm_act fills `x, mean, invstd, gamma, beta` in the forward; the
+    convolution's backward fills `sums` when its kernel took the job (it runs first: gradients flow consumer -> producer)."""
+    __slots__ = ('x', 'mean', 'invstd', 'gamma', 'beta', 'sums')
+
+    def __init__(self):
+        self.x = self.mean = self.invstd = self.gamma = self.beta = self.sums = None
+
+
+BN_BWD_FUSE = _os.environ.get('DYNMM_BN_BWD_FUSE', '1') != '0'
+
+
 class PackedWeights:
     """The operand layouts of every conv weight a training step uses — the implicit-GEMM layouts (dynmm_pack_weight) and the
     Winograd filter transforms (dynmm_wino_pack) — produced by ONE launch each per step instead of one per convolution (186
@@ -516,7 +530,8 @@ PREPACK = None
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, w_owner=None, stats=None):
+    def forward(ctx, x, x2, weight, bias, stride, padding, act, mask_input, defer_mask, link, w_owner=None, stats=None,
+                bn_link=None):
         lib = _lib()
         st = _stream()
         x, x2, weight, bias = _chk(x, 'x'), _chk(x2, 'x2'), _chk(weight, 'weight'), _chk(bias, 'bias')
@@ -579,6 +594,7 @@ class _Conv2d(Function):
         ctx.mask_input = mask_input       # x is a ReLU output: apply [x > 0] in the dgrad epilogue
         ctx.defer_mask = defer_mask       # our own ReLU backward is applied by the consumer's dgrad
         ctx.link = link
+        ctx.bn_link = bn_link
         ctx.save_for_backward(x, x2, utd43 if wino_d43 else (utd if wino_d else wpd),
                               y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
@@ -630,9 +646,22 @@ class _Conv2d(Function):
                 # caller) are copied into fresh allocations first
                 gyw = gy if gy.data_ptr() % 16 == 0 else gy.clone()
                 mask, accum = (t if (t is None or t.data_ptr() % 16 == 0) else t.clone() for t in (mask, accum))
-                fn = lib.dynmm_conv2d_wino43_dgrad if ctx.wino_d == 43 else lib.dynmm_conv2d_wino_dgrad
-                L.check(_timed('dgrad', g, lambda: fn(_p(gyw), _p(wpd), _p(mask), _p(accum), _p(dx), C.byref(g), st),
-                               extra=extra, wino=ctx.wino_d), 'conv2d_wino_dgrad')
+                bl = ctx.bn_link
+                if (bl is not None and bl.x is not None and ctx.wino_d == 23 and mask is None and accum is None and
+                        bl.x.data_ptr() % 8 == 0 and lib.dynmm_conv2d_wino_dgrad_bnred_supported(C.byref(g))):
+                    # x = relu(BN(c)) of a training-mode BatchNorm: mask by [BN(c) > 0] here and leave that BatchNorm's backward
+                    # reductions with the link (its backward, which runs next, skips its reduction pass)
+                    sums, zeroed = _zero_sums(2 * g.Ci, dx.device)
+                    if not zeroed:
+                        sums.zero_()
+                    L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_wino_dgrad_bnred(
+                        _p(gyw), _p(wpd), _p(bl.x), _p(bl.mean), _p(bl.invstd), _p(bl.gamma), _p(bl.beta), _p(sums), _p(dx),
+                        C.byref(g), st), extra=1, wino=ctx.wino_d), 'conv2d_wino_dgrad_bnred')
+                    bl.sums = sums
+                else:
+                    fn = lib.dynmm_conv2d_wino43_dgrad if ctx.wino_d == 43 else lib.dynmm_conv2d_wino_dgrad
+                    L.check(_timed('dgrad', g, lambda: fn(_p(gyw), _p(wpd), _p(mask), _p(accum), _p(dx), C.byref(g), st),
+                                   extra=extra, wino=ctx.wino_d), 'conv2d_wino_dgrad')
             else:
                 L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_dgrad(_p(gy), _p(wpd), _p(mask), _p(accum), _p(dx),
                                                                           _p(dx2), C.byref(g), st), extra=extra), 'conv2d_dgrad')
@@ -661,11 +690,11 @@ class _Conv2d(Function):
         _grads_enqueued(torch.cuda.current_stream(), ws_stream)
         if dw_ret is not None and tuple(dw_ret.shape) != ctx.wshape:
             dw_ret = dw_ret.reshape(ctx.wshape)
-        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None, None
+        return dx, dx2, dw_ret, dbias_ret, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_input=False, defer_mask=False,
-           link=None, w_owner=None, bn_stats=False):
+           link=None, w_owner=None, bn_stats=False, bn_link=None):
     """act(conv2d(cat([x, x2], 1), weight) + bias).  Differentiable.
 
     Backward-fusion hints (set by block code that knows the dataflow; results are unchanged):
@@ -673,14 +702,15 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_in
       mask_input : x is the output of a `defer_mask` op: the dgrad epilogue applies [x > 0];
       link       : GradLink whose residual-branch gradient is added in the dgrad epilogue.
     bn_stats: the output goes straight into a training-mode batch_norm_act: where the forward kernel can, it leaves the BatchNorm's
-    batch statistics with the output (`y._bn_sums`) and batch_norm_act skips its statistics pass."""
+    batch statistics with the output (`y._bn_sums`) and batch_norm_act skips its statistics pass.
+    bn_link: x is the output of batch_norm_act(..., 'relu', bwd_link=bn_link) and this convolution is its only consumer (BNLink)."""
     if not torch.is_grad_enabled() and isinstance(weight, torch.nn.Parameter) and w_owner is None:
         # inference: the packed weight is cached on the parameter (conv2d_fused_eval) instead of re-laid-out per call
         # (the factorised blocks' conv -> ReLU pairs were 83 pack launches per forward of config P)
         return conv2d_fused_eval(x, weight, bias, None, act, None, stride, padding, x2)
     holder = {} if (bn_stats and CONV_BN_STATS and x2 is None) else None
     y = _Conv2d.apply(x, x2, weight, bias, _pair(stride), _pair(padding), ACT[act], bool(mask_input),
-                      bool(defer_mask), link, w_owner, holder)
+                      bool(defer_mask), link, w_owner, holder, bn_link if BN_BWD_FUSE else None)
     if holder:
         y._bn_sums = holder['sums']
     if ACT_TRACE is not None and ACT[act] == L.ACT_RELU:
@@ -819,7 +849,8 @@ def _zero_sums(n, device):
 
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt, pre_sums=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, link, nbt, pre_sums=None,
+                bwd_link=None):
         lib = _lib()
         st = _stream()
         x, residual = _chk(x, 'x'), _chk(residual, 'residual')
@@ -848,6 +879,10 @@ class _BatchNormAct(Function):
         ctx.act = act
         ctx.training = training
         ctx.link = link
+        ctx.bwd_link = None
+        if bwd_link is not None and training and act == L.ACT_RELU and residual is None:
+            bwd_link.x, bwd_link.mean, bwd_link.invstd, bwd_link.gamma, bwd_link.beta = x, mean, invstd, gamma, beta
+            ctx.bwd_link = bwd_link
         ctx.has_res = residual is not None
         # ReLU without residual: the backward re-derives the mask from x (bit-identical to this forward's
         # fma) instead of reading y — one tensor read less in bn_bwd_reduce and in bn_bwd_apply
@@ -865,9 +900,15 @@ class _BatchNormAct(Function):
         N, Cc, H, W = x.shape
         HW = H * W
         dev = x.device
-        sums, zeroed = _zero_sums(2 * Cc, dev)
-        L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-                                        N, Cc, HW, ctx.act, zeroed, st), 'bn_bwd_reduce')
+        bl = ctx.bwd_link
+        if bl is not None and bl.sums is not None:
+            sums, bl.sums = bl.sums, None          # left by the consumer convolution's input-gradient launch (BNLink)
+        else:
+            sums, zeroed = _zero_sums(2 * Cc, dev)
+            L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
+                                            N, Cc, HW, ctx.act, zeroed, st), 'bn_bwd_reduce')
+        if bl is not None:
+            bl.x = None
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[5]
         dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None
@@ -881,10 +922,10 @@ class _BatchNormAct(Function):
         if ctx.link is not None and dres is not None:
             ctx.link.dres, dres = dres, None      # absorbed by the first conv's dgrad epilogue
         _grads_enqueued()
-        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None, None
+        return dx, dgamma_ret, dbeta_ret, None, None, dres, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
+def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None, bwd_link=None):
     """act(BatchNorm2d(x) + residual) using the parameters/buffers of the nn.BatchNorm2d `bn`.
     `link`: GradLink that carries the residual's gradient to the op that consumes the same tensor."""
     training = bn.training if training is None else training
@@ -895,7 +936,7 @@ def batch_norm_act(x, bn, act=None, residual=None, training=None, link=None):
     if pre is not None and (pre.numel() % (2 * x.shape[1]) != 0 or pre.numel() == 0):
         pre = None
     y = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
-                            bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt, pre)
+                            bool(training), float(bn.momentum), float(bn.eps), ACT[act], link, nbt, pre, bwd_link)
     if ACT_TRACE is not None and ACT[act] == L.ACT_RELU:
         ACT_TRACE.append(y.detach())
     return y

@@ -127,6 +127,14 @@ int dynmm_wino_pack_multi(const float* src_base, float* dst_base, const void* de
                           void* stream);
 int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y,
                           const dynmm_conv_geom* g, int act, void* stream);
+/* The input gradient of a 3x1 convolution whose input is z = relu(BN(c)) (resnet.py:131-135 conv3x1_2 after bn1 + ReLU), together
+ * with that BatchNorm's backward reductions: dx = the convolution's input gradient masked by [BN(c) > 0] (re-derived from c = bn_x
+ * with bn_apply's own fma), and sums[0][ch] += sum dx, sums[1][ch] += sum dx * xhat over (N, H, W) — the `sums` operand of
+ * dynmm_bn_bwd_apply (fp64 [2][Ci], zeroed by the caller) without a dynmm_bn_bwd_reduce launch. */
+int dynmm_conv2d_wino_dgrad_bnred_supported(const dynmm_conv_geom* g);
+int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, const float* bn_x, const float* bn_mean,
+                                  const float* bn_invstd, const float* bn_gamma, const float* bn_beta, double* sums, float* dx,
+                                  const dynmm_conv_geom* g, void* stream);
 /* The forward of a convolution that feeds a training-mode BatchNorm (resnet.py:110,118 `bn1` / `bn2` after conv1x3_*;
  * model_utils.py:11-23 ConvBNAct), horizontal taps (1x3, 3x3), Co % 64 == 0, no activation: y as dynmm_conv2d_wino_fwd, and the
  * per-channel sums of y and y^2 over (N, H, W) ADDED to stats [nslots][2][Co] (fp64, zeroed by the caller; pixel tile p adds into
