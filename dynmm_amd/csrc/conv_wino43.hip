@@ -42,8 +42,10 @@ struct Wino43Args {
     int n_co_tiles, n_q_tiles;
 };
 
-template <bool VERT>
+// KR3: 3x3 filter (a template flag since round 5, as in conv_wino.hip: the three-tap launches carry no tap bookkeeping)
+template <bool VERT, bool KR3 = false>
 __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a) {
+    static_assert(!KR3 || !VERT, "3x3 filters run on the horizontal quad form");
     constexpr int BK = 8, S = 3, TCO = 64, TQ = 64, NT = 6;
     constexpr int A4_STAGE = BK * TCO * 4, A2_STAGE = BK * TCO * 2;         // floats
     constexpr int PIXW = 4 * TQ + 8;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     __shared__ __attribute__((aligned(16))) float A4s[S * A4_STAGE];
     __shared__ __attribute__((aligned(16))) float A2s[S * A2_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[S * B_STAGE];
-    __shared__ __attribute__((aligned(16))) float Zs[VERT ? 4 : B_STAGE];
+    __shared__ __attribute__((aligned(16))) float Zs[KR3 ? B_STAGE : 4];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -71,8 +73,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     const int q0 = (lin / a.n_co_tiles) * TQ;
     const int HW = a.H * a.W;
     const int NC = a.Ci / BK;
-    const int nst = a.KR * NC;
-    auto dh_of = [&](int r) { return a.KR == 3 ? 1 - r : 0; };       // (input gradient: the vertical taps run the other way)
+    const int nst = KR3 ? 3 * NC : NC;
+    auto dh_of = [&](int r) { return KR3 ? 1 - r : 0; };       // (input gradient: the vertical taps run the other way)
 
     // ---------------------------------------------------------------- loader state
     unsigned b_off[NIB];
@@ -101,9 +103,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
             const int n = m / HW, rem = m - n * HW;
             const int h = rem / a.W;
             b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
-            for (int r = 0; r < a.KR; ++r) {
-                const int hh = h + dh_of(r);
-                b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
+            if constexpr (KR3) {
+                for (int r = 0; r < 3; ++r) {
+                    const int hh = h + dh_of(r);
+                    b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
+                }
             }
         }
     }
@@ -112,27 +116,49 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     const unsigned lds_a4 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)A4s);
     const unsigned lds_a2 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)A2s);
     const unsigned lds_b = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Bs);
-    int l_t = 0, l_r = 0, l_c = 0;
+    // running request state (conv_wino.hip's: constant strides per stage, no multiplications in the loop)
+    const float* a4_ptr = a.ut4 + ((size_t)(2 * wave) * a.Co + co0) * 4;
+    const float* a2_ptr = a.ut2 + ((size_t)(2 * wave) * a.Co + co0) * 2;
+    const size_t a4_step = (size_t)BK * a.Co * 4, a2_step = (size_t)BK * a.Co * 2, a4_row = (size_t)a.Co * 4;
+    const float* b_ptr = a.x;
+    const size_t b_step = (size_t)BK * HW;
+    unsigned l_a4dst = lds_a4 + (unsigned)(2 * wave * TCO * 4 * 4), l_a2dst = lds_a2 + (unsigned)(2 * wave * TCO * 2 * 4);
+    unsigned l_bdst = lds_b + (unsigned)(wave * QPW * 4 * 4);
+    const unsigned l_a4dst_end = l_a4dst + (unsigned)(S * A4_STAGE * 4);
+    int l_left = nst;
+    int l_r = 0, l_c = 0;
+    unsigned l_shift = (unsigned)(dh_of(0) * a.W * 4);
     auto issue = [&]() {
-        if (l_t < nst) {
-            const int slot = l_t % S;
-            const size_t row0 = (size_t)(l_r * a.Ci + l_c * BK + 2 * wave);
-            const float* a4 = a.ut4 + (row0 * a.Co + co0) * 4;
-            const unsigned a4dst = lds_a4 + (unsigned)((slot * A4_STAGE + 2 * wave * TCO * 4) * 4);
-            dma16(a4, a4_voff, a4dst);
-            dma16(a4 + (size_t)a.Co * 4, a4_voff, a4dst + 1024u);
-            dma16(a.ut2 + (row0 * a.Co + co0) * 2, a2_voff, lds_a2 + (unsigned)((slot * A2_STAGE + 2 * wave * TCO * 2) * 4));
-            const float* bbase = a.x + (size_t)(l_c * BK) * HW;
-            const unsigned bdst = lds_b + (unsigned)((slot * B_STAGE + wave * QPW * 4) * 4);
-            const int shift = dh_of(l_r) * a.W * 4;
+        if (l_left > 0) {
+            dma16(a4_ptr, a4_voff, l_a4dst);
+            dma16(a4_ptr + a4_row, a4_voff, l_a4dst + 1024u);
+            dma16(a2_ptr, a2_voff, l_a2dst);
 #pragma unroll
             for (int i = 0; i < NIB; ++i) {
                 unsigned voff = b_off[i];
-                if constexpr (!VERT) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? (unsigned)shift : 0u;
-                if (b_act[i]) dma16(bbase, voff, bdst + (unsigned)i * 1024u);
+                if constexpr (KR3) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? l_shift : 0u;
+                if (b_act[i]) dma16(b_ptr, voff, l_bdst + (unsigned)i * 1024u);
             }
-            ++l_t;
-            if (++l_c == NC) { l_c = 0; ++l_r; }
+            --l_left;
+            a4_ptr += a4_step;
+            a2_ptr += a2_step;
+            b_ptr += b_step;
+            l_a4dst += (unsigned)(A4_STAGE * 4);
+            l_a2dst += (unsigned)(A2_STAGE * 4);
+            l_bdst += (unsigned)(B_STAGE * 4);
+            if (l_a4dst == l_a4dst_end) {
+                l_a4dst -= (unsigned)(S * A4_STAGE * 4);
+                l_a2dst -= (unsigned)(S * A2_STAGE * 4);
+                l_bdst -= (unsigned)(S * B_STAGE * 4);
+            }
+            if constexpr (KR3) {
+                if (++l_c == NC) {
+                    l_c = 0;
+                    ++l_r;
+                    b_ptr = a.x;
+                    l_shift = (unsigned)(dh_of(l_r) * a.W * 4);
+                }
+            }
         }
     };
 
@@ -167,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
             dv[5] = w + 4 < a.W;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ov[j] = true;
-            if (a.KR == 3) {
+            if constexpr (KR3) {
                 rbits = 0;
                 for (int r = 0; r < 3; ++r) {
                     const int hh = h + dh_of(r);
@@ -186,7 +212,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-    if constexpr (!VERT) {
+    if constexpr (KR3) {
         for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
     }
 
@@ -235,10 +261,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     wait_vm<2 * NI>();
     __syncthreads();
     int cr = 0, cc = 0;
+    int c_a4 = 0, c_a2 = 0, c_b = 0;              // ring offsets (floats) of the stage being consumed
     const float* A4p = A4s;
     const float* A2p = A2s;
     const float* Bp = Bs;
-    if constexpr (!VERT) {
+    if constexpr (KR3) {
         if (!(rbits & 1u)) Bp = Zs;
     }
     read_raw(0, 0, A4p, A2p, Bp);
@@ -268,12 +295,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
             else wait_vm<0>();
             __syncthreads();
             issue();
-            if (++cc == NC) { cc = 0; ++cr; }
-            const int slot = (s + 1) % S;
-            A4p = A4s + slot * A4_STAGE;
-            A2p = A2s + slot * A2_STAGE;
-            Bp = Bs + slot * B_STAGE;
-            if constexpr (!VERT) {
+            c_a4 += A4_STAGE;
+            c_a2 += A2_STAGE;
+            c_b += B_STAGE;
+            if (c_a4 == S * A4_STAGE) { c_a4 = 0; c_a2 = 0; c_b = 0; }
+            A4p = A4s + c_a4;
+            A2p = A2s + c_a2;
+            Bp = Bs + c_b;
+            if constexpr (KR3) {
+                if (++cc == NC) { cc = 0; ++cr; }
                 if (!((rbits >> cr) & 1u)) Bp = Zs;
             }
             read_raw(0, 0, A4p, A2p, Bp);
@@ -494,6 +524,7 @@ extern "C" int dynmm_conv2d_wino43_dgrad(const float* dy, const float* ut, const
     a.n_q_tiles = ceil_div(a.MQ, 64);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_q_tiles));
     if (vert) hipLaunchKernelGGL((conv_wino43_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (KR == 3) hipLaunchKernelGGL((conv_wino43_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_wino43_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;

@@ -181,6 +181,29 @@ def broadcast_parameters(module, src=0, process_group=None):
             dist.broadcast(t, src=src, group=process_group)
 
 
+def broadcast_buffers(module, src=0, process_group=None):
+    """Rank `src`'s buffers (BatchNorm running statistics, step counters) on every replica — DDP's `broadcast_buffers`.
+    Running statistics are updated per replica from its own shard (no SyncBN, like the reference), so before a SHARDED
+    evaluation the replicas must agree on them, or the all-reduced confusion matrix describes no single model
+    (engine.evaluate).  One collective per dtype: the buffers are flattened, broadcast and copied back."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return 0
+    by_dtype = {}
+    for b in module.buffers():
+        if b.numel():
+            by_dtype.setdefault((b.dtype, b.device), []).append(b)
+    with torch.no_grad():
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=src, group=process_group)
+            off = 0
+            for b in bufs:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
+    return sum(len(v) for v in by_dtype.values())
+
+
 def shard_batch(global_batch, rank, world):
     """Contiguous per-rank slice [lo, hi) of a global batch (used by train/eval drivers)."""
     per = global_batch // world

@@ -21,9 +21,11 @@ from . import lib as L
 
 class FlatParameters:
     """Re-home the given parameters into one contiguous fp32 buffer (views keep state_dict,
-    load_state_dict and autograd working unchanged).  Layout = reverse parameter order, the order in
-    which dp.GradBucketReducer lays out the flat gradient buffer.  align > 1 (elements): every parameter starts on a multiple
-    of `align` (zero padding between them; kernels that stage weights with 16-byte loads — csrc/seq_ffn.hip — need align = 4)."""
+    load_state_dict and autograd working unchanged).  Layout = reverse parameter order; with align = 1 (the default) it is
+    element for element the layout of dp.GradBucketReducer's flat gradient buffer.  align > 1 (elements): every parameter
+    starts on a multiple of `align` (zero padding between them; kernels that stage weights with 16-byte loads —
+    csrc/seq_ffn.hip — need align = 4): such a buffer does NOT match the reducer's packed layout and needs a gradient buffer
+    laid out with the same spans (AffectTrainStep allocates its own; _FlatOptimizer asserts equal sizes)."""
 
     def __init__(self, params, align=1):
         self.params = list(params)
@@ -469,7 +471,8 @@ def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard
 
     Data parallel (new; the reference is single-device): with `shard` and an initialised process group, rank r runs
     batches r, r + world, ... and the 40x40 confusion matrix (int64: exact) is all-reduced once at the end — every rank
-    returns the same mIoU for 1/world of the forward passes.
+    returns the same mIoU for 1/world of the forward passes.  The module buffers (BatchNorm running statistics) are
+    broadcast from rank 0 first, so the result is rank 0's model evaluated on the whole set.
 
     `losses` (a dict) + `class_weight`: also accumulate validate()'s two validation losses (train.py:432-440;
     src/utils.py:53-97) from batches that carry the 4th element; the dict receives `sum_weighted`, `weight_sum`,
@@ -482,6 +485,11 @@ def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard
     acc4 = torch.zeros(4, dtype=torch.float64, device=dev)
     cw = None if class_weight is None else torch.as_tensor(class_weight, dtype=torch.float32, device=dev)
     rank, world = _dist_world(group) if shard else (0, 1)
+    if world > 1:
+        # the replicas' BatchNorm running statistics differ (each rank updates them from its own shard): a sharded
+        # evaluation must describe ONE model — rank 0's, the one train.py checkpoints
+        dp.broadcast_buffers(model, 0, group)
+        ops.note_mutation()
     for i, batch in enumerate(batches):
         if i % world != rank:
             continue

@@ -51,10 +51,18 @@ def run_branches(fns):
             _POOL.append(torch.cuda.Stream())
             _ALL.append(_POOL[-1])
         taken.append(_POOL.pop())
+    # fork BEFORE branch 0 is enqueued on `main`: a side stream that waited for `main` afterwards would wait for the whole of
+    # branch 0 (in DynMMNetV2: the gate transformer), i.e. one branch followed by four instead of five in parallel — also in
+    # the captured hipGraph.  The event marks the inputs' readiness only.
+    fork = torch.cuda.Event()
+    fork.record(main)
+    if torch.cuda.is_current_stream_capturing():
+        from .. import ops
+        ops._CAPTURE_EVENTS.append(fork)           # an event recorded into a capture must outlive it (ops._queue_wgrad)
     first = fns[0]()                               # host order = list order (the injected-mask tests count calls)
     outs = []
     for st, f in zip(taken, fns[1:]):
-        st.wait_stream(main)
+        st.wait_event(fork)
         with torch.cuda.stream(st):
             outs.append(f())
     capturing = torch.cuda.is_current_stream_capturing()

@@ -439,8 +439,12 @@ class PackedWeights:
             self.dirty = True
         else:
             for i, f in enumerate(flags):
-                if f and not e[5 + i]:
-                    e[5 + i] = True
+                if f and e[5 + i] != f:
+                    # (wino_dgrad is tri-state — 1: stride-1 transform, 2: stride-2 polyphase operand; the two are different
+                    # operands of different kernels, so a weight is registered with exactly one of them: store the value)
+                    if i == 3 and e[5 + i] and f:
+                        raise L.DynmmHipError('a convolution weight was registered with both Winograd input-gradient operand kinds')
+                    e[5 + i] = f
                     self.dirty = True
 
     def lookup(self, weight, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False):
@@ -452,6 +456,8 @@ class PackedWeights:
         for need, t in zip((need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad), s):
             if need and t is None:
                 return None
+        if wino_dgrad and self.reg[id(weight)][5 + 3] != int(wino_dgrad):
+            return None                          # the slot holds the other operand kind (stride-1 transform vs stride-2 polyphase)
         return s
 
     def _layout(self):

@@ -33,6 +33,9 @@
 //     outside the image points the reads at an all-zero slot.
 #include <stdlib.h>
 
+#ifndef EXP
+#define EXP 0
+#endif
 #include "common.h"
 #include "conv_igemm.h"
 
@@ -81,13 +84,8 @@ __device__ __forceinline__ float quad_sum(float v) {            // sum over the 
 // conv3x1_2 consumes relu(bn1(.))).  `mask` carries c, the BatchNorm's INPUT: the epilogue re-derives [BN(c) > 0] with the
 // forward's own fma, and leaves the BatchNorm backward's two reductions, sum g.[z > 0] and sum g.[z > 0].xhat, in a.stats
 // (the `sums` of dynmm_bn_bwd_apply) — bn_bwd_reduce_kernel's launch and its pass over g and c are not needed.
-// KR3: a 3x3 filter (horizontal taps in the pair form, vertical taps looped as part of the reduction).  A template flag since
-// round 5: the three-tap launches (58 + 64 of every 64 + 67) carry none of the tap bookkeeping — no zero slot in LDS (4 workgroups
-// per CU fit where the registers allow), no row bits, a loader whose addresses advance by constant strides.
-template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, bool BNRED = false,
-          bool KR3 = false>
-__global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
-    static_assert(!KR3 || (!VERT && !S2 && !BNRED), "3x3 filters run on the horizontal pair form");
+template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, bool BNRED = false>
+__global__ void __launch_bounds__(256, MCO == 1 ? (EXP == 6 ? 4 : 3) : 2) conv_wino_kernel(const WinoArgs a) {
     static_assert(!BNRED || (DGRAD && VERT && !S2 && MCO == 1 && TCO == 64 && !TAIL && !STATS), "BatchNorm reductions: vertical dgrad");
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
     static_assert(!STATS || (!DGRAD && !VERT && MCO == 1 && TCO == 64 && !TAIL), "statistics: the forward's small horizontal tile");
@@ -113,7 +111,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 
     __shared__ __attribute__((aligned(16))) float As[S * A_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[S * B_STAGE];
-    __shared__ __attribute__((aligned(16))) float Zs[KR3 ? B_STAGE : 4];   // zeros: a vertical tap outside the image (3x3)
+    __shared__ __attribute__((aligned(16))) float Zs[(VERT || EXP == 6) ? 4 : B_STAGE];  // zeros: a vertical tap outside the image (3x3)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -128,11 +126,12 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     const int HW = a.H * a.W;
     const int HWin = a.Hin * a.Win;
     const int NC = a.Ci / BK;
-    const int nst = KR3 ? 3 * NC : NC;
+    const int nst = a.KR * NC;
 
-    auto dh_of = [&](int r) { return KR3 ? (DGRAD ? 1 - r : r - 1) : 0; };
+    auto dh_of = [&](int r) { return a.KR == 3 ? (DGRAD ? 1 - r : r - 1) : 0; };
 
     // ---------------------------------------------------------------- loader state
+    const int p0l = (EXP == 3) ? 0 : p0;
     unsigned b_off[NIB];
     unsigned b_rows = 0;                          // horizontal 3x3: bit 3*i + r: the quad's row shifted by tap r is inside the image
     bool b_act[NIB];
@@ -143,7 +142,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         const int q = wave * QPW + (b_act[i] ? ql : 0);
         if constexpr (VERT) {
             const int k = q / (NP * QPR), j = (q / QPR) % NP, gq = q % QPR;
-            int p = p0 + 4 * gq;
+            int p = p0l + 4 * gq;
             p = p > a.MP - 4 ? a.MP - 4 : p;       // quads past the tensor: any mapped address (never used)
             const int per = a.H2 * a.W;
             const int n = p / per, rr = p - n * per;
@@ -154,63 +153,40 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         } else {
             const int k = q / QPR, quad = q - k * QPR;
             const int M = S2 ? a.MP : 2 * a.MP;    // input pixels
-            int m = (S2 ? p0 : 2 * p0) - 4 + 4 * quad;
+            int m = (S2 ? p0l : 2 * p0l) - 4 + 4 * quad;
             m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
             const int n = m / HWin, rem = m - n * HWin;
             const int h = rem / a.Win;
             b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HWin + (unsigned)rem) * 4u;
-            if constexpr (KR3) {
-                for (int r = 0; r < 3; ++r) {
-                    const int hh = h + dh_of(r);
-                    b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
-                }
+            for (int r = 0; r < a.KR; ++r) {
+                const int hh = h + dh_of(r);
+                b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
             }
         }
     }
     const unsigned a_voff = (unsigned)lane * 16u;
     const unsigned lds_a = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)As);
     const unsigned lds_b = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Bs);
-    // Next stage to request.  Everything the request needs advances by a constant per stage (the filter operand's row
-    // 8 * stage + 2 * wave of [tap row][ci] x CoS, the input's channel chunk, the ring slot): running pointers, no
-    // multiplications in the loop — the first version recomputed them from the stage index, ~70 scalar instructions per wave and
-    // stage beside 16 MFMAs (profiles/r05_wino_bound.md).
-    const float* a_ptr = a.ut + ((size_t)(2 * wave) * a.CoS + co0) * 4;
-    const size_t a_step = (size_t)BK * a.CoS * 4, a_row = (size_t)a.CoS * 4;
-    const float* b_ptr = a.x;
-    const size_t b_step = (size_t)BK * HWin;
-    unsigned l_adst = lds_a + (unsigned)(2 * wave * TCO * 4 * 4), l_bdst = lds_b + (unsigned)(wave * QPW * 4 * 4);
-    const unsigned l_adst_end = l_adst + (unsigned)(S * A_STAGE * 4);
-    int l_left = nst;                             // stages not yet requested
-    int l_r = 0, l_c = 0;                         // 3x3: vertical tap / channel chunk of the next request
-    unsigned l_shift = (unsigned)(dh_of(0) * a.W * 4);
+    int l_t = 0, l_r = 0, l_c = 0;                // next stage to request: index, vertical tap, channel chunk
     auto issue = [&]() {
-        if (l_left > 0) {
+        if (l_t < nst) {
+            const int slot = l_t % S;
+            const float* abase = a.ut + ((size_t)(l_r * a.Ci + l_c * BK + 2 * wave) * a.CoS + co0) * 4;
+            const unsigned adst = lds_a + (unsigned)((slot * A_STAGE + 2 * wave * TCO * 4) * 4);
 #pragma unroll
             for (int i = 0; i < NIA; ++i)
-                dma16(a_ptr + (size_t)(i / IPR) * a_row + 64 * (i % IPR) * 4, a_voff, l_adst + (unsigned)i * 1024u);
+                dma16(abase + ((size_t)(i / IPR) * a.CoS + 64 * (i % IPR)) * 4, a_voff, adst + (unsigned)i * 1024u);
+            const float* bbase = a.x + (size_t)(l_c * BK) * HWin;
+            const unsigned bdst = lds_b + (unsigned)((slot * B_STAGE + wave * QPW * 4) * 4);
+            const int shift = dh_of(l_r) * a.W * 4;
 #pragma unroll
             for (int i = 0; i < NIB; ++i) {
                 unsigned voff = b_off[i];
-                if constexpr (KR3) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? l_shift : 0u;
-                if (b_act[i]) dma16(b_ptr, voff, l_bdst + (unsigned)i * 1024u);
+                if constexpr (!VERT) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? (unsigned)shift : 0u;
+                if (b_act[i]) dma16(bbase, voff, bdst + (unsigned)i * 1024u);
             }
-            --l_left;
-            a_ptr += a_step;
-            b_ptr += b_step;
-            l_adst += (unsigned)(A_STAGE * 4);
-            l_bdst += (unsigned)(B_STAGE * 4);
-            if (l_adst == l_adst_end) {
-                l_adst -= (unsigned)(S * A_STAGE * 4);
-                l_bdst -= (unsigned)(S * B_STAGE * 4);
-            }
-            if constexpr (KR3) {
-                if (++l_c == NC) {
-                    l_c = 0;
-                    ++l_r;
-                    b_ptr = a.x;
-                    l_shift = (unsigned)(dh_of(l_r) * a.W * 4);
-                }
-            }
+            ++l_t;
+            if (++l_c == NC) { l_c = 0; ++l_r; }
         }
     };
 
@@ -240,7 +216,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             m0 = w > 0;
             m2 = true;
             m3 = S2 ? (w >> 1) + 1 < a.Win : w + 2 < a.W;         // (S2: e1, the next dy column, exists)
-            if constexpr (KR3) {
+            if (a.KR == 3) {
                 rbits = 0;
                 for (int r = 0; r < 3; ++r) {
                     const int hh = h + dh_of(r);
@@ -260,18 +236,25 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][mi][j] = 0.f;
 
-    if constexpr (KR3) {
-        for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
+    if constexpr (!VERT) {
+        if (EXP != 6) for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
     }
 
     float4 fa[2][MCO];                            // [register set][mi]: U_0..U_3 of (k, co)
     float fd[2][4];                               // [register set]: raw d0..d3 of (k, pair)
-    float fv[2][4];                               // [register set][transform]: V_i of (k, pair)
+    float fv[2][4];
+    if (EXP == 5) { for (int ss = 0; ss < 2; ++ss) { for (int mi = 0; mi < MCO; ++mi) fa[ss][mi] = make_float4(1.f, 2.f, 3.f, 4.f); for (int i = 0; i < 4; ++i) fd[ss][i] = 0.5f * i; } }
     // The fragment traffic of k-pair q + 1 is split in two so that no LDS wait sits between the MFMAs of k-pair q (measured
     // with the compiler's own interleaving: MFMA-busy 0.47): read_raw issues the LDS reads BEFORE the 8 MFMAs of k-pair q,
     // transform consumes them AFTER those MFMAs have been issued (its handful of VALU instructions runs while the last MFMA
     // executes); scheduling barriers pin the three phases.
     auto read_raw = [&](int set, int q, const float* Ap, const float* Bp) {
+        if (EXP == 5) {
+#pragma unroll
+            for (int mi = 0; mi < MCO; ++mi) { asm volatile("" : "+v"(fa[set][mi].x), "+v"(fa[set][mi].y), "+v"(fa[set][mi].z), "+v"(fa[set][mi].w)); }
+            asm volatile("" : "+v"(fd[set][0]), "+v"(fd[set][1]), "+v"(fd[set][2]), "+v"(fd[set][3]));
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi)
             fa[set][mi] = *reinterpret_cast<const float4*>(Ap + a_frag + (2 * q * TCO + mi * 32) * 4);
@@ -296,6 +279,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         }
     };
     auto transform = [&](int set) {
+        if (EXP == 4) { fv[set][0] = fd[set][0]; fv[set][1] = fd[set][1]; fv[set][2] = fd[set][2]; fv[set][3] = fd[set][3]; return; }
         if constexpr (S2) {                           // V = (e0, e0, e1): no arithmetic, the zero past the last row / column
             fv[set][0] = fv[set][1] = fd[set][0];
             fv[set][2] = m3 ? fd[set][1] : 0.f;
@@ -320,8 +304,10 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
                 continue;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fv[set][i], acc[i][mi], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                if (EXP == 2) acc[i][mi][0] = fmaf(av[i], fv[set][i], acc[i][mi][0]);
+                else acc[i][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], fv[set][i], acc[i][mi], 0, 0, 0);
+            }
         }
     };
 #define DYNMM_WINO_PHASE() __builtin_amdgcn_sched_barrier(0)
@@ -337,11 +323,10 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     issue();
     wait_vm<2 * NI>();                            // (nst >= 3: the launcher requires >= 24 reduction channels)
     __syncthreads();
-    int cr = 0, cc = 0;                           // 3x3: vertical tap / chunk of the stage being consumed
-    int c_a = 0, c_b = 0;                         // ring offsets (floats) of the stage being consumed
+    int cr = 0, cc = 0;                           // vertical tap / chunk of the stage being consumed
     const float* Ap = As;
     const float* Bp = Bs;
-    if constexpr (KR3) {
+    if constexpr (!VERT) {
         if (!(rbits & 1u)) Bp = Zs;               // this lane's row under vertical tap 0 is outside the image: all four d are 0
     }
     read_raw(0, 0, Ap, Bp);
@@ -371,13 +356,11 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             else wait_vm<0>();
             __syncthreads();
             issue();
-            c_a += A_STAGE;
-            c_b += B_STAGE;
-            if (c_a == S * A_STAGE) { c_a = 0; c_b = 0; }
-            Ap = As + c_a;
-            Bp = Bs + c_b;
-            if constexpr (KR3) {
-                if (++cc == NC) { cc = 0; ++cr; }
+            if (++cc == NC) { cc = 0; ++cr; }
+            const int slot = (s + 1) % S;
+            Ap = As + slot * A_STAGE;
+            Bp = Bs + slot * B_STAGE;
+            if constexpr (!VERT) {
                 if (!((rbits >> cr) & 1u)) Bp = Zs;
             }
             read_raw(0, 0, Ap, Bp);
@@ -394,6 +377,17 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     // The epilogue operands of batch b+1 (8 channels x 2 outputs of one accumulator block half) are requested before batch b
     // is transformed and stored, the first batch before the rings are released: with two workgroups per CU nothing else
     // hides their latency (a dgrad launch with a ReLU mask ran at 95 TFLOP/s against 121 without, before this).
+    if (EXP == 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mi = 0; mi < MCO; ++mi)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc += acc[i][mi][j];
+        if (sacc == 123456.789f) a.y[0] = sacc;
+        return;
+    }
     const float* __restrict__ res_p = a.residual;
     const float* __restrict__ mask_p = a.mask;
     float* __restrict__ y_p = a.y;
@@ -656,6 +650,11 @@ static bool wino_s2_geom_ok(const dynmm_conv_geom* g) {
     return true;
 }
 
+static int env_int_wino(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool s2 = false) {
     if (s2) {                                      // pairs = dy positions; a.Hin / a.Win were set by the caller
         a.H2 = a.Hin;
@@ -672,35 +671,50 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool 
     a.Win = a.W;
     a.H2 = (a.H + 1) / 2;
     a.MP = vert ? a.N * a.H2 * a.W : a.N * a.H * a.W / 2;
-    // tile: 64 co x 64 pairs, 4 accumulator blocks per wave, 3 workgroups per CU.  (Round 4 also kept 128 x 64 / 64 x 128 tiles
-    // with 8 blocks per wave behind DYNMM_WINO_TILE=1: slower on every encoder shape but one at batch 32 — C = 256 / 512: 143-148
-    // / 125-134 against 115-122 / 108-110 TFLOP/s algorithmic — and removed in round 5 with their six instantiations.)
+    // tile: 64 co x 64 pairs with 4 accumulator blocks per wave (default), or (128 co x 64 pairs | 64 co x 128 pairs) with 8
+    // (DYNMM_WINO_TILE=1).  Measured at batch 32 (scratch/r4/wino_check.py, then in the step): the small tile is faster on
+    // every encoder shape but one — C = 256 / 512: 143-148 / 125-134 against 115-122 / 108-110 TFLOP/s algorithmic (600 / 300
+    // large tiles do not fill two rounds of 512 slots), C = 64: 91-97 against 88-93, C = 128: 116-119 against 107-122 —,
+    // equal on the 3x3 convolutions; input-gradient kernel time per step 16.2 -> 14.0 ms.
+    static const int tile_env = env_int_wino("DYNMM_WINO_TILE", 0);
+    const int big_tco = (a.Co % 128 == 0) ? 128 : 64;
     const bool tail = a.Co % 64 != 0;
-    const bool kr3 = a.KR == 3;
-    a.n_co_tiles = ceil_div(a.Co, 64);
-    a.n_p_tiles = ceil_div(a.MP, 64);
+    const bool small = tile_env != 1 || tail || a.stats != nullptr;
+    const int tco = small ? 64 : big_tco;
+    const int tp = small ? 64 : (tco == 128 ? 64 : 128);
+    a.n_co_tiles = ceil_div(a.Co, tco);
+    a.n_p_tiles = ceil_div(a.MP, tp);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
-#define DYNMM_WINO_LAUNCH(...) hipLaunchKernelGGL((conv_wino_kernel<64, 1, __VA_ARGS__>), grid, dim3(256), 0, st, a)
     if (a.stats && dgrad) {                       // BatchNorm backward reductions from the vertical input gradient
-        DYNMM_WINO_LAUNCH(true, true, false, false, false, true);
-    } else if (a.stats) {                         // (the entry point admitted only what these instantiations serve)
-        if (kr3) DYNMM_WINO_LAUNCH(false, false, false, false, true, false, true);
-        else DYNMM_WINO_LAUNCH(false, false, false, false, true);
-    } else if (tail) {
-        if (vert) DYNMM_WINO_LAUNCH(true, false, false, true);
-        else if (kr3) DYNMM_WINO_LAUNCH(false, false, false, true, false, false, true);
-        else DYNMM_WINO_LAUNCH(false, false, false, true);
-    } else if (vert) {
-        if (dgrad) DYNMM_WINO_LAUNCH(true, true);
-        else DYNMM_WINO_LAUNCH(true, false);
-    } else if (kr3) {
-        if (dgrad) DYNMM_WINO_LAUNCH(false, true, false, false, false, false, true);
-        else DYNMM_WINO_LAUNCH(false, false, false, false, false, false, true);
-    } else {
-        if (dgrad) DYNMM_WINO_LAUNCH(false, true);
-        else DYNMM_WINO_LAUNCH(false, false);
+        hipLaunchKernelGGL((conv_wino_kernel<64, 1, true, true, false, false, false, true>), grid, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
     }
-#undef DYNMM_WINO_LAUNCH
+    if (a.stats) {                                // (the entry point admitted only what this instantiation serves)
+        hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, false, false, false, true>), grid, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
+    if (tail) {
+        if (vert) hipLaunchKernelGGL((conv_wino_kernel<64, 1, true, false, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wino_kernel<64, 1, false, false, false, true>), grid, dim3(256), 0, st, a);
+        DYNMM_LAUNCH_CHECK();
+        return DYNMM_OK;
+    }
+#define DYNMM_WINO_GO(TCO, MCO)                                                                                        \
+    do {                                                                                                               \
+        if (vert) {                                                                                                    \
+            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, true, true>), grid, dim3(256), 0, st, a);         \
+            else hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, true, false>), grid, dim3(256), 0, st, a);              \
+        } else {                                                                                                       \
+            if (dgrad) hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, false, true>), grid, dim3(256), 0, st, a);        \
+            else hipLaunchKernelGGL((conv_wino_kernel<TCO, MCO, false, false>), grid, dim3(256), 0, st, a);             \
+        }                                                                                                              \
+    } while (0)
+    if (small) DYNMM_WINO_GO(64, 1);
+    else if (tco == 128) DYNMM_WINO_GO(128, 2);
+    else DYNMM_WINO_GO(64, 2);
+#undef DYNMM_WINO_GO
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -709,37 +723,37 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool 
 
 using namespace dynmm;
 
-extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) {
+extern "C" int exp_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) {
     if (wino_geom_ok(g, dgrad != 0)) return 1;
     return (dgrad && wino_s2_geom_ok(g)) ? 2 : 0;
 }
 
-extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
+extern "C" size_t exp_wino_packed_floats(int Co, int Ci, int KH, int KW) {
     if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
     // either operand: [KR][K][rows rounded up to 64][4]
     const size_t fwd = (size_t)Ci * ((Co + 63) & ~63), dg = (size_t)Co * ((Ci + 63) & ~63);
     return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * (fwd > dg ? fwd : dg) * 4;
 }
 
-extern "C" int dynmm_wino_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int KH, int KW, int dgrad,
+extern "C" int exp_wino_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int KH, int KW, int dgrad,
                                void* stream) {
     (void)hipGetLastError();
     if (!w || !ut || Co <= 0 || Ci <= 0 || (scale && dgrad) || dgrad < 0 || dgrad > 2) return DYNMM_EINVAL;
     if (dgrad == 2 && KH == 3 && KW == 3) return DYNMM_EUNSUPPORTED;
     if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
-    const size_t total = dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4;
+    const size_t total = exp_wino_packed_floats(Co, Ci, KH, KW) / 4;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        reinterpret_cast<float4*>(ut), scale, Co, Ci, KH, KW, dgrad);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
 
-extern "C" int dynmm_wino_pack_multi_blocks(int Co, int Ci, int KH, int KW) {
-    return (int)ceil_div_sz(dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4, 256);
+extern "C" int exp_wino_pack_multi_blocks(int Co, int Ci, int KH, int KW) {
+    return (int)ceil_div_sz(exp_wino_packed_floats(Co, Ci, KH, KW) / 4, 256);
 }
 
-extern "C" int dynmm_wino_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
+extern "C" int exp_wino_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks,
                                      void* stream) {
     (void)hipGetLastError();
     if (!src_base || !dst_base || !desc || ndesc <= 0 || total_blocks <= 0) return DYNMM_EINVAL;
@@ -751,7 +765,7 @@ extern "C" int dynmm_wino_pack_multi(const float* src_base, float* dst_base, con
     return DYNMM_OK;
 }
 
-extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y,
+extern "C" int exp_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y,
                                      const dynmm_conv_geom* g, int act, void* stream) {
     (void)hipGetLastError();
     if (!x || !ut || !y || !g) return DYNMM_EINVAL;
@@ -767,18 +781,18 @@ extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const floa
     return launch_wino(a, g->KW == 1, false, (hipStream_t)stream);
 }
 
-extern "C" int dynmm_conv2d_wino_dgrad_bnred_supported(const dynmm_conv_geom* g) {
+extern "C" int exp_conv2d_wino_dgrad_bnred_supported(const dynmm_conv_geom* g) {
     // 3x1 stride-1 input gradient on the pair kernel; few enough pixel tiles that their atomics on one address do not serialise
     return (wino_geom_ok(g, true) && g->KH == 3 && g->KW == 1 && g->Ci % 64 == 0 &&
             ceil_div(g->N * ((g->H + 1) / 2) * g->W, 64) <= 2400) ? 1 : 0;
 }
 
-extern "C" int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, const float* bn_x, const float* bn_mean,
+extern "C" int exp_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, const float* bn_x, const float* bn_mean,
                                              const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
                                              double* sums, float* dx, const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();
     if (!dy || !ut || !bn_x || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !sums || !dx || !g) return DYNMM_EINVAL;
-    if (!dynmm_conv2d_wino_dgrad_bnred_supported(g)) return DYNMM_EUNSUPPORTED;
+    if (!exp_conv2d_wino_dgrad_bnred_supported(g)) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(bn_x) | reinterpret_cast<uintptr_t>(sums)) & 7u)
         return DYNMM_EUNSUPPORTED;
@@ -794,22 +808,22 @@ extern "C" int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, c
     return launch_wino(a, true, true, (hipStream_t)stream);
 }
 
-extern "C" int dynmm_conv2d_wino_fwd_stats_supported(const dynmm_conv_geom* g) {
+extern "C" int exp_conv2d_wino_fwd_stats_supported(const dynmm_conv_geom* g) {
     return (wino_geom_ok(g, false) && g->KW == 3 && g->Co % 64 == 0) ? 1 : 0;
 }
 
-extern "C" int dynmm_conv2d_wino_fwd_stats_slots(const dynmm_conv_geom* g) {
-    if (!dynmm_conv2d_wino_fwd_stats_supported(g)) return 0;
+extern "C" int exp_conv2d_wino_fwd_stats_slots(const dynmm_conv_geom* g) {
+    if (!exp_conv2d_wino_fwd_stats_supported(g)) return 0;
     const int tiles = ceil_div(g->N * g->H * g->W / 2, 64);           // 64-pair tiles: each adds once per channel and statistic
     const int s = tiles / 600;
     return s < 1 ? 1 : (s > 8 ? 8 : s);
 }
 
-extern "C" int dynmm_conv2d_wino_fwd_stats(const float* x, const float* ut, const float* bias, float* y, double* stats,
+extern "C" int exp_conv2d_wino_fwd_stats(const float* x, const float* ut, const float* bias, float* y, double* stats,
                                            int nslots, const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();
     if (!x || !ut || !y || !stats || !g || nslots < 1 || nslots > 64) return DYNMM_EINVAL;
-    if (!dynmm_conv2d_wino_fwd_stats_supported(g)) return DYNMM_EUNSUPPORTED;
+    if (!exp_conv2d_wino_fwd_stats_supported(g)) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(stats)) & 7u) return DYNMM_EUNSUPPORTED;
     WinoArgs a{};
@@ -821,7 +835,7 @@ extern "C" int dynmm_conv2d_wino_fwd_stats(const float* x, const float* ut, cons
     return launch_wino(a, false, false, (hipStream_t)stream);
 }
 
-extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
+extern "C" int exp_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
                                        const dynmm_conv_geom* g, void* stream) {
     (void)hipGetLastError();
     if (!dy || !ut || !dx || !g) return DYNMM_EINVAL;

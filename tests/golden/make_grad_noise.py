@@ -142,8 +142,7 @@ def two_steps():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'two_steps':  # add / refresh part (d) only
         blob = dict(np.load(os.path.join(HERE, 'grad_noise.npz')))
-        prev = blob.get('two_steps', np.zeros(2))
-        blob['two_steps'] = np.maximum(two_steps(), prev)
+        blob['two_steps'] = two_steps()
         np.savez_compressed(os.path.join(HERE, 'grad_noise.npz'), **blob)
         print('two_steps (others, SE):', blob['two_steps'])
         return
@@ -180,12 +179,9 @@ def main():
     blob['b2_480x640'] = summarise(draws, g64, names)
     blob['two_steps'] = two_steps()
     blob['small_fixtures'], blob['small'] = small_fixtures()
-    # multi-threaded oneDNN sums are not run-to-run reproducible: keep the worst deviation ever observed per fixture
-    old = os.path.join(HERE, 'grad_noise.npz')
-    if os.path.exists(old):
-        prev = np.load(old)
-        if 'small' in prev.files and list(prev['small_fixtures']) == list(blob['small_fixtures']):
-            blob['small'] = np.maximum(blob['small'], prev['small'])
+    # (no ratchet: the table is what THIS run of the fixed draw list shows.  Fixtures whose spread exceeds 0.08 — a flipped
+    # ReLU / arg-max decision between correct fp32 evaluations — are not compared with the reference's fp32 gradients at all;
+    # tests/test_hip_model.py compares them with the fp64 oracle at equal decisions instead, at a fixed 0.02)
     np.savez_compressed(os.path.join(HERE, 'grad_noise.npz'), **blob)
     for k in ('n8', 'n8_reference_fp32', 'b2_480x640'):
         print(k, np.array2string(blob[k], precision=4))

@@ -150,3 +150,43 @@ def test_shard_batch_partitions():
         spans = [dp.shard_batch(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_buffers(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dynmm_amd import dp
+    torch.manual_seed(3)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4), torch.nn.BatchNorm2d(4))
+    m.train()
+    torch.manual_seed(50 + rank)                     # each replica updates its running statistics from its own shard
+    for _ in range(3):
+        m(torch.randn(2, 3, 5, 5) * (1 + rank))
+    if rank == 1:
+        m[2].num_batches_tracked.add_(5)
+    before = [b.detach().clone() for b in m.buffers()]
+    n = dp.broadcast_buffers(m, 0)
+    after = [b.detach().numpy().copy() for b in m.buffers()]
+    q.put((rank, n, [b.numpy().copy() for b in before], after, [p.detach().numpy().copy() for p in m.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_buffers_makes_replicas_agree_on_running_statistics():
+    """engine.evaluate shards the validation batches over the ranks: every rank must then evaluate rank 0's BatchNorm
+    running statistics (the replicas' own differ), int64 step counters included; parameters are not touched."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_buffers, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, before0, after0, _), (_, n1, before1, after1, _) = res
+    assert n0 == n1 == 6                                            # 2 x (running_mean, running_var, num_batches_tracked)
+    assert any(not np.array_equal(a, b) for a, b in zip(before0, before1))     # the replicas really had diverged
+    for b0, a0, a1 in zip(before0, after0, after1):
+        assert np.array_equal(a0, b0) and np.array_equal(a1, b0) and a1.dtype == b0.dtype      # rank 0's values, bit for bit

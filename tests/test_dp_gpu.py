@@ -154,3 +154,53 @@ def test_bucket_allreduce_over_rccl_single_rank():
     _, launched, nb, finite, mass = res
     assert launched == nb and nb >= 4          # every bucket's all-reduce went out during backward, through RCCL
     assert finite and mass > 0
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dynmm_amd import dp, engine, synth
+    from dynmm_amd.nn.net import SkipGateESANet
+    h, w, n = 96, 128, 2
+    m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+    synth.fill_state_dict(m.state_dict(), seed=0)
+    m = m.cuda().eval()
+    dp.broadcast_parameters(m)
+    with torch.no_grad():                                        # what a few training steps on different shards leave behind:
+        gen = torch.Generator(device='cuda').manual_seed(10 + rank)      # replicas that disagree on the running statistics
+        for name, b in m.named_buffers():
+            if name.endswith('running_mean'):
+                b.add_(0.05 * torch.randn(b.shape, device='cuda', generator=gen))
+            elif name.endswith('running_var'):
+                b.mul_(1.0 + 0.1 * torch.rand(b.shape, device='cuda', generator=gen))
+    batches = []
+    for i in range(4):
+        rgb, depth = synth.synth_inputs(n, h, w, seed=500 + i, device='cuda')
+        batches.append((rgb, depth, synth.synth_labels(n, h, w, seed=600 + i, device='cuda').to(torch.uint8)))
+    own_first = engine.evaluate(m, batches, shard=False)         # this replica's own model on the whole set
+    sharded = engine.evaluate(m, batches, shard=True)            # buffers from rank 0, batches rank, rank + 2, ...
+    own_after = engine.evaluate(m, batches, shard=False)         # every replica now holds rank 0's buffers
+    q.put((rank, own_first[0], own_first[1].numpy(), sharded[0], sharded[1].numpy(), own_after[0], own_after[1].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_describes_rank0_model():
+    """BatchNorm running statistics differ between the replicas; the sharded evaluate() must report the mIoU of
+    ONE model — rank 0's, the one train.py checkpoints — not a mixture of per-rank models."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, m0, cm0, ms0, cms0, ma0, cma0), (_, m1, cm1, ms1, cms1, ma1, cma1) = res
+    assert not np.array_equal(cm0, cm1)                          # the two replicas were different models
+    assert ms0 == ms1 and np.array_equal(cms0, cms1)             # both ranks report the same sharded result ...
+    assert np.array_equal(cms0, cm0) and ms0 == m0               # ... and it is rank 0's unsharded one, exactly
+    assert np.array_equal(cma1, cm0) and ma1 == m0               # rank 1 now evaluates rank 0's statistics

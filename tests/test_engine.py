@@ -68,6 +68,75 @@ def test_temperature_schedule_matches_reference(golden_dir):
 
 
 @pytest.mark.gpu
+def test_two_train_steps_vs_fp64_oracle_at_equal_decisions(golden_dir):
+    """The two SGD-Nesterov steps of the reference fixture (train_steps_P_se.npz: batch 2, 96x128) against the fp64 oracle at EQUAL
+    decisions (tests/test_hip_model.py: test_model_gradients_vs_fp64_oracle_at_equal_decisions): the HIP pass's ReLU decisions are
+    imposed on the oracle at its near-ties and must equal the oracle's elsewhere.  Each step is checked from a COMMON state: the
+    oracle takes step 0 from the fixture's weights and step 1 from the HIP path's own weights and momentum buffers after step 0
+    (in fp64) — a gradient tensor of this net carries ~1e-2 of fp32 conditioning noise which one update turns
+    into a weight perturbation that moves decisions far outside any rounding band, so the second forward of two free-running
+    implementations is not comparable decision for decision.  (That free-running comparison is the golden test below, held to
+    bands calibrated on the fp32 oracle's own spread.)  Per step: the four losses and the total to 1e-4, every parameter norm
+    after the update to 1e-3 of the fp64 result and every parameter TENSOR to 2e-3 in relative L2 (measured 1.4e-4 / 3.2e-4; momentum, Nesterov look-ahead and weight decay of step 1 included)."""
+    from dynmm_amd import engine, ops
+    from dynmm_amd.nn.net import SkipGateESANet
+    from oracle import dynmm_oracle as O
+    from tests import helpers as Hh
+    from tests.test_hip_blocks import hip_relu_decisions
+    from tests.test_hip_model import DECISION_BAND
+    g = np.load(os.path.join(golden_dir, 'train_steps_P_se.npz'))
+    h, w, n = [int(v) for v in g['meta']]
+    lr, wd, mom, ratio, budget, temp = [float(v) for v in g['hyper']]
+    m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+    synth.fill_state_dict(m.state_dict(), 0)
+    m = m.cuda().train()
+    m.temp, m.hard_gate = temp, False
+    rgb, depth = synth.synth_inputs(n, h, w, seed=1234)
+    labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s) for s in (1, 8, 16, 32)]
+    step = engine.TrainStep(m, g['cw'], lr=lr, momentum=mom, weight_decay=wd, loss_ratio=ratio, flop_budget=budget,
+                            use_graph=False, multi_stream=False)
+    hp = dict(m.named_parameters())
+    sd = Hh.filled_state_dict(Hh.CFGS['P_se'], seed=0)
+    sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+    names = list(params)
+    opt = torch.optim.SGD(list(params.values()), lr=lr, weight_decay=wd, momentum=mom, nesterov=True)
+    se = np.array(['se_layer' in nm for nm in names])
+    for s in range(2):
+        if s:                                    # common state: the HIP path's weights, running statistics and momentum
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    sd[k].copy_(v.cpu().to(sd[k].dtype))
+                for k in names:
+                    lo, hi = step.flatp.span[id(hp[k])]
+                    opt.state[params[k]]['momentum_buffer'].copy_(step.opt.buf[lo:hi].view_as(hp[k]).cpu().double())
+        ops.ACT_TRACE = []
+        try:
+            out = step(rgb.cuda(), depth.cuda(), [t.cuda() for t in labels])
+        finally:
+            trace, ops.ACT_TRACE = ops.ACT_TRACE, None
+        opt.zero_grad()
+        with hip_relu_decisions(trace, tau=DECISION_BAND) as census:
+            outs, lf = O.forward(sd, rgb.double(), depth.double(), Hh.CFGS['P_se'], training=True, temp=temp)
+        assert census['outside_band'] == 0 and not any(census['queues'].values()), (s, census['outside_band'])
+        losses = O.cross_entropy_2d(outs, labels, torch.from_numpy(g['cw']).double())
+        total = sum(losses) + ratio * torch.clamp(lf - budget, min=0.0)
+        total.backward()
+        opt.step()
+        assert np.allclose(out['losses'].cpu().numpy(), [float(v.detach()) for v in losses], rtol=1e-4), (s, out['losses'], losses)
+        assert abs(out['total'].item() - total.item()) < 1e-4 * abs(total.item()), s
+        new_sd = m.state_dict()
+        ref = np.array([sd[k].detach().norm().item() for k in names])
+        got = np.array([new_sd[k].double().norm().item() for k in names])
+        rel = np.abs(got - ref) / np.maximum(ref, 1e-3)
+        full = max(((new_sd[k].double().cpu() - sd[k].detach()).norm() / sd[k].detach().norm().clamp_min(1e-3)).item() for k in names)
+        print(f'step {s} at equal decisions ({census["imposed"]} imposed): worst parameter-norm deviation {rel[~se].max():.2e} '
+              f'(SE layers {rel[se].max():.2e}); worst full-tensor relative L2 {full:.2e}')
+        bad = np.nonzero(rel >= 1e-3)[0]
+        assert bad.size == 0 and full < 2e-3, (s, full, [(names[i], got[i], ref[i], rel[i]) for i in bad[:8]])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_two_train_steps_match_reference(golden_dir, use_graph):
     from dynmm_amd import engine
@@ -263,7 +332,8 @@ def test_freeze_trains_only_the_gate():
             if ref_g.norm() > 1e-6:
                 assert not torch.equal(new[k].cpu(), v), k
                 cos = torch.nn.functional.cosine_similarity(upd, ref_g, dim=0).item()
-                assert cos > 0.98 and abs((upd.norm() / ref_g.norm()).item() - 1) < 0.15, (k, cos, upd.norm(), ref_g.norm())
+                print(f'gate gradient {k}: cosine {cos:.5f}, norm ratio {(upd.norm() / ref_g.norm()).item():.4f}')
+                assert cos > 0.995 and abs((upd.norm() / ref_g.norm()).item() - 1) < 0.05, (k, cos, upd.norm(), ref_g.norm())
         elif 'gate' not in k and v.dtype.is_floating_point and 'running_' not in k:
             assert torch.equal(new[k].cpu(), v), k                  # frozen: bit-identical
 

@@ -15,14 +15,17 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 2e-4        # eval-mode logits (fp32 oracle vs fp64 oracle differ by ~4e-5 themselves)
 TRAIN_OUT_TOL = 1e-3    # train-mode outputs incl. 3x4 side maps: batch-stat BN amplifies rounding; north_star bar
-# Whole-model fp32 gradients are ill-conditioned (see test_model_vs_oracle_*).  The bars are CALIBRATED: tests/golden/
-# grad_noise.npz (tests/golden/make_grad_noise.py) holds, per fixture, how far the fp32 CPU oracle itself moves between
-# summation orders (thread counts 1 / 8, oneDNN / native convolutions) — the worst deviation of a per-parameter gradient
-# norm and of a stored full gradient tensor from the reference's fp32 values.  HIP is held to that range x 1.25 (floor
-# 0.05: a 4-draw maximum under-estimates the range of the well-conditioned fixtures); fixtures without a row keep the
-# round-2 constants.
-GRAD_NORM_TOL = 0.2
-GRAD_FULL_TOL = 0.25
+# Whole-model fp32 gradients: two comparisons.
+#  (1) test_model_gradients_vs_fp64_oracle_at_equal_decisions — the parity gate proper: against the fp64 oracle with the HIP pass's
+#      ReLU / arg-max decisions imposed at its near-ties, every per-parameter gradient norm to EQUAL_DECISION_NORM_TOL = 0.02, every
+#      fixture and mode (train_hard included).
+#  (2) against the reference's own fp32 gradients in the fixtures (its decisions, its summation order): bars CALIBRATED in
+#      tests/golden/grad_noise.npz (tests/golden/make_grad_noise.py: how far the fp32 CPU oracle itself moves between thread
+#      counts, oneDNN / native and direct / Winograd-form convolutions — one run of a fixed draw list, no ratchet), x 1.25 with a
+#      floor of 0.05.  A fixture whose calibrated bar exceeds GOLDEN_GRAD_CAP = 0.10 (one flipped decision between correct fp32
+#      evaluations: P_se train_hard, R50_se) is NOT compared with the fixture's gradients — a bar that wide tests nothing —
+#      and must be covered by (1).
+GOLDEN_GRAD_CAP = 0.10
 NOISE_MARGIN = 1.25
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -36,9 +39,10 @@ def calibrated_tols(cfg, h, w, mode):
     tags = [str(t) for t in g['small_fixtures']]
     tag = f'{cfg} {h}x{w} {mode}'
     if tag not in tags:
-        return GRAD_NORM_TOL, GRAD_FULL_TOL
+        return None
     nrm, full = g['small'][tags.index(tag)]
-    return max(NOISE_MARGIN * float(nrm), 0.05), max(NOISE_MARGIN * float(full), 0.05)
+    tols = max(NOISE_MARGIN * float(nrm), 0.05), max(NOISE_MARGIN * float(full), 0.05)
+    return tols if max(tols) <= GOLDEN_GRAD_CAP else None
 
 
 def hip_model(cfg_name, h, w, seed=0):
@@ -97,15 +101,22 @@ def test_model_matches_reference_goldens(golden_dir, cfg, h, w):
             names = [str(s) for s in g[f'{mode}/grad_names']]
             norms = np.array([0.0 if params[nm].grad is None else params[nm].grad.norm().item() for nm in names])
             ref = g[f'{mode}/grad_norms']
-            norm_tol, full_tol = calibrated_tols(cfg, hh, ww, mode)
+            tols = calibrated_tols(cfg, hh, ww, mode)
             dev = np.abs(norms - ref) / np.maximum(ref, 1e-2 * ref.max())
-            print(f'{cfg} {hh}x{ww} {mode}: worst gradient-norm deviation {dev.max():.4f} (bar {norm_tol:.4f})')
-            bad = dev > norm_tol
-            assert not bad.any(), [(names[i], norms[i], ref[i]) for i in np.nonzero(bad)[0][:8]]
+            if tols is None:
+                # decisions differ between correct fp32 evaluations of this fixture: gradient parity is (1) above
+                assert (cfg, hh, ww, mode) in EQUAL_DECISION_CASES, (cfg, hh, ww, mode)
+                print(f'{cfg} {hh}x{ww} {mode}: gradient-norm deviation from the fixture {dev.max():.4f} (not a bar: see '
+                      'test_model_gradients_vs_fp64_oracle_at_equal_decisions)')
+            else:
+                norm_tol, full_tol = tols
+                print(f'{cfg} {hh}x{ww} {mode}: worst gradient-norm deviation {dev.max():.4f} (bar {norm_tol:.4f})')
+                bad = dev > norm_tol
+                assert not bad.any(), [(names[i], norms[i], ref[i]) for i in np.nonzero(bad)[0][:8]]
             sd = m.state_dict()
             for k in g.files:
-                if k.startswith(f'{mode}/grad:') and np.abs(g[k]).max() > 1e-6:   # skip analytically-zero grads
-                    assert Hh.rel_err(params[k.split('grad:')[1]].grad.cpu(), g[k]) < full_tol, k
+                if tols is not None and k.startswith(f'{mode}/grad:') and np.abs(g[k]).max() > 1e-6:   # skip analytically-zero grads
+                    assert Hh.rel_err(params[k.split('grad:')[1]].grad.cpu(), g[k]) < tols[1], k
                 if k.startswith(f'{mode}/rm:'):
                     assert Hh.rel_err(sd[k.split('rm:')[1] + '.running_mean'].cpu(), g[k]) < 1e-4, k
                 if k.startswith(f'{mode}/rv:'):
@@ -122,6 +133,107 @@ def test_model_matches_reference_goldens(golden_dir, cfg, h, w):
         assert Hh.rel_err(out[:, :, ::stride, ::stride], g[f'{mode}/strided']) < tol, mode
         assert Hh.rel_err(out.sum(dim=(2, 3)), g[f'{mode}/csum']) < 1e-3, mode
         assert Hh.rel_err(out.abs().sum(dim=(2, 3)), g[f'{mode}/cabs']) < 1e-3, mode
+
+
+class hip_gate_decisions:
+    """Run the oracle's DiffSoftmax (…globalgate.py:20-30) with the hard arg-max the HIP pass took wherever the oracle's own two
+    largest probabilities lie within `tau` of each other — the same construction as tests/test_hip_blocks.hip_relu_decisions for
+    the one other DECISION of the forward pass.  Away from such a near-tie the HIP decision must equal the oracle's (`outside`)."""
+
+    def __init__(self, hip_weight, tau=1e-5):
+        self.idx = None if hip_weight is None else hip_weight.argmax(1)
+        self.tau = tau
+        self.imposed = self.outside = self.calls = 0
+
+    def __enter__(self):
+        from oracle import dynmm_oracle as O
+        self.O, self.orig = O, O.diff_softmax
+
+        def diff_softmax(logits, tau=1.0, hard=False, dim=-1):
+            y_soft = (logits / tau).softmax(dim)
+            if not hard or self.idx is None:
+                return self.orig(logits, tau, hard, dim)
+            self.calls += 1
+            top = y_soft.detach().flatten(1).topk(2, dim=1).values
+            band = (top[:, 0] - top[:, 1]) <= self.tau
+            own = y_soft.detach().flatten(1).argmax(1)
+            dis = own != self.idx
+            self.imposed += int((dis & band).sum())
+            self.outside += int((dis & ~band).sum())
+            idx = torch.where(band, self.idx, own).view(-1, *([1] * (logits.dim() - 1)))
+            y_hard = torch.zeros_like(logits).scatter_(dim, idx, 1.0)
+            return y_hard - y_soft.detach() + y_soft
+        O.diff_softmax = diff_softmax
+        return self
+
+    def __exit__(self, *a):
+        self.O.diff_softmax = self.orig
+
+
+DECISION_BAND = TRAIN_OUT_TOL     # a pre-activation within the forward bar of zero is a legitimately open decision
+EQUAL_DECISION_NORM_TOL = 0.02      # per-parameter gradient norm, HIP fp32 vs the fp64 oracle at equal decisions
+EQUAL_DECISION_CASES = [('P_se', 96, 128, 'train_soft'), ('P_se', 96, 128, 'train_hard'), ('P_add', 96, 128, 'train_soft'),
+                        ('S_se', 96, 128, 'train_soft'), ('R50_se', 96, 128, 'train_soft'), ('R18_se', 96, 128, 'train_soft'),
+                        ('P_se', 160, 192, 'train_soft'), ('S_add', 96, 128, 'train_soft')]
+
+
+@pytest.mark.parametrize('cfg,h,w,mode', EQUAL_DECISION_CASES)
+def test_model_gradients_vs_fp64_oracle_at_equal_decisions(golden_dir, cfg, h, w, mode):
+    """Whole-model parameter gradients against the fp64 oracle with the DECISIONS of the HIP pass — every ReLU that conv2d /
+    batch_norm_act evaluate, and the hard gate's arg-max — imposed on the oracle where its own pre-activation (its two largest
+    gate probabilities) lies within DECISION_BAND of a tie, and REQUIRED to equal the oracle's everywhere else.  A gradient is a function
+    of the decisions taken in the forward pass; two correct fp32 evaluations of the same sums take different ones at
+    rounding-level pre-activations (one flipped ReLU / arg-max moves a single parameter's gradient norm of
+    these small fixtures by up to 0.37), so the fixtures' fp32 gradients — the reference's own decisions — are comparable only
+    up to that, while at EQUAL decisions the HIP gradients are held to 0.02 on every per-parameter norm (measured: <= 0.006), `train_hard` included.
+    Same inputs, weights, modes and loss as the reference fixtures (tests/golden/make_goldens.py)."""
+    from oracle import dynmm_oracle as O
+    from dynmm_amd import ops
+    from tests.test_hip_blocks import hip_relu_decisions
+    g = np.load(os.path.join(golden_dir, f'model_{cfg}_{h}x{w}.npz'))
+    hh, ww, n, _ = [int(v) for v in g['meta']]
+    rgb, depth = synth.synth_inputs(n, hh, ww, seed=1234)
+    m = hip_model(cfg, hh, ww)
+    set_mode(m, mode, n)
+    m.dual_stream = False                    # the oracle evaluates the RGB stage before the depth stage: same ReLU order
+    m.start_weight()
+    ops.ACT_TRACE = []
+    try:
+        outs, lf = m(rgb.cuda(), depth.cuda())
+    finally:
+        trace, ops.ACT_TRACE = ops.ACT_TRACE, None
+    hip_weight = m.weight_list.clone()
+    m.save_weight_info = False
+    Hh.train_loss(outs, lf).backward()
+    torch.cuda.synchronize()
+
+    sd = Hh.filled_state_dict(Hh.CFGS[cfg], seed=0)
+    sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+    kw = dict(Hh.MODE_KW[mode])
+    # band: the forward's own tolerance — pre-activations of the deep layers differ from fp64 by up to ~1e-4 of the tensor's
+    # maximum after ~100 layers with batch-statistic BatchNorms (TRAIN_OUT_TOL is 1e-3), against 1e-5 for a single block
+    with hip_relu_decisions(trace, tau=DECISION_BAND) as census, \
+            hip_gate_decisions(hip_weight if kw.get('hard_gate') else None, tau=DECISION_BAND) as gate:
+        outs64, lf64 = O.forward(sd, rgb.double(), depth.double(), Hh.CFGS[cfg], **kw)
+    assert census['outside_band'] == 0, f'{census["outside_band"]} ReLU decisions differ from the fp64 oracle away from zero'
+    assert not any(census['queues'].values()), 'traced HIP ReLU outputs the oracle never matched'
+    assert gate.outside == 0 and (gate.calls == 1) == bool(kw.get('hard_gate')), (gate.outside, gate.calls)
+    tot = 3.0 * lf64
+    for i, o in enumerate(outs64):
+        tot = tot + (o * Hh.grad_probe(tuple(o.shape), f's{i}').double()).mean()
+    tot.backward()
+    for a, b in zip(outs, outs64):
+        assert Hh.rel_err(a.detach().cpu(), b.detach()) < TRAIN_OUT_TOL
+    hp = dict(m.named_parameters())
+    names = [k for k in params if params[k].grad is not None]
+    ref = np.array([params[k].grad.norm().item() for k in names])
+    got = np.array([0.0 if hp[k].grad is None else hp[k].grad.double().norm().item() for k in names])
+    dev = np.abs(got - ref) / np.maximum(ref, 1e-2 * ref.max())
+    worst = int(dev.argmax())
+    print(f'{cfg} {hh}x{ww} {mode}: {census["imposed"]} ReLU + {gate.imposed} gate decisions imposed of {census["sites"]} traced '
+          f'activations; worst gradient-norm deviation {dev.max():.4f} ({names[worst]})')
+    assert dev.max() < EQUAL_DECISION_NORM_TOL, [(names[i], got[i], ref[i]) for i in np.argsort(-dev)[:8]]
 
 
 def _oracle_train_step(cfg, rgb, depth, dtype, seed, temp):
@@ -304,9 +416,13 @@ def test_edge_shapes_and_errors():
 
 @pytest.mark.parametrize('dual', [False, True])
 def test_all_parameter_gradients_are_run_to_run_reproducible(dual):
-    """No float atomics anywhere on the gradient path (conv slabs, SE / gate MLPs, depthwise upsample, bias
-    sums are all reduced in a fixed order): two runs of the same train step give bit-identical gradients for
-    EVERY parameter, single-stream and on the 3-stream schedule alike."""
+    """No fp32 atomics anywhere on the gradient path (conv slabs, SE / gate MLPs, depthwise upsample, bias sums are all reduced
+    in a fixed order): two runs of the same train step give bit-identical gradients for EVERY parameter, single-stream and on
+    the 3-stream schedule alike.  The one order-dependent accumulation is in FLOAT64: the per-channel BatchNorm sums that the
+    convolution epilogues add with fp64 atomics (csrc/conv_wino.hip STATS / BNRED; bn_stats / bn_bwd_reduce finish their sums the
+    same way).  Their order noise is ~1e-16 relative and is rounded away when mean / invstd / dgamma / dbeta are formed in fp32
+    (a change needs the fp64 value within 1e-16 of an fp32 rounding boundary: ~1e-9 per value) — bit-identical here, and at the
+    size where tiles number in the thousands in test_full_size_gradients_are_run_to_run_reproducible below."""
     from dynmm_amd import engine
     h, w, n = 96, 128, 4
     rgb, depth = synth.synth_inputs(n, h, w, seed=5, device='cuda')
@@ -327,6 +443,37 @@ def test_all_parameter_gradients_are_run_to_run_reproducible(dual):
     for other in grads[1:]:
         diff = [k for k in grads[0] if not torch.equal(grads[0][k], other[k])]
         assert not diff, diff[:8]
+
+
+def test_full_size_gradients_are_run_to_run_reproducible():
+    """BASELINE configs[2]'s own size — batch 32, 480x640, the 3-stream schedule, BatchNorm statistics and backward reductions
+    from the convolution epilogues (4800 pixel tiles per C = 64 launch adding fp64 atomics into 1-8 slabs): two runs of the same
+    train step from the same state.  fp64-atomic order is the ONE tolerated source of run-to-run difference on this path (see
+    above); it is bounded here: every parameter gradient within 1e-6 in relative L2 of the first run's — in practice
+    bit-identical, the count of tensors that are not is printed."""
+    from dynmm_amd import engine, ops
+    h, w, n = 480, 640, 32
+    rgb, depth = synth.synth_inputs(n, h, w, seed=5, device='cuda')
+    m = hip_model('P_se', h, w, seed=1)
+    m.train()
+    m.temp, m.dual_stream = 0.7, True
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    grads = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad.zero_()
+        with engine.direct_gradients(True):
+            outs, lf = m(rgb, depth)
+            Hh.train_loss(outs, lf).backward()
+            ops.join_async()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+        del outs, lf
+    diff = [k for k in grads[0] if not torch.equal(grads[0][k], grads[1][k])]
+    worst = max((_rl2(grads[1][k], grads[0][k]) for k in diff), default=0.0)
+    print(f'batch 32, 480x640: {len(diff)} of {len(grads[0])} gradient tensors not bit-identical between two runs (worst relative L2 {worst:.1e})')
+    assert worst < 1e-6, (len(diff), worst, diff[:8])
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -556,6 +556,100 @@ def test_conv_epilogue_batchnorm_statistics(ops, case):
         assert rel(b[i], a[i]) < 2e-4, i
 
 
+class _CallSpy:
+    """Count the calls of C-ABI entry points (the ctypes function objects of the loaded library are replaced by counting
+    wrappers for the duration of the block)."""
+
+    def __init__(self, lib, *names):
+        self.lib, self.names, self.count = lib, names, {n: 0 for n in names}
+
+    def __enter__(self):
+        self.orig = {n: getattr(self.lib, n) for n in self.names}
+        for n in self.names:
+            def wrapper(*a, _n=n):
+                self.count[_n] += 1
+                return self.orig[_n](*a)
+            setattr(self.lib, n, wrapper)
+        return self
+
+    def __exit__(self, *a):
+        for n in self.names:
+            setattr(self.lib, n, self.orig[n])
+
+
+@pytest.mark.parametrize('case,fits', [((3, 128, 15, 20, 128), True),        # odd H: the last row pair has one live row
+                                       ((2, 64, 24, 32, 128), True),
+                                       ((7, 64, 6, 12, 64), True),           # 252 pairs: a ragged last pixel tile
+                                       ((8, 64, 120, 160, 64), True),        # 1200 pixel tiles: the C = 64 stage at batch 8
+                                       ((17, 64, 120, 160, 64), False)])     # 2550 tiles > 2400: the rule sends it down the unfused path
+def test_batchnorm_backward_reductions_from_the_consumer_dgrad(ops, case, fits):
+    """relu(BN(c)) -> conv3x1 (resnet.py:127-135: bn1 -> conv3x1_2): with ops.BNLink the convolution's input-gradient launch
+    (dynmm_conv2d_wino_dgrad_bnred, csrc/conv_wino.hip BNRED) masks by [BN(c) > 0] from c itself and leaves the BatchNorm
+    backward's two reductions — fp64 atomics, one per channel, statistic and tile — so bn_bwd_reduce is not launched.  Checked
+    through the C ABI against float64 autograd: every gradient to GTOL, the two reductions (= dbeta, dgamma) to 1e-6 of their
+    absolute sums, fused == unfused; a spy asserts which path ran (the link consumed on the fused one), on both sides of the
+    2400-tile rule."""
+    import torch.nn as nn
+    N, Ci, H, W, Co = case
+    torch.manual_seed(N * 1000 + Ci + Co)
+    conv = nn.Conv2d(Ci, Co, (3, 1), padding=(1, 0)).cuda()
+    bn = nn.BatchNorm2d(Ci, eps=1e-3).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    c = rnd(N, Ci, H, W, seed=1)
+    gam, bet = bn.weight.detach().cpu().double(), bn.bias.detach().cpu().double()
+    for _ in range(4):                           # no BatchNorm output within 1e-4 of the ReLU's corner (decisions are not under test)
+        z0 = F.batch_norm(c.double(), None, None, gam, bet, True, 0.0, 1e-3)
+        near = z0.abs() < 1e-3
+        if not near.any():
+            break
+        c = c + near.float() * 0.02 * torch.where(z0 >= 0, 1.0, -1.0).float() / gam.float().view(1, -1, 1, 1)
+    assert F.batch_norm(c.double(), None, None, gam, bet, True, 0.0, 1e-3).abs().min() > 1e-4
+    gy = rnd(N, Co, H, W, seed=2)
+    # float64 truth
+    cr = c.double().requires_grad_(True)
+    gr, br, wr, bcr = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True), \
+        conv.weight.detach().cpu().double().requires_grad_(True), conv.bias.detach().cpu().double().requires_grad_(True)
+    zr = F.relu(F.batch_norm(cr, None, None, gr, br, True, 0.0, 1e-3))
+    zr.retain_grad()
+    F.conv2d(zr, wr, bcr, 1, (1, 0)).backward(gy.double())
+    g_masked = zr.grad * (zr.detach() > 0)
+    mu, var = c.double().mean((0, 2, 3), keepdim=True), c.double().var((0, 2, 3), unbiased=False, keepdim=True)
+    xhat = (c.double() - mu) / (var + 1e-3).sqrt()
+    abs1, abs2 = g_masked.abs().sum((0, 2, 3)), (g_masked * xhat).abs().sum((0, 2, 3))
+    lib = ops._lib()
+    old = ops.BN_BWD_FUSE
+
+    def run(fuse):
+        ops.BN_BWD_FUSE = fuse
+        bn.reset_running_stats()
+        for q in list(conv.parameters()) + list(bn.parameters()):
+            q.grad = None
+        ci = c.clone().cuda().requires_grad_(True)
+        bnl = ops.BNLink()
+        with _CallSpy(lib, 'dynmm_conv2d_wino_dgrad_bnred', 'dynmm_bn_bwd_reduce') as spy:
+            z = ops.batch_norm_act(ci, bn, 'relu', bwd_link=bnl)
+            y = ops.conv2d(z, conv.weight, conv.bias, 1, (1, 0), None, bn_link=bnl)
+            y.backward(gy.cuda())
+            torch.cuda.synchronize()
+        assert bnl.sums is None and bnl.x is None            # consumed (or never filled) — nothing dangling on the link
+        return (ci.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()), dict(spy.count)
+    try:
+        (a, ca), (b, cb) = run(False), run(True)
+    finally:
+        ops.BN_BWD_FUSE = old
+    assert ca == {'dynmm_conv2d_wino_dgrad_bnred': 0, 'dynmm_bn_bwd_reduce': 1}, ca
+    assert cb == ({'dynmm_conv2d_wino_dgrad_bnred': 1, 'dynmm_bn_bwd_reduce': 0} if fits else ca), (cb, fits)
+    for got in (a, b):
+        for t, ref in zip(got, (cr.grad, gr.grad, br.grad, wr.grad, bcr.grad)):
+            assert rel(t, ref) < GTOL
+        assert ((got[2].cpu().double() - br.grad).abs() / abs1).max() < 1e-6         # sum g.[z > 0]
+        assert ((got[1].cpu().double() - gr.grad).abs() / abs2).max() < 1e-6         # sum g.[z > 0].xhat
+    for t, u in zip(a, b):
+        assert rel(u, t) < 2e-5
+
+
 @pytest.mark.parametrize('case', [(3, 64, 16, 24, 128, (3, 1), (2, 1), (1, 0)), (3, 128, 16, 24, 128, (1, 3), (1, 2), (0, 1)),
                                   (2, 128, 30, 40, 256, (3, 1), (2, 1), (1, 0)), (4, 64, 9, 16, 40, (1, 3), (1, 2), (0, 1))])
 def test_conv2d_stride2_input_gradient_on_the_pair_kernel(ops, case):

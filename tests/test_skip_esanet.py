@@ -215,7 +215,8 @@ def test_skip_model_matches_reference_goldens(golden_dir):
             norms = np.array([0.0 if pr[nm].grad is None else pr[nm].grad.norm().item() for nm in names])
             ref = g[f'{mode}/grad_norms']
             big = ref > 1e-3 * ref.max()
-            assert np.max(np.abs(norms - ref)[big] / ref[big]) < 0.2       # see test_hip_model: fp32 conditioning
+            print(f'skip {mode}: worst gradient-norm deviation from the fixture {np.max(np.abs(norms - ref)[big] / ref[big]):.4f}')
+            assert np.max(np.abs(norms - ref)[big] / ref[big]) < 0.05      # (measured 0.005; fp32 conditioning: see test_hip_model)
             assert np.all((ref == 0) == (norms == 0))                         # unused params get no gradient
         else:
             with torch.no_grad():
