@@ -1168,7 +1168,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
         p.tco = wgrad_v6_tco(g);
         p.tk = 192;
         p.n_co_tiles = g->Co / p.tco;
-        p.n_k_tiles = g->Ci / 64;
+        p.n_k_tiles = (g->KH == 3 && g->KW == 3 ? 3 : 1) * (g->Ci / 64);       // 3x3: one vertical tap per workgroup
         p.target = target6 ? target6 : 256 * wgrad_v6_occupancy(g);
         plan_splits(p, g, 1);
         return p;

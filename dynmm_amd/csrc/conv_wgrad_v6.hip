@@ -39,9 +39,14 @@ using ic = std::integral_constant<int, I>;
 // summed over the pairs: 16 instead of 24 MFMAs per wave, step and 32-row block (2/3 of the matrix work), same loads, same
 // slabs (the output transform runs on the accumulators, the halvings are exact), error vs fp64 of the class of the direct
 // fp32 sum.  Both operand transforms are one add per MFMA operand in registers.
-template <int MCO, bool VT, int NST, int OCC, bool WINO = false>
+// K33 (round 5): a 3x3 filter (BasicBlock, resnet.py:66-84; the decoder's conv3x3, model.py:343-357) is three 1x3 filters on
+// input rows shifted by -1 / 0 / +1: one workgroup owns ONE vertical tap of its 64 input channels (k-tiles = 3 x Ci / 64), stages
+// the X rows `dr` image rows away (a quad whose row leaves the image reads the zero quad instead — the vertical padding) and
+// writes taps 3 (dr + 1) .. 3 (dr + 1) + 2 of the slab.  Same Winograd pairs, same loads, same slabs as the 1x3 launch.
+template <int MCO, bool VT, int NST, int OCC, bool WINO = false, bool K33 = false>
 __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs a_in, const WgradGroup grp) {
     static_assert(!(WINO && VT), "the Winograd form is implemented for the horizontal taps");
+    static_assert(!K33 || (WINO && !VT), "3x3 filters take the horizontal Winograd form per vertical tap");
     constexpr int NACC = WINO ? 4 : 3;
     WgradArgs a = a_in;
     constexpr int TCO = 64 * MCO, BP = 16;
@@ -78,7 +83,9 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     }
     const int tile = lin % n_tiles;
     const int co0 = (tile % a.n_co_tiles) * TCO;
-    const int ci0 = (tile / a.n_co_tiles) * 64;
+    const int ktile = tile / a.n_co_tiles;
+    const int ci0 = (K33 ? ktile % (a.Ci / 64) : ktile) * 64;
+    const int dr = K33 ? ktile / (a.Ci / 64) - 1 : 0;          // 3x3: this workgroup's vertical tap reads rows h + dr
     const int split = lin / n_tiles;
     const int HW = a.H * a.W, W = a.W, H = a.H, M = a.M;
 
@@ -113,7 +120,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
         h_m = step_begin * BP + 4 * ((q7 < 6 ? q7 : 5) - 1);
         const int n = h_m < 0 ? -1 : h_m / HW;
         h_rem = h_m - n * HW;
-        h_xoff = (unsigned)(((n * a.Ci + ci0 + wave * 16 + r7) * HW + h_rem) * 4);
+        h_xoff = (unsigned)(((n * a.Ci + ci0 + wave * 16 + r7) * HW + h_rem + dr * W) * 4);
     }
     const unsigned lds_g = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Gs);
     const unsigned lds_x = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Xs);
@@ -145,7 +152,8 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
                 }
             }
         } else {
-            const unsigned v = (h_m >= 0 && h_m < M) ? h_xoff : 0u;
+            // (3x3: a quad whose shifted row leaves the image is never used — any mapped address)
+            const unsigned v = (h_m >= 0 && h_m < M && (!K33 || (unsigned)(h_rem + dr * W) < (unsigned)HW)) ? h_xoff : 0u;
             const unsigned dst = lds_x + (unsigned)((slot * X_STAGE + wave * 16 * LDX) * 4);
 #pragma unroll
             for (int i = 0; i < NJX1; ++i) {
@@ -231,9 +239,16 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
             }
         } else {
             // bx[i] = pixel 8*khalf + i - 4 of the step (row position 8*khalf + i), i < 16
+            // (3x3: quads 0, 1 lie in the first quad's image row wherever their values are used, quads 2, 3 in the second's)
+            bool okA = true, okB = true;
+            if constexpr (K33) {
+                okA = (unsigned)(r_oh + dr) < (unsigned)H;
+                okB = (unsigned)(oh1 + dr) < (unsigned)H;
+            }
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const float4 u = *reinterpret_cast<const float4*>(xs + rd_x + 4 * qd);
+                const float* px = (qd < 2 ? okA : okB) ? xs + rd_x + 4 * qd : Zs;
+                const float4 u = *reinterpret_cast<const float4*>(px);
                 bx[S][4 * qd] = u.x; bx[S][4 * qd + 1] = u.y; bx[S][4 * qd + 2] = u.z; bx[S][4 * qd + 3] = u.w;
             }
             // left neighbours of the quads' first pixels / right neighbours of their last pixels: zero at the row ends
@@ -333,12 +348,13 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     }
 
     if (do_bias && t < TCO) a.out_bias[(size_t)split * a.Co + co0 + t] = bsum;
-    const int KHKW = 3;
+    const int KHKW = K33 ? 9 : 3;
     float* out = a.out + (size_t)split * a.Co * a.K;
     const int ci = ci0 + wave_k * 32 + l31;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const size_t col = a.k_major_out ? (size_t)(s * a.Ci + ci) : (size_t)ci * KHKW + s;
+        const int tap = K33 ? 3 * (dr + 1) + s : s;
+        const size_t col = a.k_major_out ? (size_t)tap * a.Ci + ci : (size_t)ci * KHKW + tap;
         const size_t rowlen = a.k_major_out ? (size_t)a.K : (size_t)a.Ci * KHKW;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi)
@@ -368,7 +384,9 @@ bool wgrad_v6_shape_ok(const dynmm_conv_geom* g) {
     if (off) return false;
     const bool h_taps = g->KH == 1 && g->KW == 3 && g->PH == 0 && g->PW == 1;
     const bool v_taps = g->KH == 3 && g->KW == 1 && g->PH == 1 && g->PW == 0;
-    if (!h_taps && !v_taps) return false;
+    static const int wino33 = env_int_v6("DYNMM_WGRAD_WINO", 1);
+    const bool k33 = wino33 && g->KH == 3 && g->KW == 3 && g->PH == 1 && g->PW == 1 && g->H >= 2;     // (the Winograd form only)
+    if (!h_taps && !v_taps && !k33) return false;
     if (g->SH != 1 || g->SW != 1 || g->H != g->Ho || g->W != g->Wo || g->c_split != g->Ci) return false;
     if (g->W % 4 != 0 || g->W < 16 || g->Ci % 64 != 0 || g->Co % 64 != 0) return false;
     static const int min_co = env_int_v6("DYNMM_WGRAD_V6_MIN_CO", 64);
@@ -386,7 +404,7 @@ int wgrad_v6_tco(const dynmm_conv_geom* g) { return g->Co % 128 == 0 ? 128 : 64;
 // and two fragment sets (2 waves per SIMD), 64-row tiles half of that (3).
 int wgrad_v6_occupancy(const dynmm_conv_geom* g) {
     static const int occ_env = env_int_v6("DYNMM_WGRAD_V6_OCC", 0);
-    if (g->KH == 3) return 2;
+    if (g->KH == 3 && g->KW == 1) return 2;
     static const int wino = env_int_v6("DYNMM_WGRAD_WINO", 1);
     if (wino) return g->Co % 128 == 0 ? 2 : 3;
     if (occ_env == 2 || occ_env == 3) return occ_env;
@@ -397,7 +415,12 @@ bool wgrad_wino_vt_on(const dynmm_conv_geom* g);
 void launch_wgrad_wino_vt(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t st);
 
 void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int occ, hipStream_t st) {
-    const bool vt = a.KH == 3;
+    const bool vt = a.KH == 3 && a.KW == 1;
+    if (a.KH == 3 && a.KW == 3) {                   // one vertical tap per workgroup, horizontal Winograd pairs
+        if (a.Co % 128 == 0) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, false, 3, 2, true, true>), grid, dim3(256), 0, st, a, grp);
+        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, false, 3, 3, true, true>), grid, dim3(256), 0, st, a, grp);
+        return;
+    }
     {
         dynmm_conv_geom g{};
         g.KH = a.KH; g.KW = a.KW;

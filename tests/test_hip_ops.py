@@ -72,6 +72,10 @@ CONV_CASES = [
     (5, 64, 17, 20, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),       # vertical taps, 64-row tile, M = 1700, odd H
     (2, 128, 9, 16, 256, (3, 1), (1, 1), (1, 0), True, None),        # narrowest rows (one step = one row), 2 co tiles x 2 ci tiles
     (1, 192, 8, 24, 64, (1, 3), (1, 1), (0, 1), False, None),        # 3 ci tiles, no bias, a step straddles rows
+    # ... 3x3 filters on the same kernel, one vertical tap per workgroup (round 5: BasicBlock / decoder conv3x3 weight gradients)
+    (3, 64, 17, 20, 64, (3, 3), (1, 1), (1, 1), True, None),         # 64-row tile, odd H, M = 1020: steps straddle rows AND images
+    (2, 128, 9, 16, 256, (3, 3), (1, 1), (1, 1), True, 'relu'),      # narrowest rows: every step is one image row, 2 x 2 x 3 k-tiles
+    (1, 64, 2, 32, 128, (3, 3), (1, 1), (1, 1), False, None),        # H = 2: the outer taps see one live row each
 ]
 
 
@@ -913,7 +917,8 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
                                   (4, 64, 24, 32, 64, (1, 3), (0, 1), True),        # three-tap kernel, 64-row tile
                                   (3, 128, 15, 20, 256, (1, 3), (0, 1), True),      # ... horizontal taps, M = 900 (ragged)
                                   (2, 128, 12, 16, 128, (1, 1), (0, 0), True),      # vectorised 128x128 kernel
-                                  (4, 128, 24, 32, 128, (3, 3), (1, 1), False)])
+                                  (4, 128, 24, 32, 128, (3, 3), (1, 1), False),       # 3x3 on the three-tap kernel (tap rows as k-tiles)
+                                  (3, 64, 15, 20, 64, (3, 3), (1, 1), True)])          # ... 64-row tile, bias, ragged M = 900
 def test_grouped_weight_gradients(ops, case):
     """dynmm_conv2d_wgrad_group through the C ABI: 3 same-geometry convolutions in one launch against fp64 torch (and
     the bias gradients that ride along), bit-identical between two calls, and the n = 1 / not-groupable fallbacks."""
@@ -935,6 +940,8 @@ def test_grouped_weight_gradients(ops, case):
         ref_w.append(wd.grad)
         ref_b.append(dy.double().cpu().sum((0, 2, 3)))
     assert lib.dynmm_conv2d_wgrad_groupable(C.byref(g)) in (1, 2)
+    if k != (1, 1) and Ci % 64 == 0 and Co % 64 == 0 and W % 4 == 0 and W >= 16:
+        assert lib.dynmm_conv2d_wgrad_variant(C.byref(g)) == 6          # conv_wgrad_v6.hip (Winograd pairs), 3x3 included
 
     def run(n):
         dws = [torch.empty(Co, Ci, *k, device='cuda') for _ in range(n)]
