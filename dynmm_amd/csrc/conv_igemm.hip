@@ -1475,7 +1475,10 @@ extern "C" size_t dynmm_conv2d_wgrad_workspace_bytes(const dynmm_conv_geom* g) {
     const size_t stem = stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split < g->Ci, false)
                             ? stem_conv_wgrad_workspace_bytes(g->N, g->Ci, g->Ho, g->Wo) : 0;
     const size_t gen = generic_wgrad_workspace_bytes(g);
-    return stem > gen ? stem : gen;
+    const size_t co8 = co8_wgrad_eligible(g->Ci, g->Co, g->H, g->W, g->Ho, g->Wo, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split)
+                           ? co8_wgrad_workspace_bytes(g->N, g->Ci, g->Co) : 0;
+    const size_t m = stem > gen ? stem : gen;
+    return co8 > m ? co8 : m;
 }
 
 static size_t plan_workspace_bytes(const dynmm_conv_geom* g, const WgradPlan& p) {
@@ -1504,6 +1507,14 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
         return launch_stem_conv_wgrad(x, dy, dw, (float*)workspace, g->N, g->Ci, g->H, g->W, g->Ho, g->Wo, (hipStream_t)stream);
     }
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15u) == 0;
+    if (co8_wgrad_eligible(g->Ci, g->Co, g->H, g->W, g->Ho, g->Wo, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split) &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2)) & 15u) == 0) {
+        // the gate head's first convolution: direct vector-ALU kernel (conv_small.hip), weight and bias gradient in one launch
+        const size_t need_c = co8_wgrad_workspace_bytes(g->N, g->Ci, g->Co);
+        if (!workspace || workspace_bytes < need_c || (reinterpret_cast<uintptr_t>(workspace) & 15u)) return DYNMM_EWORKSPACE;
+        return launch_co8_wgrad(x, x2, dy, dw, dbias, (float*)workspace, g->N, g->Ci, g->H, g->W, g->Co, g->Ho, g->Wo,
+                                g->c_split, (hipStream_t)stream);
+    }
     const WgradPlan p = plan_wgrad(g, aligned16 && !x2);
     const size_t need = generic_wgrad_workspace_bytes(g);
     if (need > 0 && (!workspace || workspace_bytes < need)) return DYNMM_EWORKSPACE;
@@ -1590,6 +1601,7 @@ extern "C" int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g) {
     static const int off = env_int("DYNMM_NO_WGRAD_GROUP");
     if (off || !geom_ok(g) || g->c_split != g->Ci) return 0;
     if (stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, false, false)) return 0;
+    if (co8_wgrad_eligible(g->Ci, g->Co, g->H, g->W, g->Ho, g->Wo, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split)) return 0;
     const WgradPlan p = plan_wgrad(g);
     if (p.splits <= 1) return 0;
     static const int no_generic = env_int("DYNMM_NO_WGRAD_GROUP_GENERIC");
@@ -1599,6 +1611,7 @@ extern "C" int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g) {
 extern "C" int dynmm_conv2d_wgrad_variant(const dynmm_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split < g->Ci, false)) return 0;
+    if (co8_wgrad_eligible(g->Ci, g->Co, g->H, g->W, g->Ho, g->Wo, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split)) return 8;
     const WgradPlan p = plan_wgrad(g);
     if (p.v6) return 6;
     return wgrad_v4_shape_ok(g, p) ? 4 : 0;

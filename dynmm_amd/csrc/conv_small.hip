@@ -13,6 +13,7 @@
 // loader (it ran at 42 TFLOP/s through the element-wise generic path).
 #include "common.h"
 #include "conv_small.h"
+#include "conv_igemm.h"
 #include <cstring>
 
 namespace dynmm {
@@ -145,6 +146,220 @@ __global__ void __launch_bounds__(256) conv_co8_fwd_kernel(const SmallConvArgs a
             a.y[(((size_t)n * a.Co + co) * a.Ho + oh) * a.Wo + ow] = small_act(v, a.act);
         }
     }
+}
+
+// ---- gate conv weight gradient (round 5) ------------------------------------------------------------------------------
+// dW[co][ci][kh][kw] = sum over (n, oh, ow) of dy[n][co][oh][ow] * x[n][ci][2 oh + kh][2 ow + kw]   (…globalgate.py:378-386,
+// the 128 -> 8 channel 5x5 stride-2 convolution of the gate head on the 120x160 stage-1 maps of BOTH encoders).  With 8 output
+// channels the implicit-GEMM tile is 3/4 padding (10.8 TFLOP/s, 0.69 ms per step); the same observation as for the forward
+// above: on the vector ALUs nothing is padded.
+//   A workgroup owns G input channels x NI images and ALL 25 x 8 weights of those channels.  A lane keeps the 200
+//   accumulators of one channel (acc[kh][kw][co]) for its 5 consecutive output pixels of one output row; the four waves
+//   cover 16 output rows per pass.  Per (image, pass): the 35 input rows the pass touches are ONE contiguous piece of the
+//   channel's plane — staged by `global_load_lds_dwordx4` into a double-buffered LDS tile (the next piece is in flight under
+//   this one's arithmetic); the lane's 8 x 5 dy values come straight from L2 (dy is 4.6 MB in all).  1000 FMAs per lane per
+//   staged piece against 65 LDS reads.  After the channel's last piece: 16-lane sums by DPP, the 16 row sums of the workgroup
+//   through LDS in a fixed order, one slab row per image group; the slabs (and the bias-gradient slabs of the first channel
+//   group's workgroups) are summed by the library's ordered slab reduction — bit-reproducible like every other weight gradient.
+struct Co8WgradArgs {
+    const float* x;
+    const float* x2;
+    const float* dy;
+    float* slabs;          // [image groups][Co * Ci * 25]
+    float* bias_slabs;     // [image groups][Co] or nullptr
+    int N, Ci, H, W, Co, Ho, Wo, c_split, NI, G;
+};
+
+__device__ __forceinline__ float row16_sum(float v) {            // sum over the lane's row of 16 lanes, in every lane of it
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
+
+template <int KS, int S>
+__global__ void __launch_bounds__(256, 1) conv_co8_wgrad_kernel(const Co8WgradArgs a) {
+    constexpr int PR = 16;                             // output rows per pass (4 waves x 4 lane rows)
+    constexpr int IR = (PR - 1) * S + KS;              // input rows a pass touches (35)
+    constexpr int XW = (kSP - 1) * S + KS;             // input columns a lane touches per row (13)
+    constexpr int NACC = KS * KS * 8;
+    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+    const int tile_floats = IR * a.W + 16;             // (+ slack: the last lanes' windows run a few floats past the piece)
+    float* const tiles = dyn_lds;                      // [2][tile_floats]
+    float* const red = dyn_lds + 2 * tile_floats;      // [16 lane rows of the workgroup][NACC + 8]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cg = lane & 15, rl = lane >> 4;
+    const int n_cgroups = a.Ci / a.G;
+    const int cgrp = (int)blockIdx.x % n_cgroups, igrp = (int)blockIdx.x / n_cgroups;
+    const int n0 = igrp * a.NI, n1 = min(a.N, n0 + a.NI);
+    const int passes = (a.Ho + PR - 1) / PR;
+    const int HW = a.H * a.W;
+    const unsigned lds_t = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)tiles);
+
+    auto plane = [&](int n, int ci) -> const float* {
+        return ci < a.c_split ? a.x + ((size_t)n * a.c_split + ci) * HW
+                              : a.x2 + ((size_t)n * (a.Ci - a.c_split) + (ci - a.c_split)) * HW;
+    };
+    // piece q = ((ci_local * (n1 - n0)) + n_local) * passes + pass of this workgroup's sequence
+    const int per_ci = (n1 - n0) * passes;
+    const int total = a.G * per_ci;
+    auto request = [&](int q) {                         // DMA of piece q into tile q & 1: 16 bytes per lane and instruction
+        const int cl = q / per_ci, rem = q - cl * per_ci;
+        const int nl = rem / passes, ps = rem - nl * passes;
+        const int row0 = ps * PR * S;
+        const int rows = min(IR, a.H - row0);
+        const int quads = rows * a.W / 4;
+        const float* src = plane(n0 + nl, cgrp * a.G + cl) + (size_t)row0 * a.W;
+        const unsigned dst = lds_t + (unsigned)((q & 1) * tile_floats * 4);
+        for (int base = wave * 64; base < quads; base += 256) {
+            const int qd = base + lane;
+            if (qd < quads) dma16(src + (size_t)base * 4, (unsigned)lane * 16u, dst + (unsigned)base * 16u);
+        }
+    };
+
+    float acc[KS][KS][8];
+    float bacc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) bacc[co] = 0.f;
+    const bool do_bias = a.bias_slabs != nullptr && cgrp == 0;
+
+    // Lanes without a live output pixel (rows past Ho in the last pass, the column group past Wo) read tile positions no piece
+    // of this pass wrote, against dy = 0: the tiles start as zeros, so such a position holds zeros or an earlier piece's finite
+    // values — never an uninitialised bit pattern that could be a NaN.
+    for (int i = t; i < 2 * tile_floats; i += 256) tiles[i] = 0.f;
+    __syncthreads();
+    request(0);
+    for (int q = 0; q < total; ++q) {
+        const int cl = q / per_ci, rem = q - cl * per_ci;
+        const int nl = rem / passes, ps = rem - nl * passes;
+        if (rem == 0) {
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) acc[kh][kw][co] = 0.f;
+        }
+        // this lane's dy values of the pass (zero outside the output map / past Co)
+        const int orow = ps * PR + wave * 4 + rl;
+        float dyv[8][kSP];
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+#pragma unroll
+            for (int p = 0; p < kSP; ++p) {
+                const int ow = cg * kSP + p;
+                const bool ok = co < a.Co && orow < a.Ho && ow < a.Wo;
+                dyv[co][p] = ok ? a.dy[(((size_t)(n0 + nl) * a.Co + co) * a.Ho + orow) * a.Wo + ow] : 0.f;
+            }
+        // every wave is done with the other tile (read during piece q - 1); this wave's requests for piece q have landed
+        wait_vm<0>();                                   // (the dy loads above as well: they are consumed right away)
+        __syncthreads();
+        if (q + 1 < total) request(q + 1);
+        const float* tile = tiles + (q & 1) * tile_floats;
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+            const float* row = tile + (S * (wave * 4 + rl) + kh) * a.W + S * kSP * cg;
+            float xv[XW];
+#pragma unroll
+            for (int j = 0; j < XW; ++j) xv[j] = row[j];
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+#pragma unroll
+                    for (int p = 0; p < kSP; ++p) acc[kh][kw][co] = fmaf(dyv[co][p], xv[S * p + kw], acc[kh][kw][co]);
+        }
+        if (do_bias && cl == 0) {
+#pragma unroll
+            for (int co = 0; co < 8; ++co) bacc[co] += ((dyv[co][0] + dyv[co][1]) + (dyv[co][2] + dyv[co][3])) + dyv[co][4];
+        }
+        if (rem == per_ci - 1) {                        // the channel is complete: reduce its 200 sums over the workgroup
+            __syncthreads();                            // (red is read by the previous channel's writers until here)
+            float* dst = red + (wave * 4 + rl) * (NACC + 8);
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) {
+                        const float sres = row16_sum(acc[kh][kw][co]);
+                        if (cg == 0) dst[(co * KS + kh) * KS + kw] = sres;
+                    }
+            const bool last_bias = do_bias && cl == 0;
+            if (last_bias) {
+#pragma unroll
+                for (int co = 0; co < 8; ++co) {
+                    const float sres = row16_sum(bacc[co]);
+                    if (cg == 0) dst[NACC + co] = sres;
+                }
+            }
+            __syncthreads();
+            const int ci = cgrp * a.G + cl;
+            if (t < NACC + (last_bias ? 8 : 0)) {
+                float v = 0.f;
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) v += red[r16 * (NACC + 8) + t];
+                if (t < NACC) {
+                    const int co = t / (KS * KS), tap = t - co * (KS * KS);
+                    if (co < a.Co) a.slabs[(size_t)igrp * a.Co * a.Ci * (KS * KS) + ((size_t)co * a.Ci + ci) * (KS * KS) + tap] = v;
+                } else if (t - NACC < a.Co) {
+                    a.bias_slabs[(size_t)igrp * a.Co + (t - NACC)] = v;
+                }
+            }
+        }
+    }
+}
+
+static void co8_wgrad_plan(int N, int Ci, int* NI, int* G) {
+    *G = 4;                                            // channels per workgroup
+    int ni = (int)(((long)N * (Ci / 4)) / 256);        // one workgroup per CU (200 accumulators per lane): ~256 workgroups
+    *NI = ni < 1 ? 1 : (ni > 8 ? 8 : ni);
+}
+
+bool co8_wgrad_eligible(int Ci, int Co, int H, int W, int Ho, int Wo, int KH, int KW, int SH, int SW, int PH, int PW, int c_split) {
+    static const bool off = small_off_early("gatew");
+    if (off) return false;
+    if (KH != 5 || KW != 5 || SH != 2 || SW != 2 || PH != 0 || PW != 0) return false;
+    if (Co < 1 || Co > 8 || Ci < 16 || Ci % 4 != 0 || W % 4 != 0) return false;
+    if (c_split != Ci && c_split % 4 != 0) return false;               // a channel group never straddles the two inputs
+    if (Wo > kSCols || Ho < 1) return false;                           // one column group set covers the output row
+    return (size_t)(2 * (35 * W + 16) + 16 * 208) * sizeof(float) <= 160 * 1024;
+}
+
+size_t co8_wgrad_workspace_bytes(int N, int Ci, int Co) {
+    int NI, G;
+    co8_wgrad_plan(N, Ci, &NI, &G);
+    const size_t groups = (size_t)ceil_div(N, NI);
+    return sizeof(float) * (((groups * Co * Ci * 25 + 3) & ~(size_t)3) + groups * Co);
+}
+
+int launch_co8_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias, float* workspace, int N, int Ci,
+                     int H, int W, int Co, int Ho, int Wo, int c_split, hipStream_t st) {
+    Co8WgradArgs a{};
+    co8_wgrad_plan(N, Ci, &a.NI, &a.G);
+    const int groups = ceil_div(N, a.NI);
+    const size_t wfloats = ((size_t)groups * Co * Ci * 25 + 3) & ~(size_t)3;
+    a.x = x; a.x2 = x2; a.dy = dy;
+    a.slabs = groups > 1 ? workspace : dw;
+    a.bias_slabs = dbias ? (groups > 1 ? workspace + wfloats : dbias) : nullptr;
+    a.N = N; a.Ci = Ci; a.H = H; a.W = W; a.Co = Co; a.Ho = Ho; a.Wo = Wo; a.c_split = c_split;
+    const size_t lds = (size_t)(2 * (35 * W + 16) + 16 * 208) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DYNMM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_co8_wgrad_kernel<5, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_co8_wgrad_kernel<5, 2>), dim3((unsigned)(groups * (Ci / a.G))), dim3(256), lds, st, a);
+    DYNMM_LAUNCH_CHECK();
+    if (groups > 1)
+        launch_reduce_slabs(workspace, dw, Co * Ci * 25, groups, st, dbias ? workspace + wfloats : nullptr, dbias, dbias ? Co : 0);
+    DYNMM_LAUNCH_CHECK();
+    return DYNMM_OK;
 }
 
 // ---- stem: 1 or 3 input channels, 64 output channels, 7x7 stride 2 pad 3 — fp32 MFMA from an LDS patch ---------

@@ -332,6 +332,8 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
             name = f'conv_wgrad_v6<co{128 if g.Co % 128 == 0 else 64},{g.KH}x{g.KW}>'
         elif variant == 4:
             name = 'conv_wgrad_v4<co128>'                   # the vectorised 128x128 kernel (conv_igemm.hip: wgrad_v4_shape_ok)
+        elif variant == 8:
+            name = 'conv_co8_wgrad<direct,valu>'            # conv_small.hip: the gate conv's weight + bias gradient
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
     if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction

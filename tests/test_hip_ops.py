@@ -190,6 +190,46 @@ def test_conv2d_dual_input(ops):
         assert rel(got, ref) < GTOL
 
 
+@pytest.mark.parametrize('case', [(2, 128, 64, 24, 32, 8, True),        # the gate conv's own geometry class: rgb + depth, bias
+                                  (3, 32, 32, 21, 40, 6, True),         # single input, Co = 6, odd H, Wo = 18
+                                  (17, 128, 64, 13, 16, 8, False),      # 17 images: image groups of 2 (ragged last group), no bias
+                                  (2, 64, 32, 75, 164, 8, True)])       # Wo = 80: the last column group is full; 3 passes of rows
+def test_gate_conv_weight_gradient_on_the_vector_alus(ops, case):
+    """dynmm_conv2d_wgrad for the gate head's first convolution (…globalgate.py:378-386: 5x5, stride 2, <= 8 output channels, the
+    rgb | depth pair as two inputs): csrc/conv_small.hip conv_co8_wgrad_kernel — weight AND bias gradient in one launch, vs
+    float64, bit-identical between two calls, and the library reports the variant."""
+    import ctypes as C
+    from dynmm_amd import lib as L
+    lib = L.load()
+    N, Ci, split, H, W, Co, bias = case
+    st = torch.cuda.current_stream().cuda_stream
+    x = rnd(N, Ci, H, W, seed=1)
+    w0 = torch.empty(Co, Ci, 5, 5)
+    xa, xb = (x[:, :split].contiguous().cuda(), x[:, split:].contiguous().cuda()) if split < Ci else (x.cuda(), None)
+    g = ops._geom(xa, xb, w0, (2, 2), (0, 0))
+    assert lib.dynmm_conv2d_wgrad_variant(C.byref(g)) == 8
+    dy = rnd(N, Co, g.Ho, g.Wo, seed=2)
+    wd = torch.zeros(Co, Ci, 5, 5, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wd, None, 2).backward(dy.double())
+    dyc = dy.cuda()
+
+    def run():
+        dw = torch.full((Co, Ci, 5, 5), float('nan'), device='cuda')
+        db = torch.full((Co,), float('nan'), device='cuda') if bias else None
+        nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
+        ws = torch.empty(max(nbytes // 4, 1), device='cuda')
+        L.check(lib.dynmm_conv2d_wgrad(xa.data_ptr(), None if xb is None else xb.data_ptr(), dyc.data_ptr(), dw.data_ptr(),
+                                       None if db is None else db.data_ptr(), ws.data_ptr(), nbytes, C.byref(g), st), 'wgrad')
+        torch.cuda.synchronize()
+        return dw, db
+    dw, db = run()
+    assert rel(dw, wd.grad) < GTOL
+    if bias:
+        assert rel(db, dy.double().sum((0, 2, 3))) < GTOL
+    dw2, db2 = run()
+    assert torch.equal(dw, dw2) and (not bias or torch.equal(db, db2))
+
+
 @pytest.mark.parametrize('act', [None, 'relu'])
 @pytest.mark.parametrize('with_res', [False, True])
 def test_conv_fused_eval(ops, act, with_res):
