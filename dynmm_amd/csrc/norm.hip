@@ -7,6 +7,14 @@
 
 namespace dynmm {
 
+// ReLU decisions of a BatchNorm + residual + ReLU (resnet.py:136-147: bn2 + identity) as ONE BIT per element, written by the
+// forward's normalise pass and read by the two backward passes in place of the output tensor (4 bytes per element, twice).
+// Layout: the V = 4 kernels walk a plane in wave groups of 256 consecutive elements (lane l: elements 4 l .. 4 l + 3); group k
+// of plane p owns words [(p * groups + k) * 4, + 4): word j = the wave's ballot of "element 4 l + j is positive".  A bit is
+// addressed by (plane, element) alone, so the reduce pass (whole planes per workgroup) and the apply pass (8192-element
+// chunks) read the same words the forward wrote.
+__device__ __forceinline__ size_t mask_word(int plane, int groups, int i) { return ((size_t)plane * groups + (i >> 8)) * 4; }
+
 static inline int reduce_splits(int N, int C) {
     int s = 2048 / (C > 0 ? C : 1);
     if (s < 1) s = 1;
@@ -50,7 +58,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, const float* __restrict__ residual,
     float* __restrict__ y, long long* __restrict__ num_batches_tracked, int N, int C, int HW, float eps,
-    float momentum, int training, int act, int chunk) {
+    float momentum, int training, int act, int chunk, unsigned long long* __restrict__ mask_bits) {
     const int plane = blockIdx.x;
     const int c = plane % C;
     float mean, invstd;
@@ -92,17 +100,35 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(
     const size_t base = (size_t)plane * HW;
     const int beg = blockIdx.y * chunk;
     const int end = min(HW, beg + chunk);
-    for (int i = beg + threadIdx.x * V; i < end; i += 256 * V) {
+    const int groups = (HW + 255) >> 8;
+    // (mask_bits: V = 4 only; the loop bound is rounded up so that every lane of a wave takes part in the ballots)
+    const int end_w = (V == 4 && mask_bits) ? beg + ((end - beg + 255) & ~255) : end;
+    for (int i = beg + threadIdx.x * V; i < end_w; i += 256 * V) {
         float v[V], r[V];
-        vload<V>(x + base + i, v);
-        if (residual) vload<V>(residual + base + i, r);
+        const bool in = i < end;
+        if (in) {
+            vload<V>(x + base + i, v);
+            if (residual) vload<V>(residual + base + i, r);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float o = fmaf(v[j], sc, sh);       // (the backward re-evaluates exactly this expression)
-            if (residual) o += r[j];
-            v[j] = act_fwd(o, act);
+            for (int j = 0; j < V; ++j) {
+                float o = fmaf(v[j], sc, sh);       // (the backward re-evaluates exactly this expression)
+                if (residual) o += r[j];
+                v[j] = act_fwd(o, act);
+            }
+            vstore<V>(y + base + i, v);
         }
-        vstore<V>(y + base + i, v);
+        if constexpr (V == 4) {
+            if (mask_bits) {
+                unsigned long long w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = __ballot(in && v[j] > 0.f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* dst = mask_bits + mask_word(plane, groups, i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[j] = w[j];
+                }
+            }
+        }
     }
 }
 
@@ -142,13 +168,16 @@ template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
     const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, double* __restrict__ sums, int N, int C, int HW, int act) {
+    const float* __restrict__ beta, double* __restrict__ sums, int N, int C, int HW, int act,
+    const unsigned long long* __restrict__ mask_bits) {
     __shared__ float red[4];
     const int c = blockIdx.x, S = gridDim.y;
     const float mu = mean[c], is = invstd[c];
+    const int groups = (HW + 255) >> 8;
+    const int lane = threadIdx.x & 63;
     // y == nullptr (ReLU, no residual): the mask [y > 0] is re-derived from x with the forward's own
     // arithmetic, fma(x, sc, sh) > 0 — one tensor read less in each backward pass
-    const bool remask = act != DYNMM_ACT_NONE && y == nullptr;
+    const bool remask = act != DYNMM_ACT_NONE && y == nullptr && mask_bits == nullptr;
     const float sc = remask ? gamma[c] * is : 0.f;
     const float sh = remask ? fmaf(-mu, sc, beta[c]) : 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -159,10 +188,17 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(
             float gv[V], yv[V], xv[V];
             vload<V>(g + base + i, gv);
             vload<V>(x + base + i, xv);
-            if (act != DYNMM_ACT_NONE && !remask) vload<V>(y + base + i, yv);
+            const bool bits = V == 4 && mask_bits != nullptr;
+            if (bits) {                                 // the forward's ReLU decisions, one bit per element (ReLU only)
+                const unsigned long long* wsrc = mask_bits + mask_word(n * C + c, groups, i);
+#pragma unroll
+                for (int j = 0; j < V; ++j) yv[j] = ((wsrc[j & 3] >> lane) & 1ull) ? 1.f : 0.f;
+            } else if (act != DYNMM_ACT_NONE && !remask) {
+                vload<V>(y + base + i, yv);
+            }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                if (remask) yv[j] = fmaf(xv[j], sc, sh);
+                if (remask && !bits) yv[j] = fmaf(xv[j], sc, sh);
                 const float ge = (act != DYNMM_ACT_NONE) ? act_bwd(gv[j], yv[j], act) : gv[j];
                 a1 += ge;
                 a2 += ge * (xv[j] - mu) * is;
@@ -184,11 +220,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const double* __restrict__ sums, float* __restrict__ dx,
     float* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int HW,
-    int training, int act, int chunk) {
+    int training, int act, int chunk, const unsigned long long* __restrict__ mask_bits) {
     const int plane = blockIdx.x;
     const int c = plane % C;
     const float mu = mean[c], is = invstd[c];
-    const bool remask = act != DYNMM_ACT_NONE && y == nullptr;
+    const int groups = (HW + 255) >> 8;
+    const int lane = threadIdx.x & 63;
+    const bool remask = act != DYNMM_ACT_NONE && y == nullptr && mask_bits == nullptr;
     const float sc = remask ? gamma[c] * is : 0.f;
     const float sh = remask ? fmaf(-mu, sc, beta[c]) : 0.f;
     const float sg = (float)sums[c], sgx = (float)sums[C + c];
@@ -207,10 +245,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
         float gv[V], yv[V], xv[V], o[V];
         vload<V>(g + base + i, gv);
         vload<V>(x + base + i, xv);
-        if (act != DYNMM_ACT_NONE && !remask) vload<V>(y + base + i, yv);
+        const bool bits = V == 4 && mask_bits != nullptr;
+        if (bits) {
+            const unsigned long long* wsrc = mask_bits + mask_word(plane, groups, i);
+#pragma unroll
+            for (int j = 0; j < V; ++j) yv[j] = ((wsrc[j & 3] >> lane) & 1ull) ? 1.f : 0.f;
+        } else if (act != DYNMM_ACT_NONE && !remask) {
+            vload<V>(y + base + i, yv);
+        }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            if (remask) yv[j] = fmaf(xv[j], sc, sh);
+            if (remask && !bits) yv[j] = fmaf(xv[j], sc, sh);
             const float ge = (act != DYNMM_ACT_NONE) ? act_bwd(gv[j], yv[j], act) : gv[j];
             gv[j] = ge;
             o[j] = k0 * (ge - m1 - (xv[j] - mu) * is * m2);
@@ -293,9 +338,11 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
                               const float* beta, float* running_mean, float* running_var,
                               float* save_mean, float* save_invstd, const float* residual, float* y,
                               long long* num_batches_tracked, int N, int C, int HW, float eps, float momentum,
-                              int training, int act, void* stream) {
+                              int training, int act, unsigned long long* relu_bits, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
+    if (relu_bits && (act != DYNMM_ACT_RELU || !can_vec4(HW, {x, residual, y}) || (reinterpret_cast<uintptr_t>(relu_bits) & 7u)))
+        return DYNMM_EUNSUPPORTED;
     if (training && (!sums || (long long)N * HW <= 1)) return DYNMM_EINVAL;
     if (!training && (!running_mean || !running_var)) return DYNMM_EINVAL;
     int nchunks;
@@ -305,13 +352,18 @@ extern "C" int dynmm_bn_apply(const float* x, const double* sums, const float* g
     if (can_vec4(HW, {x, residual, y}))
         hipLaunchKernelGGL(bn_apply_kernel<4>, grid, dim3(256), 0, st, x, sums, gamma, beta,
                            running_mean, running_var, save_mean, save_invstd, residual, y,
-                           num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk);
+                           num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk, relu_bits);
     else
         hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, st, x, sums, gamma, beta,
                            running_mean, running_var, save_mean, save_invstd, residual, y,
-                           num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk);
+                           num_batches_tracked, N, C, HW, eps, momentum, training, act, chunk, (unsigned long long*)nullptr);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
+}
+
+extern "C" size_t dynmm_bn_relu_bits_words(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0 || HW % 4 != 0) return 0;
+    return (size_t)N * C * ((HW + 255) / 256) * 4;
 }
 
 extern "C" int dynmm_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
@@ -332,19 +384,22 @@ extern "C" int dynmm_bn_finalize(const double* sums, const float* gamma, const f
 extern "C" int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x, const float* mean,
                                    const float* invstd, const float* gamma, const float* beta,
                                    double* sums, int N, int C, int HW, int act, int sums_are_zero,
-                                   void* stream) {
+                                   const unsigned long long* relu_bits, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0) return DYNMM_EINVAL;
-    if (act != DYNMM_ACT_NONE && !y && (act != DYNMM_ACT_RELU || !gamma || !beta)) return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y && !relu_bits && (act != DYNMM_ACT_RELU || !gamma || !beta)) return DYNMM_EINVAL;
+    if (relu_bits && (act != DYNMM_ACT_RELU || !can_vec4(HW, {g, x}) || (reinterpret_cast<uintptr_t>(relu_bits) & 7u)))
+        return DYNMM_EUNSUPPORTED;
+    if (relu_bits) y = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (!sums_are_zero) DYNMM_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
     dim3 grid(C, reduce_splits(N, C));
     if (can_vec4(HW, {g, y, x}))
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd, gamma, beta,
-                           sums, N, C, HW, act);
+                           sums, N, C, HW, act, relu_bits);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd, gamma, beta,
-                           sums, N, C, HW, act);
+                           sums, N, C, HW, act, (const unsigned long long*)nullptr);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -352,21 +407,26 @@ extern "C" int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* 
 extern "C" int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x, const float* mean,
                                   const float* invstd, const float* gamma, const float* beta,
                                   const double* sums, float* dx, float* d_residual, float* dgamma,
-                                  float* dbeta, int N, int C, int HW, int training, int act, void* stream) {
+                                  float* dbeta, int N, int C, int HW, int training, int act,
+                                  const unsigned long long* relu_bits, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!g || !x || !mean || !invstd || !gamma || !sums || !dx || N <= 0 || C <= 0 || HW <= 0)
         return DYNMM_EINVAL;
-    if (act != DYNMM_ACT_NONE && !y && (act != DYNMM_ACT_RELU || !beta || d_residual)) return DYNMM_EINVAL;
+    if (act != DYNMM_ACT_NONE && !y && !relu_bits && (act != DYNMM_ACT_RELU || !beta || d_residual)) return DYNMM_EINVAL;
+    if (relu_bits && (act != DYNMM_ACT_RELU || !can_vec4(HW, {g, x, dx, d_residual}) || (reinterpret_cast<uintptr_t>(relu_bits) & 7u)))
+        return DYNMM_EUNSUPPORTED;
+    if (relu_bits) y = nullptr;
     int nchunks;
     const int chunk = plane_chunk(HW, &nchunks);
     dim3 grid(N * C, nchunks);
     hipStream_t st = (hipStream_t)stream;
     if (can_vec4(HW, {g, y, x, dx, d_residual}))
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
-                           gamma, beta, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
+                           gamma, beta, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk, relu_bits);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, st, g, y, x, mean, invstd,
-                           gamma, beta, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk);
+                           gamma, beta, sums, dx, d_residual, dgamma, dbeta, N, C, HW, training, act, chunk,
+                           (const unsigned long long*)nullptr);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

@@ -76,9 +76,10 @@ SIGNATURES = {
     'dynmm_act_bwd_bias_workspace_bytes': (c_sz, [c_i, c_i]),
     'dynmm_act_bwd_bias': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     'dynmm_bn_stats': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
-    'dynmm_bn_apply': (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f]),
-    'dynmm_bn_bwd_reduce': (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_i, c_i, c_f]),
-    'dynmm_bn_bwd_apply': (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_i, c_i, c_f]),
+    'dynmm_bn_relu_bits_words': (c_sz, [c_i, c_i, c_i]),
+    'dynmm_bn_apply': (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
+    'dynmm_bn_bwd_reduce': (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    'dynmm_bn_bwd_apply': (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     'dynmm_bn_fold': (c_i, [c_f] * 7 + [c_i, c_fl, c_f]),
     'dynmm_maxpool3x3s2_fwd': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
     'dynmm_maxpool3x3s2_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 6 + [c_f]),
@@ -146,7 +147,7 @@ SIGNATURES = {
     'dynmm_clip_grad_norm': (c_i, [c_f, c_sz, c_fl, c_f, c_f, c_f]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

@@ -413,6 +413,9 @@ class BNLink:
 
 
 BN_BWD_FUSE = _os.environ.get('DYNMM_BN_BWD_FUSE', '1') != '0'
+# BatchNorm + residual + ReLU (bn2 of every residual block): the ReLU decisions travel to the backward as one bit per element
+# instead of the 4-byte output tensor (tests / A-B: ops.BN_RELU_BITS = False)
+BN_RELU_BITS = True
 
 
 class PackedWeights:
@@ -881,9 +884,16 @@ class _BatchNormAct(Function):
         y = torch.empty_like(x)
         # (training = the number of slabs the sums arrive in: 1, or the slots of the producing convolution's epilogue)
         nsl = (sums.numel() // (2 * Cc)) if training else 0
+        # ReLU after a residual add, gradient recorded: the backward cannot re-derive the mask from x — the normalise pass leaves
+        # the decisions as one bit per element and the two backward passes read those instead of y (csrc/norm.hip)
+        bits = None
+        if (BN_RELU_BITS and act == L.ACT_RELU and residual is not None and HW % 4 == 0 and
+                any(ctx.needs_input_grad[i] for i in (0, 1, 2, 5)) and
+                all(t.data_ptr() % 16 == 0 for t in (x, residual, y))):
+            bits = torch.empty(lib.dynmm_bn_relu_bits_words(N, Cc, HW), device=dev, dtype=torch.int64)
         L.check(lib.dynmm_bn_apply(_p(x), _p(sums), _p(gamma), _p(beta), _p(running_mean),
                                    _p(running_var), _p(mean), _p(invstd), _p(residual), _p(y), _p(nbt),
-                                   N, Cc, HW, eps, momentum, nsl, act, st), 'bn_apply')
+                                   N, Cc, HW, eps, momentum, nsl, act, _p(bits), st), 'bn_apply')
         ctx.act = act
         ctx.training = training
         ctx.link = link
@@ -894,8 +904,8 @@ class _BatchNormAct(Function):
         ctx.has_res = residual is not None
         # ReLU without residual: the backward re-derives the mask from x (bit-identical to this forward's
         # fma) instead of reading y — one tensor read less in bn_bwd_reduce and in bn_bwd_apply
-        need_y = act != L.ACT_NONE and not (act == L.ACT_RELU and residual is None)
-        ctx.save_for_backward(x, y if need_y else None, gamma, mean, invstd, beta)
+        need_y = act != L.ACT_NONE and not (act == L.ACT_RELU and residual is None) and bits is None
+        ctx.save_for_backward(x, y if need_y else None, gamma, mean, invstd, beta, bits)
         ctx.g_param, ctx.b_param = gamma, beta
         return y
 
@@ -903,8 +913,10 @@ class _BatchNormAct(Function):
     def backward(ctx, gy):
         lib = _lib()
         st = _stream()
-        x, y, gamma, mean, invstd, beta = ctx.saved_tensors
+        x, y, gamma, mean, invstd, beta, bits = ctx.saved_tensors
         gy = _chk(gy, 'grad')
+        if bits is not None and gy.data_ptr() % 16 != 0:
+            gy = gy.clone()                      # (a gradient view off the 16-byte grid: the bit path reads 16 bytes per lane)
         N, Cc, H, W = x.shape
         HW = H * W
         dev = x.device
@@ -914,7 +926,7 @@ class _BatchNormAct(Function):
         else:
             sums, zeroed = _zero_sums(2 * Cc, dev)
             L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-                                            N, Cc, HW, ctx.act, zeroed, st), 'bn_bwd_reduce')
+                                            N, Cc, HW, ctx.act, zeroed, _p(bits), st), 'bn_bwd_reduce')
         if bl is not None:
             bl.x = None
         dx = torch.empty_like(x)
@@ -924,7 +936,7 @@ class _BatchNormAct(Function):
         dbeta, dbeta_ret = _grad_dst(ctx.b_param)
         L.check(lib.dynmm_bn_bwd_apply(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
                                        _p(dx), _p(dres), _p(dgamma), _p(dbeta), N, Cc, HW,
-                                       int(ctx.training), ctx.act, st), 'bn_bwd_apply')
+                                       int(ctx.training), ctx.act, _p(bits), st), 'bn_bwd_apply')
         if need_res and dres is None:
             dres = gy            # no activation: the residual branch receives the gradient unchanged
         if ctx.link is not None and dres is not None:

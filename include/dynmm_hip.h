@@ -204,11 +204,17 @@ int dynmm_bn_stats(const float* x, double* sums, int N, int C, int HW, int sums_
  *             dynmm_conv2d_wino_fwd_stats) — (biased var for normalisation); writes save_mean/save_invstd[C],
  *             updates running_mean/var with `momentum` (unbiased var), as F.batch_norm does, and
  *             increments *num_batches_tracked (int64, optional) as nn.BatchNorm2d does.
- * training=0: uses running_mean/var; sums / save_* may be NULL. */
+ * training=0: uses running_mean/var; sums / save_* may be NULL.
+ * relu_bits (optional; act = ReLU, HW % 4 == 0, 16-byte aligned tensors): the ReLU decisions [y > 0], ONE BIT per element
+ *             (dynmm_bn_relu_bits_words(N, C, HW) 64-bit words: per plane and group of 256 consecutive elements four ballot
+ *             words, word j bit l = element 4 l + j).  The two backward passes read them in place of y — with a residual
+ *             (resnet.py:136-147: bn2 + identity + ReLU) the mask cannot be re-derived from x, and y is 4 bytes per element
+ *             in each pass. */
+size_t dynmm_bn_relu_bits_words(int N, int C, int HW);
 int dynmm_bn_apply(const float* x, const double* sums, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                    const float* residual, float* y, long long* num_batches_tracked, int N, int C, int HW,
-                   float eps, float momentum, int training, int act, void* stream);
+                   float eps, float momentum, int training, int act, unsigned long long* relu_bits, void* stream);
 /* The per-channel part of dynmm_bn_apply alone (training mode): mean / invstd, running statistics (+ step counter),
  * and scale = gamma*invstd, shift = beta - mean*scale for consumers that normalise on load. */
 int dynmm_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean,
@@ -217,17 +223,19 @@ int dynmm_bn_finalize(const double* sums, const float* gamma, const float* beta,
 /* backward: sums[2*C] <- (sum g_eff, sum g_eff*xhat), g_eff = g*act'(y).
  * y may be NULL for act = ReLU when the forward had no residual: the mask [y > 0] is then re-derived from
  * x as fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0 — bit-identical to the forward's own evaluation
- * (gamma, beta required in that case) — which saves one tensor read in each of the two backward passes. */
+ * (gamma, beta required in that case) — which saves one tensor read in each of the two backward passes.
+ * relu_bits (optional): the forward's ReLU decisions as written by dynmm_bn_apply; y is then not read (may be NULL). */
 int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x,
                         const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        double* sums, int N, int C, int HW, int act, int sums_are_zero, void* stream);
+                        double* sums, int N, int C, int HW, int act, int sums_are_zero,
+                        const unsigned long long* relu_bits, void* stream);
 /* dx = gamma*invstd*(g_eff - sum_g/M - xhat*sum_gx/M) (training) or gamma*invstd*g_eff (eval);
  * d_residual = g_eff (optional); dgamma/dbeta from sums. */
 int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x,
                        const float* mean, const float* invstd, const float* gamma, const float* beta,
                        const double* sums, float* dx, float* d_residual,
                        float* dgamma, float* dbeta,
-                       int N, int C, int HW, int training, int act, void* stream);
+                       int N, int C, int HW, int training, int act, const unsigned long long* relu_bits, void* stream);
 /* eval-mode folding for the fused conv epilogue: scale = gamma*rsqrt(var+eps),
  * shift = beta + (conv_bias - mean)*scale   (conv_bias optional). */
 int dynmm_bn_fold(const float* gamma, const float* beta, const float* running_mean,

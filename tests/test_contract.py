@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(lib.LIB_PATH):
         lib.build()
     handle = lib.load()            # getattr() on every symbol; raises if one is missing
-    assert handle.dynmm_abi_version() == 3
+    assert handle.dynmm_abi_version() == 4
     assert b'gfx950' in handle.dynmm_build_info()
 
 

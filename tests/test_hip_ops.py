@@ -255,6 +255,63 @@ def test_conv_fused_eval(ops, act, with_res):
     assert rel(y, ref) < TOL
 
 
+@pytest.mark.parametrize('shape', [(4, 64, 24, 32),        # HW = 768: three full 256-element groups per plane
+                                   (3, 128, 15, 20),       # HW = 300: one full group + a ragged one
+                                   (2, 64, 120, 160),      # HW = 19200: three 8192-element chunks per plane (the apply passes' grid)
+                                   (5, 32, 2, 2)])         # HW = 4: a plane is a single lane
+@pytest.mark.parametrize('training', [True, False])
+def test_batchnorm_residual_relu_decisions_as_bits(ops, shape, training):
+    """relu(BN(x) + residual) (resnet.py:136-147): the forward leaves the ReLU decisions as one bit per element and the two
+    backward passes read them instead of the output tensor (dynmm_bn_apply / _bwd_reduce / _bwd_apply `relu_bits`).  Same output
+    and — bit for bit — the same gradients as the path that reads y; against float64 at GTOL; the words themselves against the
+    output's sign pattern."""
+    N, C, H, W = shape
+    x, res, gy = rnd(*shape, seed=1) * 2 + 0.3, rnd(*shape, seed=2), rnd(*shape, seed=3)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3).cuda().train(training)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C, seed=4).abs() + 0.5)
+        bn.bias.copy_(rnd(C, seed=5) * 0.1)
+        bn.running_mean.copy_(rnd(C, seed=6) * 0.1)
+        bn.running_var.copy_(rnd(C, seed=7).abs() + 0.5)
+    state = {k: v.clone() for k, v in bn.state_dict().items()}
+    lib = ops._lib()
+    old = ops.BN_RELU_BITS
+
+    def run(flag):
+        ops.BN_RELU_BITS = flag
+        bn.load_state_dict(state)
+        for q in bn.parameters():
+            q.grad = None
+        xi, ri = x.clone().cuda().requires_grad_(True), res.clone().cuda().requires_grad_(True)
+        y = ops.batch_norm_act(xi, bn, 'relu', ri)
+        saved = y.grad_fn.saved_tensors
+        assert (saved[6] is not None) == flag and (saved[1] is None) == flag       # bits instead of y
+        if flag:
+            words = saved[6].cpu().numpy().view(np.uint64).reshape(N * C, -1, 4)
+            pos = (y.detach() > 0).reshape(N * C, H * W).cpu().numpy()
+            for plane in (0, N * C - 1):
+                for e in (0, H * W - 1, (H * W) // 2):
+                    grp, lane, j = e // 256, (e % 256) // 4, e % 4
+                    assert bool((int(words[plane, grp, j]) >> lane) & 1) == bool(pos[plane, e]), (plane, e)
+        y.backward(gy.cuda())
+        torch.cuda.synchronize()
+        return y.detach(), xi.grad, ri.grad, bn.weight.grad.clone(), bn.bias.grad.clone()
+    try:
+        a, b = run(False), run(True)
+    finally:
+        ops.BN_RELU_BITS = old
+    for t, u in zip(a, b):
+        assert torch.equal(t, u)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = state['weight'].cpu().double().requires_grad_(True), state['bias'].cpu().double().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, state['running_mean'].cpu().double(), state['running_var'].cpu().double(), gr, br, training,
+                             0.1, 1e-3) + rr)
+    yr.backward(gy.double())
+    assert rel(b[0], yr) < TOL
+    for t, ref in zip(b[1:], (xr.grad, rr.grad, gr.grad, br.grad)):
+        assert rel(t, ref) < GTOL
+
+
 @pytest.mark.parametrize('shape', [(4, 64, 24, 32), (3, 8, 27, 37), (4, 256, 1, 1), (2, 128, 5, 5)])
 @pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
 @pytest.mark.parametrize('training', [True, False])
