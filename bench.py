@@ -348,7 +348,7 @@ def executed_fraction(name):
         return 1.0
     if 'wino43' in name:
         return 0.5
-    if 'wino' in name or (name.startswith('conv_wgrad_v6') and os.environ.get('DYNMM_WGRAD_WINO', '1') != '0'):
+    if 'wino' in name or name.startswith('conv_wgrad_v6'):
         return 2.0 / 3.0
     return 1.0
 
@@ -613,6 +613,25 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_self_description():
+    """What the first SCALE record should say about the collective library it ran on: the RCCL version torch was built against /
+    loaded, the HIP runtime, the devices, and RCCL's own NCCL_DEBUG=VERSION banner (captured through NCCL_DEBUG_FILE, which
+    main() points at a per-process file before the process group is created, so nothing but the JSON line reaches stdout)."""
+    info = {'hip': torch.version.hip, 'devices': [torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())]}
+    try:
+        info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                    # noqa: BLE001 - informational only
+        info['rccl_version'] = f'unavailable ({type(e).__name__})'
+    path = os.environ.get('NCCL_DEBUG_FILE', '')
+    if path and os.path.exists(path):
+        try:
+            with open(path) as f:
+                info['rccl_debug'] = [ln.strip()[:200] for ln in f.read().splitlines() if ln.strip()][:6]
+        except OSError:
+            pass
+    return info
+
+
 def main():
     args = parse()
     if args.gpus is None:
@@ -647,6 +666,8 @@ def main():
     if world > 1:
         # nccl == RCCL on ROCm.  DYNMM_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a
         # single-GPU box (ranks then share device 0).
+        os.environ.setdefault('NCCL_DEBUG', 'VERSION')        # RCCL's version / build banner, into a file (rccl_self_description)
+        os.environ.setdefault('NCCL_DEBUG_FILE', f'/tmp/dynmm_rccl_{os.getpid()}.log')
         dist.init_process_group(os.environ.get('DYNMM_DIST_BACKEND', 'nccl'))
     train = args.mode == 'train'
 
@@ -667,7 +688,7 @@ def main():
         dist.all_reduce(ones)                          # every rank of the job answers: the line proves N ranks ran
         per_rank_ms = [1000.0 * t / args.steps for t in timed.per_rank]
         dp_info = {'backend': dist.get_backend(), 'ranks_seen': int(round(ones.item())),
-                   'devices_visible': torch.cuda.device_count(),
+                   'devices_visible': torch.cuda.device_count(), 'collective_library': rccl_self_description(),
                    'ms_per_step_rank_min_mean_max': [round(min(per_rank_ms), 3), round(sum(per_rank_ms) / world, 3),
                                                      round(max(per_rank_ms), 3)]}
         if dp_info['ranks_seen'] != args.gpus:
@@ -741,6 +762,29 @@ def main():
         res['unit'] = 'images/s'
         extra['train_hard'] = res
         extra['affect_mosei'] = measure_affect_isolated(max(10, args.steps))
+        if args.config == 'P':
+            # SURVEY.md section 8 "Config S (secondary)": the BasicBlock (3x3) variant of the same step, 300.8 GFLOP per image
+            subs = argparse.Namespace(**vars(args))
+            subs.config, subs.graph = 'S', False
+            st3, ts3, m3 = train_workload(subs, device, rank, 1)
+            for _ in range(2):
+                st3()
+            k = max(5, args.steps // 2)
+            el = timed(st3, k, 2, 1, device)
+            val = args.batch * k / el
+            saved = (ts3.multi_stream, m3.dual_stream)
+            ts3.multi_stream, m3.dual_stream = False, False
+            rs = roofline_of(kernel_timing(st3, m3))
+            ts3.multi_stream, m3.dual_stream = saved
+            extra['config_S'] = {'value': round(val, 2), 'unit': 'images/s', 'ms_per_step': round(1000 * el / k, 3),
+                                 'algorithmic_gflop_per_image': GFLOP_PER_IMG_FWD_BWD['S'],
+                                 'tflops': round(val * GFLOP_PER_IMG_FWD_BWD['S'] / 1e3, 2),
+                                 'frac_of_fp32_mfma_peak': round(val * GFLOP_PER_IMG_FWD_BWD['S'] / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 'dominant_kernel': None if not rs else {kk: rs[kk] for kk in (
+                                     'kernel', 'launches_per_step', 'avg_launch_us', 'achieved', 'frac', 'executed_frac') if kk in rs},
+                                 'workload': 'configs[2] on config S (ResNet-34 BasicBlock encoders): the same step, batch 32, 480x640'}
+            del st3, ts3, m3
+            torch.cuda.empty_cache()
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -779,8 +823,7 @@ def main():
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
-                       'winograd': {'DYNMM_WINO': ops.WINO, 'inference_forward': ops.WINO != '0' and ops.WINO_INFER,
-                                    'weight_gradients': os.environ.get('DYNMM_WGRAD_WINO', '1') != '0'},
+                       'winograd': {'passes': ops.WINO, 'input_gradients': ops.WINO_DGRAD, 'weight_gradients': True},
                        'dp': dp_info},
             'whole_step': {'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
                                   f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',

@@ -490,21 +490,11 @@ extern "C" int dynmm_debug_set_trace(void* p) {
 namespace dynmm {
 #endif
 
-// Tuning knobs for experiments (read once; unset = built-in choice):
-//   DYNMM_IGEMM_TPIX=64|128      pixel tile of the Co>64 configuration
-//   DYNMM_IGEMM_TPIX_C64=128|256 pixel tile of the 32<Co<=64 configuration
 // rows per filter tap of a packed weight / K-steps of the fast path (see pack_weight_kernel)
 static inline int round_k(int c) { return (c >= 8 && c % 16 != 0) ? ((c + 15) & ~15) : c; }
 
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : 0;
-}
-
 template <bool DGRAD>
 static int launch_igemm(IgemmArgs& a, hipStream_t st) {
-    static const int force_tpix = env_int("DYNMM_IGEMM_TPIX");
-    static const int force_tpix64 = env_int("DYNMM_IGEMM_TPIX_C64");
     const bool dual_in = a.x2 != nullptr;
     a.CiR = round_k(a.Ci);
     const bool generic = (a.CiR % 16 != 0) || (dual_in && (a.c_in_split % 16 != 0)) ||
@@ -512,8 +502,7 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Ci;
     a.CoP = (a.Co + 3) & ~3;
-    static const int no_subpix = env_int("DYNMM_NO_SUBPIX");
-    a.subpix = (DGRAD && !generic && !no_subpix && a.SH * a.SW > 1 && a.Ho % a.SH == 0 && a.Wo % a.SW == 0) ? 1 : 0;
+    a.subpix = (DGRAD && !generic && a.SH * a.SW > 1 && a.Ho % a.SH == 0 && a.Wo % a.SW == 0) ? 1 : 0;
     if (!generic && launch_igemm_v5(a, DGRAD, st)) {      // stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3: the operand-ring kernels
         DYNMM_LAUNCH_CHECK();
         return DYNMM_OK;
@@ -539,20 +528,14 @@ static int launch_igemm(IgemmArgs& a, hipStream_t st) {
         // 98 vs 73 at C=256, 80 vs 56 at C=512: this kernel is limited by latency hiding / residency
         // rounds, not by MFMA issue, so more, smaller workgroups win.  (BK=32 and a 2-deep register
         // prefetch both lost for the same reason: they cost occupancy.)
-        if (force_tpix == 128)
-            DYNMM_IGEMM_LAUNCH(128, 128, 64, 64);
-        else if (force_tpix == 32 ||
-                 (force_tpix == 0 && ceil_div(a.Co, 128) * ceil_div(a.M, 64) < 3 * 256))
+        if (ceil_div(a.Co, 128) * ceil_div(a.M, 64) < 3 * 256)
             // fewer than 3 tiles per CU (C=512 @ 15x20: 600 tiles): halve the tile so the work spreads
             // evenly — 188.6 -> 174.6 us; at >= 4.7 tiles/CU the 128x64 tile's lower L2 traffic wins.
             DYNMM_IGEMM_LAUNCH(128, 32, 32, 32);
         else
             DYNMM_IGEMM_LAUNCH(128, 64, 64, 32);
     } else if (a.Co > 32) {
-        if (force_tpix64 == 256)
-            DYNMM_IGEMM_LAUNCH(64, 256, 64, 64);
-        else
-            DYNMM_IGEMM_LAUNCH(64, 128, 32, 64);     // 77/84 vs 67/77 TFLOP/s (fwd/dgrad) at C=64
+        DYNMM_IGEMM_LAUNCH(64, 128, 32, 64);         // 77/84 TFLOP/s (fwd/dgrad) at C=64 against 67/77 for a 64x256 tile
     } else {
         DYNMM_IGEMM_LAUNCH(32, 256, 32, 64);
     }
@@ -1162,7 +1145,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
     p.v6 = 0;
     p.bp = 32;
     if (allow_v6 && wgrad_v6_shape_ok(g)) {
-        static const int target6 = env_int("DYNMM_WGRAD_V6_BLOCKS");
+        constexpr int target6 = 0;
         p.v6 = 1;
         p.bp = wgrad_wino_vt_on(g) ? 8 : 16;
         p.tco = wgrad_v6_tco(g);
@@ -1184,7 +1167,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
     }
     p.n_co_tiles = ceil_div(g->Co, p.tco);
     p.n_k_tiles = ceil_div(K, p.tk);
-    static const int target_env = env_int("DYNMM_WGRAD_BLOCKS");
+    constexpr int target_env = 0;
     p.target = target_env ? target_env : 512;          // ONE residency round: 256 CUs x 2 workgroups (180 VGPRs)
     plan_splits(p, g, 1);
     return p;
@@ -1531,14 +1514,11 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     a.K = g->KH * g->KW * g->Ci;
     a.n_co_tiles = p.n_co_tiles; a.n_k_tiles = p.n_k_tiles; a.steps_per_split = p.steps_per_split;
     hipStream_t st = (hipStream_t)stream;
-    static const int no_xcd = env_int("DYNMM_WGRAD_NO_XCD");
-    (void)no_xcd;
     dim3 grid((unsigned)(p.n_co_tiles * p.n_k_tiles * p.splits));
     const bool dual = x2 != nullptr;
     const bool fast = !dual && (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
     a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
-    static const int no_v4 = env_int("DYNMM_WGRAD_NO_V4");
-    const bool v4 = !p.v6 && !no_v4 && !dual && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
+    const bool v4 = !p.v6 && !dual && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
                     (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
                     ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH &&
                     ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15u) == 0);
@@ -1547,11 +1527,8 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     const bool perm = (v4 || p.v6) && p.splits > 1 && ((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) && bias_ok4;
     a.k_major_out = perm ? 1 : 0;
     if (p.v6 || v4) {
-        static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
         if (p.v6)
             launch_wgrad_v6(a, WgradGroup{}, grid, wgrad_v6_occupancy(g), st);
-        else if (v4_nbuf == 2)
-            hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, WgradGroup{});
         else
             hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a, WgradGroup{});
         DYNMM_LAUNCH_CHECK();
@@ -1576,9 +1553,8 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
 
 // ---- grouped weight gradients --------------------------------------------------------------------------------------
 static bool wgrad_v4_shape_ok(const dynmm_conv_geom* g, const WgradPlan& p) {
-    static const int no_v4 = env_int("DYNMM_WGRAD_NO_V4");
     if (p.v6) return (g->Co % 4 == 0);
-    return !no_v4 && g->c_split == g->Ci && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
+    return g->c_split == g->Ci && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
            (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
            ((g->Ho * g->Wo) % 4 == 0) && g->H >= g->KH && (g->Co % 4 == 0);
 }
@@ -1598,14 +1574,12 @@ static size_t group_problem_floats(const dynmm_conv_geom* g, const WgradPlan& p)
 
 // 2: the vectorised 128x128 kernel; 1: the generic tiles (single input, split pixel range); 0: not groupable
 extern "C" int dynmm_conv2d_wgrad_groupable(const dynmm_conv_geom* g) {
-    static const int off = env_int("DYNMM_NO_WGRAD_GROUP");
-    if (off || !geom_ok(g) || g->c_split != g->Ci) return 0;
+    if (!geom_ok(g) || g->c_split != g->Ci) return 0;
     if (stem_conv_wgrad_eligible(g->Ci, g->Co, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, false, false)) return 0;
     if (co8_wgrad_eligible(g->Ci, g->Co, g->H, g->W, g->Ho, g->Wo, g->KH, g->KW, g->SH, g->SW, g->PH, g->PW, g->c_split)) return 0;
     const WgradPlan p = plan_wgrad(g);
     if (p.splits <= 1) return 0;
-    static const int no_generic = env_int("DYNMM_NO_WGRAD_GROUP_GENERIC");
-    return wgrad_v4_shape_ok(g, p) ? 2 : (no_generic ? 0 : 1);
+    return wgrad_v4_shape_ok(g, p) ? 2 : 1;
 }
 
 extern "C" int dynmm_conv2d_wgrad_variant(const dynmm_conv_geom* g) {
@@ -1686,11 +1660,8 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
         return DYNMM_OK;
     }
     a.k_major_out = 1;
-    static const int v4_nbuf = env_int("DYNMM_WGRAD_V4_NBUF");
     if (p.v6)
         launch_wgrad_v6(a, grp, grid, wgrad_v6_occupancy(g), st);
-    else if (v4_nbuf == 2)
-        hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 2>), grid, dim3(512), 0, st, a, grp);
     else
         hipLaunchKernelGGL((conv_wgrad_v4_kernel<128, 128, 1>), grid, dim3(512), 0, st, a, grp);
     DYNMM_LAUNCH_CHECK();

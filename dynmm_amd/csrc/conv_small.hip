@@ -14,15 +14,8 @@
 #include "common.h"
 #include "conv_small.h"
 #include "conv_igemm.h"
-#include <cstring>
 
 namespace dynmm {
-
-// DYNMM_NO_SMALL_CO = 1 | gate | stem | stemw : A/B switch back to the implicit-GEMM kernels
-static bool small_off_early(const char* which) {
-    const char* v = getenv("DYNMM_NO_SMALL_CO");
-    return v && (strcmp(v, which) == 0 || strcmp(v, "1") == 0);
-}
 
 constexpr int kSP = 5;                // output pixels per lane (consecutive along W)
 constexpr int kSRows = 4;             // output rows per workgroup
@@ -321,8 +314,6 @@ static void co8_wgrad_plan(int N, int Ci, int* NI, int* G) {
 }
 
 bool co8_wgrad_eligible(int Ci, int Co, int H, int W, int Ho, int Wo, int KH, int KW, int SH, int SW, int PH, int PW, int c_split) {
-    static const bool off = small_off_early("gatew");
-    if (off) return false;
     if (KH != 5 || KW != 5 || SH != 2 || SW != 2 || PH != 0 || PW != 0) return false;
     if (Co < 1 || Co > 8 || Ci < 16 || Ci % 4 != 0 || W % 4 != 0) return false;
     if (c_split != Ci && c_split % 4 != 0) return false;               // a channel group never straddles the two inputs
@@ -674,8 +665,7 @@ static int stem_wgrad_grid(long tiles, int Ci) {
 }
 
 bool stem_conv_wgrad_eligible(int Ci, int Co, int KH, int KW, int SH, int SW, int PH, int PW, bool has_x2, bool has_bias) {
-    static const bool off = small_off_early("stemw");
-    if (off || has_x2 || has_bias) return false;
+    if (has_x2 || has_bias) return false;
     if (KH != 7 || KW != 7 || SH != 2 || SW != 2 || PH != 3 || PW != 3) return false;
     return (Ci == 1 || Ci == 3) && Co == 64;
 }
@@ -705,8 +695,7 @@ int launch_stem_conv_wgrad(const float* x, const float* dy, float* dw, float* wo
 }
 
 bool stem_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
-    static const bool off = small_off_early("stem");
-    if (off || residual || a.x2) return false;
+    if (residual || a.x2) return false;
     if (a.KH != 7 || a.KW != 7 || a.SH != 2 || a.SW != 2 || a.PH != 3 || a.PW != 3) return false;
     return (a.Ci == 1 || a.Ci == 3) && a.Co == 64;
 }
@@ -734,8 +723,7 @@ int launch_stem_conv_fwd(const SmallConvArgs& a_in, hipStream_t st) {
 }
 
 bool small_conv_fwd_eligible(const SmallConvArgs& a, const float* residual) {
-    static const bool off = small_off_early("gate");
-    if (off || residual) return false;
+    if (residual) return false;
     if (a.Co < 5 || a.Co > 8) return false;                       // packed rows of exactly 8 floats
     if (a.KH != 5 || a.KW != 5 || a.SH != 2 || a.SW != 2 || a.PH != 0 || a.PW != 0) return false;
     if (a.Ci % 4 != 0 || a.Ci < 16) return false;

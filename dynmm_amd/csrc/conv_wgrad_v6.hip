@@ -1,5 +1,7 @@
-// Weight gradient of the three-tap convolutions (1x3 and 3x1, stride 1, 'same' padding: every NonBottleneck1D conv,
-// resnet.py:104-117) on the fp32 matrix cores, operand tiles by direct global -> LDS loads ("v6").
+// Weight gradient of the horizontal three-tap convolutions (1x3, stride 1, 'same' padding: resnet.py:104-117) and, one vertical
+// tap per workgroup, of the 3x3 convolutions (resnet.py:66-84, model.py:343-357) on the fp32 matrix cores in the Winograd pair
+// form, operand tiles by direct global -> LDS loads ("v6").  The 3x1 convolutions take conv_wgrad_wino_vt.hip.  (Rounds 3-4 also
+// carried the direct form — three contractions per pixel, horizontal and vertical — behind DYNMM_WGRAD_WINO=0; removed in round 5.)
 //
 // dW[co][tap][ci] = sum_pix dY[co][pix] * X[ci][pix + tap shift]: M = co, N = (tap, ci), reduction over pixels.
 // What changed against conv_wgrad_v4_kernel (conv_igemm.hip), and why (DESIGN.md §4 "round 3"):
@@ -43,21 +45,19 @@ using ic = std::integral_constant<int, I>;
 // input rows shifted by -1 / 0 / +1: one workgroup owns ONE vertical tap of its 64 input channels (k-tiles = 3 x Ci / 64), stages
 // the X rows `dr` image rows away (a quad whose row leaves the image reads the zero quad instead — the vertical padding) and
 // writes taps 3 (dr + 1) .. 3 (dr + 1) + 2 of the slab.  Same Winograd pairs, same loads, same slabs as the 1x3 launch.
-template <int MCO, bool VT, int NST, int OCC, bool WINO = false, bool K33 = false>
+template <int MCO, int NST, int OCC, bool K33 = false>
 __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs a_in, const WgradGroup grp) {
-    static_assert(!(WINO && VT), "the Winograd form is implemented for the horizontal taps");
-    static_assert(!K33 || (WINO && !VT), "3x3 filters take the horizontal Winograd form per vertical tap");
-    constexpr int NACC = WINO ? 4 : 3;
+    constexpr int NACC = 4;
     WgradArgs a = a_in;
     constexpr int TCO = 64 * MCO, BP = 16;
-    constexpr int LDG = 20, LDX = VT ? 20 : 28;                 // row strides in floats
-    constexpr int XROWS = VT ? 192 : 64;
+    constexpr int LDG = 20, LDX = 28;                           // row strides in floats
+    constexpr int XROWS = 64;
     constexpr int G_STAGE = TCO * LDG, X_STAGE = XROWS * LDX;   // floats per ring slot
     constexpr int GW = TCO / 4;                                 // dY rows requested by one wave
     constexpr int NJG = (GW + 11) / 12;                         // wave instructions per stage: dY (12 rows each)
-    constexpr int RJX = VT ? 12 : 9;                            //   X rows per instruction
+    constexpr int RJX = 9;                                      //   X rows per instruction
     constexpr int NJX1 = (16 + RJX - 1) / RJX;                  //   X (16 rows per wave and tap)
-    constexpr int J = NJG + (VT ? 3 : 1) * NJX1;                // loads in flight per wave and stage
+    constexpr int J = NJG + NJX1;                               // loads in flight per wave and stage
     static_assert(NST == 3, "ring depth");
     static_assert(NST * J < 64, "vmcnt is a 6-bit counter");
 
@@ -100,28 +100,21 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     // dY and the vertical-tap X rows: lane -> (row r5 of the instruction, quad q5; q5 == 4 is the padding quad)
     const int q5 = lane % 5, r5 = lane / 5;
     int l_m = step_begin * BP + 4 * (q5 < 4 ? q5 : 3);          // first pixel of the quad
-    int l_rem, l_ow = 0, l_oh = 0;
-    unsigned l_goff, l_xoff = 0;
+    int l_rem;
+    unsigned l_goff;
     {
         const int n = l_m / HW;
         l_rem = l_m - n * HW;
         l_goff = ((unsigned)(n * a.Co + co0 + wave * GW + r5) * (unsigned)HW + (unsigned)l_rem) * 4u;
-        if (VT) {
-            l_oh = l_rem / W;
-            l_ow = l_rem - l_oh * W;
-            l_xoff = ((unsigned)(n * a.Ci + ci0 + wave * 16 + r5) * (unsigned)HW + (unsigned)l_rem) * 4u;
-        }
     }
     // horizontal-tap X rows: lane -> (row r7, quad q7 of 6: pixels [p0 - 4, p0 + 20); q7 == 6 is the padding quad)
     const int q7 = lane % 7, r7 = lane / 7;
     int h_m = 0, h_rem = 0;
     unsigned h_xoff = 0;
-    if (!VT) {
-        h_m = step_begin * BP + 4 * ((q7 < 6 ? q7 : 5) - 1);
-        const int n = h_m < 0 ? -1 : h_m / HW;
-        h_rem = h_m - n * HW;
-        h_xoff = (unsigned)(((n * a.Ci + ci0 + wave * 16 + r7) * HW + h_rem + dr * W) * 4);
-    }
+    h_m = step_begin * BP + 4 * ((q7 < 6 ? q7 : 5) - 1);
+    const int n = h_m < 0 ? -1 : h_m / HW;
+    h_rem = h_m - n * HW;
+    h_xoff = (unsigned)(((n * a.Ci + ci0 + wave * 16 + r7) * HW + h_rem + dr * W) * 4);
     const unsigned lds_g = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Gs);
     const unsigned lds_x = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Xs);
 
@@ -137,45 +130,24 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
                 if (q5 < 4 && r5 < rows) dma16(a.dy + (size_t)(12 * i) * HW, v, dst + (unsigned)(12 * i * LDG * 4));
             }
         }
-        if (VT) {
+        // (3x3: a quad whose shifted row leaves the image is never used — any mapped address)
+        const unsigned v = (h_m >= 0 && h_m < M && (!K33 || (unsigned)(h_rem + dr * W) < (unsigned)HW)) ? h_xoff : 0u;
+        const unsigned dst = lds_x + (unsigned)((slot * X_STAGE + wave * 16 * LDX) * 4);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int ih = l_oh + r - 1;
-                const bool ok = (unsigned)ih < (unsigned)H;
-                // (an out-of-image row: the centre row instead, mapped and never read)
-                const unsigned v = l_m < M ? (ok ? l_xoff + (unsigned)((r - 1) * W * 4) : l_xoff) : 0u;
-                const unsigned dst = lds_x + (unsigned)((slot * X_STAGE + (r * 64 + wave * 16) * LDX) * 4);
-#pragma unroll
-                for (int i = 0; i < NJX1; ++i) {
-                    const int rows = 16 - 12 * i < 12 ? 16 - 12 * i : 12;
-                    if (q5 < 4 && r5 < rows) dma16(a.x + (size_t)(12 * i) * HW, v, dst + (unsigned)(12 * i * LDX * 4));
-                }
-            }
-        } else {
-            // (3x3: a quad whose shifted row leaves the image is never used — any mapped address)
-            const unsigned v = (h_m >= 0 && h_m < M && (!K33 || (unsigned)(h_rem + dr * W) < (unsigned)HW)) ? h_xoff : 0u;
-            const unsigned dst = lds_x + (unsigned)((slot * X_STAGE + wave * 16 * LDX) * 4);
-#pragma unroll
-            for (int i = 0; i < NJX1; ++i) {
-                const int rows = 16 - 9 * i < 9 ? 16 - 9 * i : 9;
-                if (q7 < 6 && r7 < rows) dma16(a.x + (size_t)(9 * i) * HW, v, dst + (unsigned)(9 * i * LDX * 4));
-            }
+        for (int i = 0; i < NJX1; ++i) {
+            const int rows = 16 - 9 * i < 9 ? 16 - 9 * i : 9;
+            if (q7 < 6 && r7 < rows) dma16(a.x + (size_t)(9 * i) * HW, v, dst + (unsigned)(9 * i * LDX * 4));
         }
+    
         // advance the quad by one step
         l_m += BP; l_rem += BP; l_goff += BP * 4;
-        if (VT) { l_xoff += BP * 4; l_ow += BP; }
         if (l_rem >= HW) {
             l_rem -= HW;
             l_goff += (unsigned)((a.Co - 1) * HW) * 4u;
-            if (VT) l_xoff += (unsigned)((a.Ci - 1) * HW) * 4u;
         }
-        if (VT) {
-            if (l_ow >= W) { l_ow -= W; ++l_oh; }
-            if (l_oh >= H) l_oh -= H;
-        } else {
-            h_m += BP; h_rem += BP; h_xoff += BP * 4;
-            if (h_rem >= HW) { h_rem -= HW; h_xoff += (unsigned)((a.Ci - 1) * HW) * 4u; }
-        }
+        h_m += BP; h_rem += BP; h_xoff += BP * 4;
+        if (h_rem >= HW) { h_rem -= HW; h_xoff += (unsigned)((a.Ci - 1) * HW) * 4u; }
+    
     };
 
     // ---------------------------------------------------------------- reader state
@@ -205,7 +177,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     // set S holds the operands of one step: dY [mi][8 pixels]; X: 16 row elements + the 4 row-end variants (horizontal
     // taps) or [tap][8 pixels] (vertical taps).  The set of step s + 1 is read from LDS under the MFMAs of step s.
     float av[2][MCO][8];
-    float bx[2][VT ? 24 : 20];
+    float bx[2][20];
     int r_step = step_begin;
     auto read_frags = [&](auto SET, int slot) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
@@ -225,38 +197,25 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
             av[S][mi][0] = u0.x; av[S][mi][1] = u0.y; av[S][mi][2] = u0.z; av[S][mi][3] = u0.w;
             av[S][mi][4] = u1.x; av[S][mi][5] = u1.y; av[S][mi][6] = u1.z; av[S][mi][7] = u1.w;
         }
-        if (VT) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const bool ok0 = (unsigned)(r_oh + r - 1) < (unsigned)H;
-                const bool ok1 = (unsigned)(oh1 + r - 1) < (unsigned)H;
-                const float* p0 = ok0 ? xs + rd_x + r * 64 * LDX : Zs;
-                const float* p1 = ok1 ? xs + rd_x + r * 64 * LDX + 4 : Zs;
-                const float4 u0 = *reinterpret_cast<const float4*>(p0);
-                const float4 u1 = *reinterpret_cast<const float4*>(p1);
-                bx[S][8 * r + 0] = u0.x; bx[S][8 * r + 1] = u0.y; bx[S][8 * r + 2] = u0.z; bx[S][8 * r + 3] = u0.w;
-                bx[S][8 * r + 4] = u1.x; bx[S][8 * r + 5] = u1.y; bx[S][8 * r + 6] = u1.z; bx[S][8 * r + 7] = u1.w;
-            }
-        } else {
-            // bx[i] = pixel 8*khalf + i - 4 of the step (row position 8*khalf + i), i < 16
-            // (3x3: quads 0, 1 lie in the first quad's image row wherever their values are used, quads 2, 3 in the second's)
-            bool okA = true, okB = true;
-            if constexpr (K33) {
-                okA = (unsigned)(r_oh + dr) < (unsigned)H;
-                okB = (unsigned)(oh1 + dr) < (unsigned)H;
-            }
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const float* px = (qd < 2 ? okA : okB) ? xs + rd_x + 4 * qd : Zs;
-                const float4 u = *reinterpret_cast<const float4*>(px);
-                bx[S][4 * qd] = u.x; bx[S][4 * qd + 1] = u.y; bx[S][4 * qd + 2] = u.z; bx[S][4 * qd + 3] = u.w;
-            }
-            // left neighbours of the quads' first pixels / right neighbours of their last pixels: zero at the row ends
-            bx[S][16] = r_ow == 0 ? 0.f : bx[S][3];
-            bx[S][17] = ow1 == 0 ? 0.f : bx[S][7];
-            bx[S][18] = r_ow == W - 4 ? 0.f : bx[S][8];
-            bx[S][19] = ow1 == W - 4 ? 0.f : bx[S][12];
+        // bx[i] = pixel 8*khalf + i - 4 of the step (row position 8*khalf + i), i < 16
+        // (3x3: quads 0, 1 lie in the first quad's image row wherever their values are used, quads 2, 3 in the second's)
+        bool okA = true, okB = true;
+        if constexpr (K33) {
+            okA = (unsigned)(r_oh + dr) < (unsigned)H;
+            okB = (unsigned)(oh1 + dr) < (unsigned)H;
         }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float* px = (qd < 2 ? okA : okB) ? xs + rd_x + 4 * qd : Zs;
+            const float4 u = *reinterpret_cast<const float4*>(px);
+            bx[S][4 * qd] = u.x; bx[S][4 * qd + 1] = u.y; bx[S][4 * qd + 2] = u.z; bx[S][4 * qd + 3] = u.w;
+        }
+        // left neighbours of the quads' first pixels / right neighbours of their last pixels: zero at the row ends
+        bx[S][16] = r_ow == 0 ? 0.f : bx[S][3];
+        bx[S][17] = ow1 == 0 ? 0.f : bx[S][7];
+        bx[S][18] = r_ow == W - 4 ? 0.f : bx[S][8];
+        bx[S][19] = ow1 == W - 4 ? 0.f : bx[S][12];
+    
         if (do_bias && t < TCO) {
             const int mq = r_step * BP;
             float4 v[4];
@@ -281,34 +240,30 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     };
     auto mfmas = [&](auto SET) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
-        if constexpr (WINO) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {           // the lane's four pixel pairs: pixels (2j, 2j + 1) = bx[4 + 2j], bx[5 + 2j]
-                const float d0 = j == 0 ? bx[S][16] : (j == 2 ? bx[S][17] : bx[S][3 + 2 * j]);
-                const float d1 = bx[S][4 + 2 * j], d2 = bx[S][5 + 2 * j];
-                const float d3 = j == 1 ? bx[S][18] : (j == 3 ? bx[S][19] : bx[S][6 + 2 * j]);
-                const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
+        for (int j = 0; j < 4; ++j) {           // the lane's four pixel pairs: pixels (2j, 2j + 1) = bx[4 + 2j], bx[5 + 2j]
+            const float d0 = j == 0 ? bx[S][16] : (j == 2 ? bx[S][17] : bx[S][3 + 2 * j]);
+            const float d1 = bx[S][4 + 2 * j], d2 = bx[S][5 + 2 * j];
+            const float d3 = j == 1 ? bx[S][18] : (j == 3 ? bx[S][19] : bx[S][6 + 2 * j]);
+            const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
 #pragma unroll
-                for (int mi = 0; mi < MCO; ++mi) {
-                    const float e0 = av[S][mi][2 * j], e1 = av[S][mi][2 * j + 1];
-                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, v0, acc[mi][0], 0, 0, 0);
-                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, v1, acc[mi][1], 0, 0, 0);
-                    acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, v2, acc[mi][2], 0, 0, 0);
-                    acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1, v3, acc[mi][3], 0, 0, 0);
-                }
+            for (int mi = 0; mi < MCO; ++mi) {
+                const float e0 = av[S][mi][2 * j], e1 = av[S][mi][2 * j + 1];
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, v0, acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, v1, acc[mi][1], 0, 0, 0);
+                acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, v2, acc[mi][2], 0, 0, 0);
+                acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1, v3, acc[mi][3], 0, 0, 0);
             }
-            return;
         }
+        return;
+    
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
             float b0, b1, b2;
-            if (VT) {
-                b0 = bx[S][pp]; b1 = bx[S][8 + pp]; b2 = bx[S][16 + pp];
-            } else {
-                b0 = pp == 0 ? bx[S][16] : (pp == 4 ? bx[S][17] : bx[S][3 + pp]);
-                b1 = bx[S][4 + pp];
-                b2 = pp == 3 ? bx[S][18] : (pp == 7 ? bx[S][19] : bx[S][5 + pp]);
-            }
+            b0 = pp == 0 ? bx[S][16] : (pp == 4 ? bx[S][17] : bx[S][3 + pp]);
+            b1 = bx[S][4 + pp];
+            b2 = pp == 3 ? bx[S][18] : (pp == 7 ? bx[S][19] : bx[S][5 + pp]);
+        
 #pragma unroll
             for (int mi = 0; mi < MCO; ++mi) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][mi][pp], b0, acc[mi][0], 0, 0, 0);
 #pragma unroll
@@ -362,35 +317,23 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
             for (int j = 0; j < 16; ++j) {
                 const int co = co0 + wave_co * 32 * MCO + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
                 float v;
-                if constexpr (WINO) {                // output transform (m2, m3 were accumulated without their 1/2)
-                    const float hs = 0.5f * (acc[mi][1][j] + acc[mi][2][j]);
-                    v = s == 0 ? acc[mi][0][j] + hs : (s == 1 ? 0.5f * (acc[mi][1][j] - acc[mi][2][j]) : hs - acc[mi][3][j]);
-                } else {
-                    v = acc[mi][s][j];
-                }
+            // output transform (m2, m3 were accumulated without their 1/2)
+                const float hs = 0.5f * (acc[mi][1][j] + acc[mi][2][j]);
+                v = s == 0 ? acc[mi][0][j] + hs : (s == 1 ? 0.5f * (acc[mi][1][j] - acc[mi][2][j]) : hs - acc[mi][3][j]);
+            
                 out[(size_t)co * rowlen + col] = v;
             }
     }
 }
 
-static int env_int_v6(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s ? atoi(s) : dflt;
-}
-
 // geometry only (pointer alignment is the launcher's business)
 bool wgrad_v6_shape_ok(const dynmm_conv_geom* g) {
-    static const int off = env_int_v6("DYNMM_WGRAD_NO_V6", 0);
-    if (off) return false;
     const bool h_taps = g->KH == 1 && g->KW == 3 && g->PH == 0 && g->PW == 1;
     const bool v_taps = g->KH == 3 && g->KW == 1 && g->PH == 1 && g->PW == 0;
-    static const int wino33 = env_int_v6("DYNMM_WGRAD_WINO", 1);
-    const bool k33 = wino33 && g->KH == 3 && g->KW == 3 && g->PH == 1 && g->PW == 1 && g->H >= 2;     // (the Winograd form only)
+    const bool k33 = g->KH == 3 && g->KW == 3 && g->PH == 1 && g->PW == 1 && g->H >= 2;
     if (!h_taps && !v_taps && !k33) return false;
     if (g->SH != 1 || g->SW != 1 || g->H != g->Ho || g->W != g->Wo || g->c_split != g->Ci) return false;
     if (g->W % 4 != 0 || g->W < 16 || g->Ci % 64 != 0 || g->Co % 64 != 0) return false;
-    static const int min_co = env_int_v6("DYNMM_WGRAD_V6_MIN_CO", 64);
-    if (g->Co < min_co) return false;
     // 32-bit byte offsets inside one tensor, signed pixel counters
     const unsigned long long cmax = (unsigned long long)(g->Ci > g->Co ? g->Ci : g->Co);
     if ((unsigned long long)g->N * cmax * g->H * g->W * 4ull >= (1ull << 31)) return false;
@@ -399,49 +342,29 @@ bool wgrad_v6_shape_ok(const dynmm_conv_geom* g) {
 
 int wgrad_v6_tco(const dynmm_conv_geom* g) { return g->Co % 128 == 0 ? 128 : 64; }
 
-// workgroups per CU the launcher compiles the kernel for; the plan sizes one residency round with it.  Vertical taps:
-// three X row sets per stage, 60 / 75 KB of LDS per workgroup -> 2.  Horizontal taps: 128-row tiles hold 96 accumulators
-// and two fragment sets (2 waves per SIMD), 64-row tiles half of that (3).
+// workgroups per CU the launcher compiles the kernel for; the plan sizes one residency round with it.  Vertical taps
+// (conv_wgrad_wino_vt.hip): 2.  Horizontal taps: 128-row tiles hold 128 accumulators (2 waves per SIMD), 64-row tiles half of that (3).
 int wgrad_v6_occupancy(const dynmm_conv_geom* g) {
-    static const int occ_env = env_int_v6("DYNMM_WGRAD_V6_OCC", 0);
     if (g->KH == 3 && g->KW == 1) return 2;
-    static const int wino = env_int_v6("DYNMM_WGRAD_WINO", 1);
-    if (wino) return g->Co % 128 == 0 ? 2 : 3;
-    if (occ_env == 2 || occ_env == 3) return occ_env;
     return g->Co % 128 == 0 ? 2 : 3;
 }
 
-bool wgrad_wino_vt_on(const dynmm_conv_geom* g);
 void launch_wgrad_wino_vt(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t st);
 
+// Every eligible geometry runs the Winograd form since round 4; the direct instantiations (three contractions per pixel, the
+// DYNMM_WGRAD_WINO=0 / _V6_OCC / _V6_MIN_CO / _NO_V6 switches that kept them reachable) were removed in round 5.
 void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int occ, hipStream_t st) {
-    const bool vt = a.KH == 3 && a.KW == 1;
-    if (a.KH == 3 && a.KW == 3) {                   // one vertical tap per workgroup, horizontal Winograd pairs
-        if (a.Co % 128 == 0) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, false, 3, 2, true, true>), grid, dim3(256), 0, st, a, grp);
-        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, false, 3, 3, true, true>), grid, dim3(256), 0, st, a, grp);
-        return;
-    }
-    {
-        dynmm_conv_geom g{};
-        g.KH = a.KH; g.KW = a.KW;
-        if (vt && wgrad_wino_vt_on(&g)) {           // conv_wgrad_wino_vt.hip (the plan sized the grid for its 8-position steps)
-            launch_wgrad_wino_vt(a, grp, grid, st);
-            return;
-        }
-    }
+    (void)occ;
     const bool two = a.Co % 128 == 0;
-    static const int wino = env_int_v6("DYNMM_WGRAD_WINO", 1);
-    if (wino && !vt) {                              // horizontal taps: the Winograd form (2 workgroups per CU: 4 accumulators per block)
-        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, false, 3, 2, true>), grid, dim3(256), 0, st, a, grp);
-        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, false, 3, 3, true>), grid, dim3(256), 0, st, a, grp);
-        return;
+    if (a.KH == 3 && a.KW == 1) {                   // vertical taps: pair positions (conv_wgrad_wino_vt.hip)
+        launch_wgrad_wino_vt(a, grp, grid, st);
+    } else if (a.KH == 3 && a.KW == 3) {            // one vertical tap per workgroup, horizontal Winograd pairs
+        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, 3, 2, true>), grid, dim3(256), 0, st, a, grp);
+        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, 3, 3, true>), grid, dim3(256), 0, st, a, grp);
+    } else {                                        // horizontal taps
+        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, 3, 2, false>), grid, dim3(256), 0, st, a, grp);
+        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, 3, 3, false>), grid, dim3(256), 0, st, a, grp);
     }
-#define DYNMM_V6(MCO, VT, OCC) hipLaunchKernelGGL((conv_wgrad_v6_kernel<MCO, VT, 3, OCC>), grid, dim3(256), 0, st, a, grp)
-#define DYNMM_V6_O(MCO, VT) do { if (occ == 3) DYNMM_V6(MCO, VT, 3); else DYNMM_V6(MCO, VT, 2); } while (0)
-    if (two) { if (vt) DYNMM_V6(2, true, 2); else DYNMM_V6_O(2, false); }
-    else     { if (vt) DYNMM_V6(1, true, 2); else DYNMM_V6_O(1, false); }
-#undef DYNMM_V6_O
-#undef DYNMM_V6
 }
 
 }  // namespace dynmm

@@ -8,7 +8,8 @@
 // measured against fp64 (scratch/r4/wino43_numerics.py; tests/test_hip_ops.py on the GPU) the result is 1.7e-6 .. 2.8e-6 from
 // the truth in max-norm where a direct fp32 sum is 2e-7 .. 3e-7.  That is why this form serves the BACKWARD only — an input
 // gradient is compared with its fp64 value at 2e-4 (GTOL) and enters a gradient whose fp32 conditioning noise is 1e-2 (DESIGN.md
-// section 1); forward passes (training: direct; inference: F(2,3)) never see it.
+// section 1); forward passes (F(2,3), conv_wino.hip) never see it.  Horizontal taps only (1x3, and 3x3 with the vertical taps looped): the
+// vertical form of round 4 — six input rows per four output rows — measured slower than F(2,3) and was removed in round 5.
 //
 // Structure = conv_wino.hip's small tile: 64 co x 64 quads per workgroup, a wave owns 32 co x 32 quads x 6 transforms = 6
 // accumulator blocks (96 registers, two workgroups per CU); operands by direct global -> LDS loads into a 3-slot ring (8 channels
@@ -16,9 +17,8 @@
 //   * filter operand: two planes [tap row][ci][co][4] (U0..U3) and [tap row][ci][co][2] (U4, U5): one ds_read_b128 + one
 //     ds_read_b64 per k-pair;
 //   * horizontal taps: raw tile [8 channels][4 * quads + 8] pixels (16-byte quads, 4-pixel halo either side), a lane reads
-//     d0 | (d1..d4) | d5; vertical taps: [8 channels][6 input rows][quads] — six rows per four output rows (1.5 per row);
-//   * zero padding by lane-constant selects on the raw values (a row / column outside the image; an H that is no multiple of 4
-//     leaves the last quad with dead output rows), a whole vertical tap of a 3x3 filter outside the image reads a zero slot;
+//     d0 | (d1..d4) | d5;
+//   * zero padding by lane-constant selects on the raw values (a column outside the image), a whole vertical tap of a 3x3 filter outside the image reads a zero slot;
 //   * epilogue: output transform, ReLU mask of the producer, accumulated residual gradient; horizontal quads are 16-byte
 //     stores; the epilogue operands of batch b + 1 (4 channels x 4 outputs) are requested before batch b is stored.
 #include <stdlib.h>
@@ -38,19 +38,17 @@ struct Wino43Args {
     int N, Ci, Co, H, W;
     int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
     int MQ;                 // output quads
-    int H4;                 // vertical taps: row quads per image, (H + 3) / 4
     int n_co_tiles, n_q_tiles;
 };
 
 // KR3: 3x3 filter (a template flag since round 5, as in conv_wino.hip: the three-tap launches carry no tap bookkeeping)
-template <bool VERT, bool KR3 = false>
+template <bool KR3 = false>
 __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a) {
-    static_assert(!KR3 || !VERT, "3x3 filters run on the horizontal quad form");
     constexpr int BK = 8, S = 3, TCO = 64, TQ = 64, NT = 6;
     constexpr int A4_STAGE = BK * TCO * 4, A2_STAGE = BK * TCO * 2;         // floats
     constexpr int PIXW = 4 * TQ + 8;
-    constexpr int B_STAGE = VERT ? BK * 6 * TQ : BK * PIXW;
-    constexpr int QPR = VERT ? TQ / 4 : PIXW / 4;
+    constexpr int B_STAGE = BK * PIXW;
+    constexpr int QPR = PIXW / 4;
     constexpr int QB = B_STAGE / 4, QPW = QB / 4;
     constexpr int NIB = (QPW + 63) / 64;
     constexpr int NI = 3 + NIB;                                             // per wave and stage: 2 rows of U0..3, 2 rows of U4,5, the tile
@@ -85,29 +83,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         const int ql = i * 64 + lane;
         b_act[i] = ql < QPW;
         const int q = wave * QPW + (b_act[i] ? ql : 0);
-        if constexpr (VERT) {
-            const int k = q / (6 * QPR), j = (q / QPR) % 6, gq = q % QPR;
-            int p = q0 + 4 * gq;
-            p = p > a.MQ - 4 ? a.MQ - 4 : p;
-            const int per = a.H4 * a.W;
-            const int n = p / per, rr = p - n * per;
-            const int r4 = rr / a.W, w = rr - r4 * a.W;
-            const int row = 4 * r4 - 1 + j;
-            const int rowc = (row >= 0 && row < a.H) ? row : 4 * r4;
-            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)(rowc * a.W + w)) * 4u;
-        } else {
-            const int k = q / QPR, quad = q - k * QPR;
-            const int M = 4 * a.MQ;
-            int m = 4 * q0 - 4 + 4 * quad;
-            m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
-            const int n = m / HW, rem = m - n * HW;
-            const int h = rem / a.W;
-            b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
-            if constexpr (KR3) {
-                for (int r = 0; r < 3; ++r) {
-                    const int hh = h + dh_of(r);
-                    b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
-                }
+        const int k = q / QPR, quad = q - k * QPR;
+        const int M = 4 * a.MQ;
+        int m = 4 * q0 - 4 + 4 * quad;
+        m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
+        const int n = m / HW, rem = m - n * HW;
+        const int h = rem / a.W;
+        b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
+        if constexpr (KR3) {
+            for (int r = 0; r < 3; ++r) {
+                const int hh = h + dh_of(r);
+                b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
             }
         }
     }
@@ -168,43 +154,28 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     const bool qvalid = qg < a.MQ;
     int pn, prem;                                 // image and pixel offset of the quad's first output
     bool dv[6];                                   // d_j lies inside the image
-    bool ov[4];                                   // output j exists (vertical taps: H % 4 != 0)
     unsigned rbits = 7u;
     {
         const int pc = qvalid ? qg : 0;
-        if constexpr (VERT) {
-            const int per = a.H4 * a.W;
-            pn = pc / per;
-            const int rr = pc - pn * per;
-            const int r4 = rr / a.W, w = rr - r4 * a.W;
-            prem = 4 * r4 * a.W + w;
+        const int m = 4 * pc;
+        pn = m / HW;
+        prem = m - pn * HW;
+        const int h = prem / a.W, w = prem - h * a.W;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) dv[j] = (unsigned)(4 * r4 - 1 + j) < (unsigned)a.H;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ov[j] = 4 * r4 + j < a.H;
-        } else {
-            const int m = 4 * pc;
-            pn = m / HW;
-            prem = m - pn * HW;
-            const int h = prem / a.W, w = prem - h * a.W;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) dv[j] = true;
-            dv[0] = w > 0;
-            dv[5] = w + 4 < a.W;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ov[j] = true;
-            if constexpr (KR3) {
-                rbits = 0;
-                for (int r = 0; r < 3; ++r) {
-                    const int hh = h + dh_of(r);
-                    rbits |= (hh >= 0 && hh < a.H) ? (1u << r) : 0u;
-                }
+        for (int j = 0; j < 6; ++j) dv[j] = true;
+        dv[0] = w > 0;
+        dv[5] = w + 4 < a.W;
+        if constexpr (KR3) {
+            rbits = 0;
+            for (int r = 0; r < 3; ++r) {
+                const int hh = h + dh_of(r);
+                rbits |= (hh >= 0 && hh < a.H) ? (1u << r) : 0u;
             }
         }
     }
     const int a4_frag = (khalf * TCO + wave_co * 32 + l31) * 4;            // + 2q * TCO * 4
     const int a2_frag = (khalf * TCO + wave_co * 32 + l31) * 2;            // + 2q * TCO * 2
-    const int b_frag = VERT ? khalf * 6 * TQ + lq : khalf * PIXW + 4 * lq + 3;
+    const int b_frag = khalf * PIXW + 4 * lq + 3;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -222,17 +193,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     auto read_raw = [&](int set, int q, const float* A4p, const float* A2p, const float* Bp) {
         fa4[set] = *reinterpret_cast<const float4*>(A4p + a4_frag + 2 * q * TCO * 4);
         fa2[set] = *reinterpret_cast<const float2*>(A2p + a2_frag + 2 * q * TCO * 2);
-        if constexpr (VERT) {
-            const float* b = Bp + b_frag + 2 * q * 6 * TQ;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) fd[set][j] = b[j * TQ];
-        } else {
-            const float* b = Bp + b_frag + 2 * q * PIXW;
-            const float4 u = *reinterpret_cast<const float4*>(b + 1);
-            fd[set][0] = b[0];
-            fd[set][1] = u.x; fd[set][2] = u.y; fd[set][3] = u.z; fd[set][4] = u.w;
-            fd[set][5] = b[5];
-        }
+        const float* b = Bp + b_frag + 2 * q * PIXW;
+        const float4 u = *reinterpret_cast<const float4*>(b + 1);
+        fd[set][0] = b[0];
+        fd[set][1] = u.x; fd[set][2] = u.y; fd[set][3] = u.z; fd[set][4] = u.w;
+        fd[set][5] = b[5];
+    
     };
     auto transform = [&](int set) {
         float d[6];
@@ -321,7 +287,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     float* __restrict__ y_p = a.y;
     const bool has_res = res_p != nullptr, has_mask = mask_p != nullptr;
     const unsigned row_bytes = (unsigned)HW * 4u;
-    const unsigned step_bytes = VERT ? (unsigned)a.W * 4u : 4u;          // byte distance between the quad's outputs
     const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * 32 + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
     auto off_of = [&](int b, int e) {            // batch b: channels 8 b + 4 khalf + e, e = 0..3
         return off_base + (unsigned)(8 * b + e) * row_bytes;
@@ -339,21 +304,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         for (int e = 0; e < 4; ++e) {
             const unsigned off = off_of(b, e);
             if (!qvalid) continue;
-            if constexpr (VERT) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (has_mask && ov[j]) kk[set][e][j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off + j * step_bytes);
-                    if (has_res && ov[j]) rr[set][e][j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res_p) + off + j * step_bytes);
-                }
-            } else {
-                if (has_mask) {
-                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mask_p) + off);
-                    kk[set][e][0] = v.x; kk[set][e][1] = v.y; kk[set][e][2] = v.z; kk[set][e][3] = v.w;
-                }
-                if (has_res) {
-                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(res_p) + off);
-                    rr[set][e][0] = v.x; rr[set][e][1] = v.y; rr[set][e][2] = v.z; rr[set][e][3] = v.w;
-                }
+            if (has_mask) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mask_p) + off);
+                kk[set][e][0] = v.x; kk[set][e][1] = v.y; kk[set][e][2] = v.z; kk[set][e][3] = v.w;
+            }
+            if (has_res) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(res_p) + off);
+                rr[set][e][0] = v.x; rr[set][e][1] = v.y; rr[set][e][2] = v.z; rr[set][e][3] = v.w;
             }
         }
     };
@@ -384,13 +341,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned off = off_of(b, e);
-            if constexpr (VERT) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ov[j]) *reinterpret_cast<float*>(reinterpret_cast<char*>(y_p) + off + j * step_bytes) = yo[e][j];
-            } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<char*>(y_p) + off) = make_float4(yo[e][0], yo[e][1], yo[e][2], yo[e][3]);
-            }
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(y_p) + off) = make_float4(yo[e][0], yo[e][1], yo[e][2], yo[e][3]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -455,8 +406,8 @@ __global__ void __launch_bounds__(256) wino43_pack_kernel(const float* __restric
 static bool wino43_geom_ok(const dynmm_conv_geom* g) {
     if (!g || g->c_split != g->Ci) return false;
     if (g->SH != 1 || g->SW != 1) return false;
-    const bool k13 = g->KH == 1 && g->KW == 3, k31 = g->KH == 3 && g->KW == 1, k33 = g->KH == 3 && g->KW == 3;
-    if (!(k13 || k31 || k33)) return false;
+    const bool k13 = g->KH == 1 && g->KW == 3, k33 = g->KH == 3 && g->KW == 3;      // horizontal taps only (a vertical form was
+    if (!(k13 || k33)) return false;                                                // measured slower in round 4 and removed in round 5)
     if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
     if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
     if (g->Ci % 64 != 0 || g->Co % 8 != 0 || g->Co < 24) return false;       // rows = Ci (64-row tile), reduction = Co
@@ -513,18 +464,15 @@ extern "C" int dynmm_conv2d_wino43_dgrad(const float* dy, const float* ut, const
          reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(accum)) & 15u)
         return DYNMM_EUNSUPPORTED;
     const int KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
-    const bool vert = g->KW == 1;
     Wino43Args a{};
     a.x = dy; a.ut4 = ut; a.ut2 = ut + (size_t)KR * g->Co * g->Ci * 4; a.residual = accum; a.mask = mask; a.y = dx;
     a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;          // the roles of the channel counts swap
     a.KR = KR;
-    a.H4 = (a.H + 3) / 4;
-    a.MQ = vert ? a.N * a.H4 * a.W : a.N * a.H * a.W / 4;
+    a.MQ = a.N * a.H * a.W / 4;
     a.n_co_tiles = a.Co / 64;
     a.n_q_tiles = ceil_div(a.MQ, 64);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_q_tiles));
-    if (vert) hipLaunchKernelGGL((conv_wino43_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (KR == 3) hipLaunchKernelGGL((conv_wino43_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (KR == 3) hipLaunchKernelGGL((conv_wino43_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_wino43_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;

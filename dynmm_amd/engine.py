@@ -11,7 +11,6 @@
 """
 import contextlib
 import ctypes as C
-import os
 
 import torch
 
@@ -283,7 +282,7 @@ class TrainStep:
 
     def __init__(self, model, class_weight, lr, momentum=0.9, weight_decay=1e-4, loss_ratio=0.0,
                  flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True, optimizer='SGD',
-                 overlap=True, fuse_tail=None):
+                 overlap=True, fuse_tail=None, prepack=True):
         self.model = model
         self.cw = torch.as_tensor(class_weight, dtype=torch.float32, device=next(model.parameters()).device)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
@@ -305,8 +304,8 @@ class TrainStep:
         # 3-stream schedule: RGB encoder | depth encoder | conv weight gradients (see nn/net.py, ops.py)
         self.multi_stream = bool(multi_stream)
         # None: on unless DYNMM_NO_FUSED_TAIL is set (A/B switch for bench.py / tests)
-        self.fuse_tail = (os.environ.get('DYNMM_NO_FUSED_TAIL') is None) if fuse_tail is None else bool(fuse_tail)
-        self.prepack = ops.PackedWeights() if os.environ.get('DYNMM_NO_PREPACK') is None else None
+        self.fuse_tail = True if fuse_tail is None else bool(fuse_tail)
+        self.prepack = ops.PackedWeights() if prepack else None
         if hasattr(model, 'dual_stream'):
             model.dual_stream = self.multi_stream
         self.loss_ratio, self.flop_budget = float(loss_ratio), float(flop_budget)

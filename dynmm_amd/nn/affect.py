@@ -23,7 +23,6 @@ in_proj_weight`, ...), so `expert.state_dict()` of a trained MultiBench module l
 stream of its own (ops.manual_seed; torch's generator cannot be reproduced bit for bit, the tests inject the keep flags
 on both sides); `.eval()` switches it off as in torch.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -35,8 +34,8 @@ FEATURES = {'visual': 35, 'audio': 74, 'text': 300}      # CMU-MOSEI (affect/cou
 # The gate transformer and the experts' encoders are independent until the mixture: each runs on a HIP stream of its own
 # (five 5-layer transformers on 50-token sequences are chains of ~10-100 us kernels that do not fill 256 CUs one at a time).
 # Autograd replays a node on its forward stream, so the backward is concurrent too; a captured step keeps the branches as
-# parallel paths of the hipGraph.  DYNMM_AFFECT_STREAMS=0: one stream.
-BRANCH_STREAMS = os.environ.get('DYNMM_AFFECT_STREAMS', '1') != '0'
+# parallel paths of the hipGraph.
+BRANCH_STREAMS = True     # (module attribute; False: one stream)
 _POOL, _ALL = [], []
 
 

@@ -7,7 +7,6 @@ fallback.
 """
 import contextlib
 import ctypes as C
-import os as _os
 
 import torch
 from torch.autograd import Function
@@ -43,39 +42,30 @@ def _chk(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Three-tap convolutions by 1-D Winograd F(2,3) (csrc/conv_wino.hip: 2/3 of the matrix-core work, fp32): which passes of the
-# stride-1 1x3 / 3x1 / 3x3 convolutions with Ci, Co % 64 == 0 use it.
-#   'all'   (default) forward — training and inference — and input gradients.  The training forward in this form is closer to
-#           the fp64 result than the direct kernels on every shape tried (1.0e-6 vs 1.35e-6 on the decoder module's outputs)
-#           and takes ReLU decisions at rounding-level pre-activations differently from them about as often as either differs
-#           from fp64 (tests/flip_probe.py: 12 draws, direct 6 flips, Winograd 5); step 71.8 -> 67.9 ms;
-#   'dgrad' the input gradients only (the training forward on the direct operand-ring kernels: the round's earlier default);
-#   'fwd'   forward only;   '0' off (operand-ring kernels everywhere).
-WINO = _os.environ.get('DYNMM_WINO', 'all')
-# Inference (no gradient recorded: conv2d_fused_eval) is a continuous function of its roundings — no decision is
-# differentiated — so its forward takes the Winograd kernels whenever they are on at all (DYNMM_WINO_INFER=0: direct).
-WINO_INFER = _os.environ.get('DYNMM_WINO_INFER', '1') != '0'
-if WINO not in ('0', 'dgrad', 'fwd', 'all'):
-    raise ValueError(f'DYNMM_WINO={WINO!r}: expected 0 | dgrad | fwd | all')
-# BatchNorm batch statistics from the epilogue of the convolution that feeds the BatchNorm (csrc/conv_wino.hip STATS: the horizontal
-# Winograd forward) instead of a bn_stats launch + a pass over the conv output: DYNMM_CONV_BN_STATS=0 switches it off.
-CONV_BN_STATS = _os.environ.get('DYNMM_CONV_BN_STATS', '1') != '0'
-# Input gradients: F(2,3) ('23', conv_wino.hip: 2/3 of the direct matrix work, error class of a direct fp32 sum) or F(4,3)
-# (conv_wino43.hip: 1/2 of the work, 1e-6 .. 4e-6 from fp64) — '43' everywhere it fits, '43h' (default) for the horizontal-tap
-# filters 1x3 / 3x3 only.  Measured (alternating runs on one box, scratch/r4/ab.sh): 71.95 ms with '23', 71.63 with '43h', 72.37
-# with '43' — the vertical form stages six input rows per four output rows through b32 reads and loses more to that than it
-# gains; the horizontal form's isolated launches are no faster either (6.9 vs 6.2 ms per step: transform + epilogue overhead at
-# two workgroups per CU), the step gains because the backward's three streams share one matrix pipe.
-WINO_DGRAD = _os.environ.get('DYNMM_WINO_DGRAD', '43h')
-if WINO_DGRAD not in ('23', '43', '43h'):
-    raise ValueError(f'DYNMM_WINO_DGRAD={WINO_DGRAD!r}: expected 23 | 43 | 43h')
+# Three-tap / 3x3 convolutions by 1-D Winograd F(2,3) (csrc/conv_wino.hip: 2/3 of the matrix-core work, fp32) — forward (training
+# and inference), input gradients and weight gradients of every stride-1 1x3 / 3x1 / 3x3 convolution the kernels' geometry rules
+# admit; everything else (and a pass switched off here) runs on the operand-ring / tile kernels, which therefore stay in the
+# library either way.  These are MODULE ATTRIBUTES — caller options used by the parity tests (tests/test_hip_ops.py:
+# test_conv2d_winograd runs every mode) — not environment switches:
+#   WINO        'all' (default) | 'dgrad' (input gradients only: direct training forward) | 'fwd' | '0'.  The training forward in
+#               the Winograd form is closer to the fp64 result than the direct kernels on every shape tried (1.0e-6 vs 1.35e-6 on
+#               the decoder module's outputs); inference always takes it when WINO != '0'.
+#   WINO_DGRAD  '43h' (default): F(4,3) (csrc/conv_wino43.hip: 1/2 of the work, 1e-6 .. 4e-6 from fp64) for the input gradients of
+#               the horizontal-tap filters 1x3 / 3x3, F(2,3) for the vertical ones | '23': F(2,3) everywhere.  (A vertical F(4,3)
+#               form existed in round 4 — six input rows per four output rows through b32 reads, 72.37 ms against 71.63 — and was
+#               removed in round 5.)
+#   CONV_BN_STATS  BatchNorm batch statistics from the epilogue of the convolution that feeds the BatchNorm (conv_wino.hip STATS)
+#               instead of a bn_stats launch + a pass over the conv output.
+WINO = 'all'
+WINO_DGRAD = '43h'
+CONV_BN_STATS = True
 _WINO_OK = {}
 _WINO43_OK = {}
 
 
 def _wino43(g):
     """input gradient of this convolution on the F(4,3) kernel?  (only consulted where _wino(g, True) holds)"""
-    if WINO_DGRAD == '23' or (WINO_DGRAD == '43h' and g.KW != 3):
+    if WINO_DGRAD == '23' or g.KW != 3:
         return False
     key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
     ok = _WINO43_OK.get(key)
@@ -88,10 +78,7 @@ def _wino(g, dgrad, x2=None, infer=False):
     """does this pass of this convolution run on the Winograd kernels?"""
     if WINO == '0' or x2 is not None:
         return False
-    if infer:
-        if not WINO_INFER:
-            return False
-    elif (WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad):
+    if not infer and ((WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad)):
         return False
     key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split, bool(dgrad))
     ok = _WINO_OK.get(key)
@@ -113,7 +100,7 @@ DIRECT_GRAD = False
 # the main backward chain and fills its ramp-up / tail bubbles.  Tensors it reads are kept alive in
 # _INFLIGHT until join_async() (call it after backward, on the stream that consumes the gradients).
 ASYNC_WGRAD = False
-WGRAD_STREAMS = int(_os.environ.get('DYNMM_WGRAD_STREAMS', '2'))
+WGRAD_STREAMS = 2        # weight-gradient side streams (scratch/r4/knob_sweep.sh: 1 / 2 / 3 within 0.4 ms)
 _WGRAD_POOL = []
 _WGRAD_RR = [0]
 _INFLIGHT = []
@@ -140,8 +127,8 @@ def join_async():
 # consecutive residual blocks, RGB and depth encoder alike) go out as ONE launch.  Queues are flushed by join_async()
 # at the end of backward at the latest; the parameters are reported to the gradient reducer when their launch is
 # actually enqueued.
-WGRAD_GROUP = int(_os.environ.get('DYNMM_WGRAD_GROUP', '4'))
-WGRAD_GROUP_AGE = int(_os.environ.get('DYNMM_WGRAD_GROUP_AGE', '4'))
+WGRAD_GROUP = 4
+WGRAD_GROUP_AGE = 4
 _WGRAD_QUEUES = {}
 _CAPTURE_EVENTS = []       # events recorded while a stream capture was in progress (kept alive: see _queue_wgrad)
 _WGRAD_TICK = [0]          # conv backward calls seen; a queue that got nothing for WGRAD_GROUP_AGE of them is flushed
@@ -309,7 +296,6 @@ def _tile(co, m=1 << 30):
     return '64x128' if co > 32 else '32x256'
 
 
-_SMALL_DIRECT = _os.environ.get('DYNMM_NO_SMALL_CO') is None
 
 
 def _timed(kind, g, call, nprob=1, extra=0, wino=False):
@@ -338,7 +324,7 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
     if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction
         name = f'conv_wino{"43" if wino == 43 else ""}_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}{"s2" if g.SH * g.SW > 1 else ""}>'
-    if kind == 'fwd' and _SMALL_DIRECT:          # conv_small.hip: *_eligible (the library's own dispatch rules)
+    if kind == 'fwd':                            # conv_small.hip: *_eligible (the library's own dispatch rules)
         k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
         if k5 and 5 <= g.Co <= 8 and g.Ci % 4 == 0 and g.Ci >= 16 and (g.c_split == g.Ci or g.c_split % (g.Ci // 4) == 0):
             name = 'conv_co8_fwd<direct,valu>'
@@ -412,7 +398,7 @@ class BNLink:
         self.x = self.mean = self.invstd = self.gamma = self.beta = self.sums = None
 
 
-BN_BWD_FUSE = _os.environ.get('DYNMM_BN_BWD_FUSE', '1') != '0'
+BN_BWD_FUSE = True       # (module attribute: tests switch it to compare with the bn_bwd_reduce path)
 # BatchNorm + residual + ReLU (bn2 of every residual block): the ReLU decisions travel to the backward as one bit per element
 # instead of the 4-byte output tensor (tests / A-B: ops.BN_RELU_BITS = False)
 BN_RELU_BITS = True
@@ -753,7 +739,7 @@ class _FanOut(Function):
         return out, None
 
 
-_NO_FANOUT = bool(int(_os.environ.get('DYNMM_NO_FANOUT', '0')))     # A/B knob: let autograd accumulate pairwise
+_NO_FANOUT = False       # (tests / A-B: let autograd accumulate pairwise)
 
 
 def fan_out(x, n):
@@ -1399,8 +1385,8 @@ def stem_bn_fuse_pool(x_rgb, bn_rgb, x_depth, bn_depth, se_params=None):
                                  *(tuple(se_params) if use_se else ()))
 
 
-_FUSED_STEM_POOL = _os.environ.get('DYNMM_NO_FUSED_STEM_POOL') is None        # A/B switches
-_FUSED_STEM_BN = _os.environ.get('DYNMM_NO_FUSED_STEM_BN') is None
+_FUSED_STEM_POOL = True        # (module attributes: tests compare the fused stem with the unfused ops)
+_FUSED_STEM_BN = True
 
 
 def stem_bn_fuse_supported(h, w, bn_a, bn_b):

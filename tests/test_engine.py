@@ -451,12 +451,10 @@ def test_prepacked_weights_step_is_bit_identical(monkeypatch):
     cw = np.linspace(0.5, 1.5, 40).astype(np.float32)
     res = {}
     for pre in (True, False):
-        if not pre:
-            monkeypatch.setenv('DYNMM_NO_PREPACK', '1')
         m = hip_model('P_se', h, w, seed=4)
         m.train()
         m.temp, m.hard_gate = 1.0, False
-        step = engine.TrainStep(m, cw, lr=0.05, loss_ratio=1e-3)
+        step = engine.TrainStep(m, cw, lr=0.05, loss_ratio=1e-3, prepack=pre)
         assert (step.prepack is not None) == pre
         losses = [step(rgb, depth, labels)['total'].item() for _ in range(3)]
         torch.cuda.synchronize()

@@ -579,10 +579,11 @@ def test_conv2d_winograd(ops, mode, case):
     y_ref.backward(gy.double())
     dx_ref = xr.grad * (x > 0) + dres.double()
     old, old_d = ops.WINO, ops.WINO_DGRAD
-    # 'dgrad43': the input gradient by F(4,3) (csrc/conv_wino43.hip: half of the direct matrix work, 1e-6 .. 4e-6 from fp64 — held
-    # to the same GTOL) wherever the geometry fits; the other two modes pin F(2,3)
+    # 'dgrad43' = the product default WINO_DGRAD = '43h': the input gradient of the horizontal-tap filters (1x3, 3x3) by F(4,3)
+    # (csrc/conv_wino43.hip: half of the direct matrix work, 1e-6 .. 4e-6 from fp64 — held to the same GTOL), the vertical ones by
+    # F(2,3); the other two modes pin F(2,3) everywhere
     f43 = mode == 'dgrad43'
-    ops.WINO, ops.WINO_DGRAD = ('dgrad' if f43 else mode), ('43' if f43 else '23')
+    ops.WINO, ops.WINO_DGRAD = ('dgrad' if f43 else mode), ('43h' if f43 else '23')
     mode = 'dgrad' if f43 else mode
     calls = []
     lib = ops._lib()
@@ -601,7 +602,7 @@ def test_conv2d_winograd(ops, mode, case):
         ops.PROFILE = None
     torch.cuda.synchronize()
     names = [c[0] for c in calls]
-    assert any(n.startswith('conv_wino43_dgrad' if f43 else 'conv_wino_dgrad') for n in names), names
+    assert any(n.startswith('conv_wino43_dgrad' if (f43 and k[1] == 3) else 'conv_wino_dgrad') for n in names), names
     assert any(n.startswith('conv_wino_fwd') for n in names) == (mode == 'all'), names
     assert rel(y, y_ref) < TOL
     assert rel(xg.grad, dx_ref) < GTOL
