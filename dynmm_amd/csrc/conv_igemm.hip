@@ -1150,7 +1150,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
         p.bp = wgrad_wino_vt_on(g) ? 8 : 16;
         p.tco = wgrad_v6_tco(g);
         p.tk = 192;
-        p.n_co_tiles = g->Co / p.tco;
+        p.n_co_tiles = ceil_div(g->Co, p.tco);
         p.n_k_tiles = (g->KH == 3 && g->KW == 3 ? 3 : 1) * (g->Ci / 64);       // 3x3: one vertical tap per workgroup
         p.target = target6 ? target6 : 256 * wgrad_v6_occupancy(g);
         plan_splits(p, g, 1);

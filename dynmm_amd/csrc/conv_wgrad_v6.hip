@@ -107,6 +107,14 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
         l_rem = l_m - n * HW;
         l_goff = ((unsigned)(n * a.Co + co0 + wave * GW + r5) * (unsigned)HW + (unsigned)l_rem) * 4u;
     }
+    // Co is not a multiple of the 64-row tile (the 40-class conv_out, model.py:286): a dY row past Co is requested from row
+    // Co - 1 instead (every instruction is still issued: the hand-counted vmcnt relies on it) and read as the zero quad
+    unsigned g_adj[NJG];
+#pragma unroll
+    for (int i = 0; i < NJG; ++i) {
+        const int over = co0 + wave * GW + r5 + 12 * i - (a.Co - 1);
+        g_adj[i] = over > 0 ? (unsigned)(over * HW) * 4u : 0u;
+    }
     // horizontal-tap X rows: lane -> (row r7, quad q7 of 6: pixels [p0 - 4, p0 + 20); q7 == 6 is the padding quad)
     const int q7 = lane % 7, r7 = lane / 7;
     int h_m = 0, h_rem = 0;
@@ -127,7 +135,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int rows = GW - 12 * i < 12 ? GW - 12 * i : 12;
-                if (q5 < 4 && r5 < rows) dma16(a.dy + (size_t)(12 * i) * HW, v, dst + (unsigned)(12 * i * LDG * 4));
+                if (q5 < 4 && r5 < rows) dma16(a.dy + (size_t)(12 * i) * HW, l_m < M ? v - g_adj[i] : 0u, dst + (unsigned)(12 * i * LDG * 4));
             }
         }
         // (3x3: a quad whose shifted row leaves the image is never used — any mapped address)
@@ -190,8 +198,9 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
         const bool in0 = r_m < M, in1 = r_m + 4 < M;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
-            const float* p0 = in0 ? gs + rd_g + mi * 32 * LDG : Zs;
-            const float* p1 = in1 ? gs + rd_g + mi * 32 * LDG + 4 : Zs;
+            const bool rv = co0 + wave_co * 32 * MCO + mi * 32 + l31 < a.Co;          // (a row past Co: zeros)
+            const float* p0 = (in0 && rv) ? gs + rd_g + mi * 32 * LDG : Zs;
+            const float* p1 = (in1 && rv) ? gs + rd_g + mi * 32 * LDG + 4 : Zs;
             const float4 u0 = *reinterpret_cast<const float4*>(p0);
             const float4 u1 = *reinterpret_cast<const float4*>(p1);
             av[S][mi][0] = u0.x; av[S][mi][1] = u0.y; av[S][mi][2] = u0.z; av[S][mi][3] = u0.w;
@@ -302,7 +311,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
         if (s + 1 < nsteps) step(ic<1>{}, s + 1);
     }
 
-    if (do_bias && t < TCO) a.out_bias[(size_t)split * a.Co + co0 + t] = bsum;
+    if (do_bias && t < TCO && co0 + t < a.Co) a.out_bias[(size_t)split * a.Co + co0 + t] = bsum;
     const int KHKW = K33 ? 9 : 3;
     float* out = a.out + (size_t)split * a.Co * a.K;
     const int ci = ci0 + wave_k * 32 + l31;
@@ -316,11 +325,10 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int co = co0 + wave_co * 32 * MCO + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
-                float v;
-            // output transform (m2, m3 were accumulated without their 1/2)
+                if (co >= a.Co) continue;
+                // output transform (m2, m3 were accumulated without their 1/2)
                 const float hs = 0.5f * (acc[mi][1][j] + acc[mi][2][j]);
-                v = s == 0 ? acc[mi][0][j] + hs : (s == 1 ? 0.5f * (acc[mi][1][j] - acc[mi][2][j]) : hs - acc[mi][3][j]);
-            
+                const float v = s == 0 ? acc[mi][0][j] + hs : (s == 1 ? 0.5f * (acc[mi][1][j] - acc[mi][2][j]) : hs - acc[mi][3][j]);
                 out[(size_t)co * rowlen + col] = v;
             }
     }
@@ -333,7 +341,9 @@ bool wgrad_v6_shape_ok(const dynmm_conv_geom* g) {
     const bool k33 = g->KH == 3 && g->KW == 3 && g->PH == 1 && g->PW == 1 && g->H >= 2;
     if (!h_taps && !v_taps && !k33) return false;
     if (g->SH != 1 || g->SW != 1 || g->H != g->Ho || g->W != g->Wo || g->c_split != g->Ci) return false;
-    if (g->W % 4 != 0 || g->W < 16 || g->Ci % 64 != 0 || g->Co % 64 != 0) return false;
+    if (g->W % 4 != 0 || g->W < 16 || g->Ci % 64 != 0) return false;
+    // rows: a multiple of the 64-row tile, or — horizontal taps and 3x3 only — any multiple of 4 from 24 up (conv_out's 40 classes)
+    if (g->Co % 64 != 0 && (v_taps || g->Co % 4 != 0 || g->Co < 24)) return false;
     // 32-bit byte offsets inside one tensor, signed pixel counters
     const unsigned long long cmax = (unsigned long long)(g->Ci > g->Co ? g->Ci : g->Co);
     if ((unsigned long long)g->N * cmax * g->H * g->W * 4ull >= (1ull << 31)) return false;

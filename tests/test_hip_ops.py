@@ -76,6 +76,8 @@ CONV_CASES = [
     (3, 64, 17, 20, 64, (3, 3), (1, 1), (1, 1), True, None),         # 64-row tile, odd H, M = 1020: steps straddle rows AND images
     (2, 128, 9, 16, 256, (3, 3), (1, 1), (1, 1), True, 'relu'),      # narrowest rows: every step is one image row, 2 x 2 x 3 k-tiles
     (1, 64, 2, 32, 128, (3, 3), (1, 1), (1, 1), False, None),        # H = 2: the outer taps see one live row each
+    (2, 128, 24, 32, 40, (3, 3), (1, 1), (1, 1), True, None),        # conv_out: 40 rows in a 64-row tile (rows past Co read zeros)
+    (3, 64, 9, 20, 72, (1, 3), (1, 1), (0, 1), True, None),          # 72 = 64 + 8 rows: a full tile and a tail tile
 ]
 
 
