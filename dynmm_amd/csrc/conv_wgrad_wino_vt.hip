@@ -17,6 +17,14 @@
 // one when H is odd or even) and positions past the end of the tensor read an all-zero quad; their loads fetch a mapped
 // row whose values are never used.  Output: the same k-major slabs [split][co][tap * Ci + ci] and bias-gradient slabs as
 // v6 (the output transform runs on the accumulators; the halvings are exact).  Bit-reproducible.
+//
+// Round 5 built the rewrite VERDICT r4 #5 asked for — 16-position stages walking DOWN 16-column strips, X rows in row pairs
+// reused by the next stage (1.0 input row per output row instead of 2.0), 64-byte row pieces in an unpadded XOR-swizzled layout,
+// 64 MFMAs per barrier (scratch/r5/conv_wgrad_wino_vt_strips.hip; all tests green) — and measured it: C = 64 launches 1.69 ->
+// 1.51 ms (107 -> 120 TFLOP/s), the Co % 128 == 0 group 6.21 -> 5.99 ms (131 -> 136), but the STEP 0.3 ms slower on alternating
+// runs (65.96 against 65.68 ms): its two workgroups take all 160 KB of a CU's LDS, and a stage that ends a strip is followed by a
+// halo item and the next stage, which the reader skips to in one move — the two-item look-ahead becomes one at every strip
+// boundary, every 8 / 15 stages at C = 512 / 256.  Not kept; the fetch granularity was not what holds this kernel at 0.58.
 #include <stdlib.h>
 
 #include <type_traits>
