@@ -67,6 +67,9 @@ def _wino43(g):
     """input gradient of this convolution on the F(4,3) kernel?  (only consulted where _wino(g, True) holds)"""
     if WINO_DGRAD == '23' or g.KW != 3:
         return False
+    # (round 5, alternating runs: F(4,3) only where its quad tiles fill the chip — C <= 128 / C <= 256 — 63.94 / 64.07 ms against
+    # 63.75 with F(4,3) on every horizontal launch: where it is slower in isolation (C = 512: 124 against 111 us) the half of the
+    # matrix pipe it leaves goes to the weight-gradient streams)
     key = (g.N, g.Ci, g.H, g.W, g.Co, g.KH, g.KW, g.SH, g.SW, g.PH, g.PW, g.c_split)
     ok = _WINO43_OK.get(key)
     if ok is None:

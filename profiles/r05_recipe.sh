@@ -19,8 +19,9 @@ cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_sq2.log 2>&1
 cd $R
-python profiles/summarize_pmc.py $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv $O/pmc_sq/p_counter_collection.csv $O/pmc.md $O/pmc.json conv_ 4 > $O/pmc_summary.log 2>&1
+python profiles/summarize_pmc.py $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv $O/pmc_sq/p_counter_collection.csv $O/pmc.md $O/pmc.json conv_ 4 $O/pmc_sq2/p_counter_collection.csv > $O/pmc_summary.log 2>&1
 fi
 rm -rf $O/*/*.db $O/pmc_*/p_*.csv    # keep the merge-back small: summaries only
 tail -1 $O/single_stdout.log | cut -c1-300
