@@ -1,7 +1,7 @@
 // Implicit-GEMM convolution, round-3 operand pipeline ("v5"): stride-1, same-padded 1x1 / 3x1 / 1x3 / 3x3 convolutions
 // (forward and input gradient) on the fp32 matrix cores, every workgroup self-sufficient in latency hiding.
 //
-// Why (measured, scratch/trace + scratch/mfma/peak_random.hip, DESIGN.md §4 "round 3"): with 6 thin workgroups per CU the
+// Why (measured, scratch/trace + scratch/mfma/peak_random.hip, docs/DESIGN_history_r1-r4.md §4 "round 3"): with 6 thin workgroups per CU the
 // register-staged kernel of conv_igemm.hip saturates the MFMA pipe only while all 6 are resident; the workgroups of a CU
 // finish one after the other (the oldest wave wins the pipe), and whatever runs at reduced occupancy — the staggered tail
 // of every launch, i.e. 25-45 % of its duration — exposes the full load -> LDS -> fragment latency chain of each K-step.

@@ -4,7 +4,7 @@
 // carried the direct form — three contractions per pixel, horizontal and vertical — behind DYNMM_WGRAD_WINO=0; removed in round 5.)
 //
 // dW[co][tap][ci] = sum_pix dY[co][pix] * X[ci][pix + tap shift]: M = co, N = (tap, ci), reduction over pixels.
-// What changed against conv_wgrad_v4_kernel (conv_igemm.hip), and why (DESIGN.md §4 "round 3"):
+// What changed against conv_wgrad_v4_kernel (conv_igemm.hip), and why (docs/DESIGN_history_r1-r4.md §4 "round 3"):
 //   * ONE workgroup owns all three taps of its 64 input channels: tile (64 or 128) co x (3 taps x 64 ci), a wave holds
 //     (32 or 64) co x (3 x 32 ci) = 3 or 6 accumulator blocks.  The dY tile is staged once for three taps (v4: once per
 //     128-wide k-tile = per tap) and, for the horizontal taps, so is the X tile: the three taps are the same LDS rows read

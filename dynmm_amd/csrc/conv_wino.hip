@@ -13,16 +13,15 @@
 // from the raw input tile at the fragment read (one add per MFMA operand); the output transform is lane-local because a
 // lane of the 32x32 accumulator layout holds one pair's 16 channels for all four M_i.
 //
-// Used where it cannot move a forward result: the INPUT GRADIENT of those convolutions (the input gradient of a stride-1
-// three-tap convolution is the three-tap convolution of dy with the flipped filter) — ReLU / max-pool decisions are taken
-// in the forward pass, so the backward sees the same masks whatever its arithmetic — and, opt-in, the forward.
+// Used for the forward (training and inference) and the INPUT GRADIENT of those convolutions (the input gradient of a stride-1
+// three-tap convolution is the three-tap convolution of dy with the flipped filter).
 //
-// Kernel structure (what the round-3 measurements say pays on this part): a wave owns 64 output
-// channels x 32 pairs x 4 transforms = 8 accumulator blocks (128 registers), so a workgroup needs only one more
-// neighbour per CU to keep the matrix pipe busy (the three-tap weight-gradient kernel's recipe: 0.73-0.77 MFMA-busy at 2
-// workgroups per CU); operands go global -> LDS by `global_load_lds_dwordx4` into a 3-slot ring requested two stages
-// ahead (hand-counted vmcnt), one barrier per 8-channel stage = 32 MFMAs per wave, fragments of k-pair q+1 are read
-// under the 8 MFMAs of k-pair q.  Tiles: (128 co x 64 pairs) for Co % 128 == 0, (64 co x 128 pairs) otherwise.
+// Kernel structure: tile 64 co x 64 pairs; a wave owns 32 output channels x 32 pairs x 4 transforms = 4 accumulator blocks (64
+// registers; 3 workgroups per CU for the vertical kernels, 4 for the horizontal three-tap ones: 37.6 KB of LDS each); operands go
+// global -> LDS by `global_load_lds_dwordx4` into a 3-slot ring requested a stage ahead (hand-counted vmcnt), one barrier per
+// 8-channel stage = 16 MFMAs per wave, fragments of k-pair q+1 are read under the 4 MFMAs of k-pair q.  (Round 4 also carried
+// 128 x 64 / 64 x 128 tiles with 8 blocks per wave: slower at batch 32, removed in round 5.  What bounds the kernel:
+// profiles/r05_wino_bound.md.)
 //   * filter operand [tap row][ci][co][4 transforms]: a lane's four A values of a k-pair are ONE ds_read_b128;
 //   * horizontal taps (1x3, 3x3): the raw tile is [8 channels][2*pairs + 8] pixels (16-byte aligned quads, a 4-pixel halo
 //     either side); a lane reads (., d0) (d1, d2) (d3, .) as three conflict-free ds_read_b64;

@@ -39,10 +39,11 @@ extern "C" {
 int dynmm_abi_version(void);
 const char* dynmm_build_info(void);
 
-/* A/B switch for tests and measurement tools: which implicit-GEMM generation serves the stride-1 same-padded
- * 1x1 / 3x1 / 1x3 / 3x3 convolutions (forward + input gradient).  mode 1 = the operand-ring kernels
- * (csrc/conv_igemm_v5.hip), 0 = the register-staged kernels (csrc/conv_igemm.hip), -1 = follow the environment
- * (DYNMM_IGEMM_V5, default 1).  Process-wide; not meant to be flipped while launches are being issued from other threads. */
+/* Test hook (tests/test_skip_esanet.py measures the fp32 conditioning of a gate gradient by running one pass under two correct
+ * summation orders): which implicit-GEMM generation serves the stride-1 same-padded 1x1 / 3x1 / 1x3 / 3x3 convolutions that
+ * do not take the Winograd kernels (forward + input gradient).  mode 0 = the register-staged kernels (csrc/conv_igemm.hip),
+ * 1 or -1 (default) = the operand-ring kernels (csrc/conv_igemm_v5.hip).  Process-wide; not meant to be flipped while
+ * launches are being issued from other threads. */
 int dynmm_debug_set_igemm_v5(int mode);
 
 /* Geometry of one convolution, shared by fwd / dgrad / wgrad.
