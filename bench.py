@@ -346,6 +346,8 @@ def executed_fraction(name):
     """matrix-core FLOP executed per algorithmic (direct-convolution) FLOP of a launch"""
     if 's2' in name:                 # polyphase stride-2 input gradients on the pair kernel: no Winograd arithmetic
         return 1.0
+    if 'wino2d' in name:
+        return 4.0 / 9.0
     if 'wino43' in name:
         return 0.5
     if 'wino' in name or name.startswith('conv_wgrad_v6'):

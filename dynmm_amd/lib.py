@@ -61,6 +61,14 @@ SIGNATURES = {
     'dynmm_conv2d_wino_fwd_stats_slots': (c_i, [_GP]),
     'dynmm_conv2d_wino_fwd_stats': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, _GP, c_f]),
     'dynmm_conv2d_wino_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
+    'dynmm_conv2d_wino2d_supported': (c_i, [_GP, c_i]),
+    'dynmm_wino2d_packed_floats': (c_sz, [c_i, c_i]),
+    'dynmm_wino2d_pack': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    'dynmm_wino2d_pack_multi_blocks': (c_i, [c_i, c_i, c_i]),
+    'dynmm_wino2d_pack_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
+    'dynmm_conv2d_wino2d_stats_slots': (c_i, [_GP]),
+    'dynmm_conv2d_wino2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, _GP, c_i, c_f]),
+    'dynmm_conv2d_wino2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wino43_supported': (c_i, [_GP]),
     'dynmm_wino43_packed_floats': (c_sz, [c_i, c_i, c_i, c_i]),
     'dynmm_wino43_pack': (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -77,6 +77,23 @@ def _wino43(g):
     return ok
 
 
+_WINO2D_OK = {}
+
+
+def _wino2d(g, dgrad, x2=None, infer=False):
+    """does this pass of this (3x3) convolution run on the 2-D Winograd kernel (csrc/conv_wino2d.hip: 4/9 of the direct matrix work)?
+    Same switches as _wino; where it applies it replaces the 1-D forms (horizontal F(2,3) with looped vertical taps, F(4,3))."""
+    if WINO == '0' or x2 is not None or g.KH != 3 or g.KW != 3:
+        return False
+    if not infer and ((WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad)):
+        return False
+    key = (g.N, g.Ci, g.H, g.W, g.Co, g.SH, g.SW, g.PH, g.PW, g.c_split, bool(dgrad))
+    ok = _WINO2D_OK.get(key)
+    if ok is None:
+        ok = _WINO2D_OK[key] = bool(_lib().dynmm_conv2d_wino2d_supported(C.byref(g), int(bool(dgrad))))
+    return ok
+
+
 def _wino(g, dgrad, x2=None, infer=False):
     """does this pass of this convolution run on the Winograd kernels?"""
     if WINO == '0' or x2 is not None:
@@ -325,7 +342,9 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
             name = 'conv_co8_wgrad<direct,valu>'            # conv_small.hip: the gate conv's weight + bias gradient
     if kind != 'wgrad' and not generic and _lib().dynmm_conv2d_uses_operand_ring(C.byref(g), int(kind == 'dgrad')):
         name = f'conv_igemm_v5_{kind}<{"128x64" if co % 128 == 0 else "64x128"},kw{g.KW}>'      # conv_igemm_v5.hip
-    if wino:                                     # conv_wino.hip: one template instance per tile height, tap axis and direction
+    if wino == 22:                               # conv_wino2d.hip
+        name = f'conv_wino2d_{kind}<co{128 if co % 128 == 0 else 64},3x3>'
+    elif wino:                                   # conv_wino.hip: one template instance per tile height, tap axis and direction
         name = f'conv_wino{"43" if wino == 43 else ""}_{kind}<co{128 if co % 128 == 0 else 64},{g.KH}x{g.KW}{"s2" if g.SH * g.SW > 1 else ""}>'
     if kind == 'fwd':                            # conv_small.hip: *_eligible (the library's own dispatch rules)
         k5, k7 = (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (5, 5, 2, 2, 0, 0), (g.KH, g.KW, g.SH, g.SW, g.PH, g.PW) == (7, 7, 2, 2, 3, 3)
@@ -416,17 +435,19 @@ class PackedWeights:
     invalidate() only (the optimizer rewrites the weights after the body)."""
 
     def __init__(self):
-        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad]
-        self.slots = {}          # id(weight) -> (wp, wpd, utf, utd, utd43), None where not needed
-        self.arena = self.desc = self.wdesc = self.w43desc = None
-        self.blocks = self.wblocks = self.nwino = self.w43blocks = self.nw43 = 0
+        self.reg = {}            # id(weight) -> [weight, Co, Ci, KH, KW, need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad, wino2d_fwd, wino2d_dgrad]
+        self.slots = {}          # id(weight) -> (wp, wpd, utf, utd, utd43, ut2f, ut2d), None where not needed
+        self.arena = self.desc = self.wdesc = self.w43desc = self.w2desc = None
+        self.blocks = self.wblocks = self.nwino = self.w43blocks = self.nw43 = self.w2blocks = self.nw2 = 0
         self.valid = False
         self.dirty = False       # registrations since the arena was laid out
 
-    def register(self, weight, g, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False):
+    def register(self, weight, g, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False,
+                 wino2d_fwd=False, wino2d_dgrad=False):
         if not isinstance(weight, torch.nn.Parameter):
             return
-        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), int(wino_dgrad), bool(wino43_dgrad)]     # wino_dgrad: 0 | 1 | 2
+        flags = [bool(need_fwd), bool(need_dgrad), bool(wino_fwd), int(wino_dgrad), bool(wino43_dgrad),     # wino_dgrad: 0 | 1 | 2
+                 bool(wino2d_fwd), bool(wino2d_dgrad)]
         e = self.reg.get(id(weight))
         if e is None:
             self.reg[id(weight)] = [weight, g.Co, g.Ci, g.KH, g.KW] + flags
@@ -441,13 +462,14 @@ class PackedWeights:
                     e[5 + i] = f
                     self.dirty = True
 
-    def lookup(self, weight, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False):
+    def lookup(self, weight, need_fwd=True, need_dgrad=False, wino_fwd=False, wino_dgrad=False, wino43_dgrad=False,
+               wino2d_fwd=False, wino2d_dgrad=False):
         if not self.valid:
             return None
         s = self.slots.get(id(weight))
         if s is None:
             return None
-        for need, t in zip((need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad), s):
+        for need, t in zip((need_fwd, need_dgrad, wino_fwd, wino_dgrad, wino43_dgrad, wino2d_fwd, wino2d_dgrad), s):
             if need and t is None:
                 return None
         if wino_dgrad and self.reg[id(weight)][5 + 3] != int(wino_dgrad):
@@ -459,11 +481,11 @@ class PackedWeights:
         ents = list(self.reg.values())
         dev = ents[0][0].device
         base = min(e[0].data_ptr() for e in ents)
-        off, blk, wblk, w43blk, rows, wrows, w43rows = 0, 0, 0, 0, [], [], []
+        off, blk, wblk, w43blk, w2blk, rows, wrows, w43rows, w2rows = 0, 0, 0, 0, 0, [], [], [], []
         spans = {}
-        for w, Co, Ci, KH, KW, nf_, nd, wf, wd, wd43 in ents:
+        for w, Co, Ci, KH, KW, nf_, nd, wf, wd, wd43, w2f, w2d in ents:
             src = (w.data_ptr() - base) // 4
-            span = [None] * 5
+            span = [None] * 7
             # the multi-tensor pack always writes the forward layout; the input-gradient layout only where a direct
             # kernel reads it (dynmm_pack_weight_multi's descriptor: dst_dgrad = -1 otherwise)
             nf = lib.dynmm_packed_weight_floats(Co, Ci, KH, KW, 0)
@@ -490,13 +512,21 @@ class PackedWeights:
                 span[4] = (off, nu43)
                 off += (nu43 + 3) & ~3
                 w43blk += lib.dynmm_wino43_pack_multi_blocks(Co, Ci, KH, KW)
+            nu2 = lib.dynmm_wino2d_packed_floats(Co, Ci) if (w2f or w2d) else 0
+            for slot, dgrad, on in ((5, 0, w2f), (6, 1, w2d)):
+                if on:
+                    w2rows.append([src, off, Co | (Ci << 32), (dgrad << 16) | (w2blk << 32)])
+                    span[slot] = (off, nu2)
+                    off += nu2                   # a multiple of 4 floats
+                    w2blk += lib.dynmm_wino2d_pack_multi_blocks(Co, Ci, dgrad)
             spans[id(w)] = span
         self.arena = torch.empty(off, device=dev, dtype=torch.float32)
         self.desc = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
         self.wdesc = torch.tensor(wrows, dtype=torch.int64).to(dev) if wrows else None
         self.w43desc = torch.tensor(w43rows, dtype=torch.int64).to(dev) if w43rows else None
-        self.ndesc, self.nwino, self.nw43 = len(rows), len(wrows), len(w43rows)
-        self.base, self.blocks, self.wblocks, self.w43blocks = base, blk, wblk, w43blk
+        self.w2desc = torch.tensor(w2rows, dtype=torch.int64).to(dev) if w2rows else None
+        self.ndesc, self.nwino, self.nw43, self.nw2 = len(rows), len(wrows), len(w43rows), len(w2rows)
+        self.base, self.blocks, self.wblocks, self.w43blocks, self.w2blocks = base, blk, wblk, w43blk, w2blk
         self.slots = {k: tuple(self.arena[sp[0]:sp[0] + sp[1]] if sp is not None else None for sp in span)
                       for k, span in spans.items()}
         self.dirty = False
@@ -519,6 +549,9 @@ class PackedWeights:
         if self.w43desc is not None:
             L.check(_lib().dynmm_wino43_pack_multi(C.c_void_p(self.base), _p(self.arena), self.w43desc.data_ptr(), self.nw43,
                                                    self.w43blocks, _stream()), 'wino43_pack_multi')
+        if self.w2desc is not None:
+            L.check(_lib().dynmm_wino2d_pack_multi(C.c_void_p(self.base), _p(self.arena), self.w2desc.data_ptr(), self.nw2,
+                                                   self.w2blocks, _stream()), 'wino2d_pack_multi')
         self.valid = True
 
     def invalidate(self):
@@ -539,17 +572,19 @@ class _Conv2d(Function):
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=x.device, dtype=torch.float32)
         # (the Winograd kernels read their input with 16-byte loads; an input off that grid takes the direct kernels)
-        wino_f = _wino(g, False, x2) and x.data_ptr() % 16 == 0
-        wino_d = need_dx and _wino(g, True, x2)
+        w2f = _wino2d(g, False, x2) and x.data_ptr() % 16 == 0          # 3x3: the 2-D form replaces the 1-D ones where it applies
+        w2d = need_dx and _wino2d(g, True, x2)
+        wino_f = not w2f and _wino(g, False, x2) and x.data_ptr() % 16 == 0
+        wino_d = need_dx and not w2d and _wino(g, True, x2)
         wino_d43 = wino_d and _wino43(g)
         wino_d = 0 if wino_d43 else int(wino_d or 0)          # 0 | 1 (stride 1) | 2 (stride 2: polyphase form)
-        need_wp, need_wpd = not wino_f, need_dx and not (wino_d or wino_d43)
+        need_wp, need_wpd = not (wino_f or w2f), need_dx and not (wino_d or wino_d43 or w2d)
         # (a Linear / Conv1d weight arrives as a [Co, Ci, 1, 1] alias of its parameter: same memory, so the parameter keys the pack)
         wkey = w_owner if w_owner is not None else weight
-        wp = wpd = utf = utd = utd43 = None
-        pre = PREPACK.lookup(wkey, need_wp, need_wpd, wino_f, wino_d, wino_d43) if PREPACK is not None else None
+        wp = wpd = utf = utd = utd43 = ut2f = ut2d = None
+        pre = PREPACK.lookup(wkey, need_wp, need_wpd, wino_f, wino_d, wino_d43, w2f, w2d) if PREPACK is not None else None
         if pre is not None:
-            wp, wpd, utf, utd, utd43 = pre           # packed by the step's multi-tensor launches
+            wp, wpd, utf, utd, utd43, ut2f, ut2d = pre           # packed by the step's multi-tensor launches
         else:
             if need_wp or need_wpd:
                 wp = torch.empty(lib.dynmm_packed_weight_floats(g.Co, g.Ci, g.KH, g.KW, 0), device=x.device,
@@ -567,9 +602,28 @@ class _Conv2d(Function):
             if wino_d43:
                 utd43 = torch.empty(lib.dynmm_wino43_packed_floats(g.Co, g.Ci, g.KH, g.KW), device=x.device, dtype=torch.float32)
                 L.check(lib.dynmm_wino43_pack(_p(weight), _p(utd43), g.Co, g.Ci, g.KH, g.KW, st), 'wino43_pack')
+            if w2f or w2d:
+                nu2 = lib.dynmm_wino2d_packed_floats(g.Co, g.Ci)
+                if w2f:
+                    ut2f = torch.empty(nu2, device=x.device, dtype=torch.float32)
+                    L.check(lib.dynmm_wino2d_pack(_p(weight), _p(ut2f), None, g.Co, g.Ci, 0, st), 'wino2d_pack')
+                if w2d:
+                    ut2d = torch.empty(nu2, device=x.device, dtype=torch.float32)
+                    L.check(lib.dynmm_wino2d_pack(_p(weight), _p(ut2d), None, g.Co, g.Ci, 1, st), 'wino2d_pack')
             if PREPACK is not None:
-                PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d, wino_d43)
-        if (wino_f and stats is not None and act == L.ACT_NONE and g.KW == 3 and
+                PREPACK.register(wkey, g, need_wp, need_wpd, wino_f, wino_d, wino_d43, w2f, w2d)
+        if w2f:
+            sums, ns = None, 0
+            if stats is not None and act == L.ACT_NONE and g.Co % 64 == 0:
+                # the consumer is a training-mode BatchNorm: its batch statistics come out of this launch
+                ns = lib.dynmm_conv2d_wino2d_stats_slots(C.byref(g))
+                sums, zeroed = _zero_sums(2 * g.Co * ns, x.device)
+                if not zeroed:
+                    sums.zero_()
+                stats['sums'] = sums
+            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino2d_fwd(_p(x), _p(ut2f), _p(bias), None, _p(y), _p(sums), ns,
+                                                                         C.byref(g), act, st), wino=22), 'conv2d_wino2d_fwd')
+        elif (wino_f and stats is not None and act == L.ACT_NONE and g.KW == 3 and
                 lib.dynmm_conv2d_wino_fwd_stats_supported(C.byref(g))):
             # the consumer is a training-mode BatchNorm: its batch statistics come out of this launch (stats: a holder the
             # conv2d() wrapper hangs on the output tensor for batch_norm_act to find)
@@ -590,12 +644,12 @@ class _Conv2d(Function):
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_x2 = x2 is not None
-        ctx.wino_d = 43 if wino_d43 else (23 if wino_d else 0)
+        ctx.wino_d = 22 if w2d else (43 if wino_d43 else (23 if wino_d else 0))
         ctx.mask_input = mask_input       # x is a ReLU output: apply [x > 0] in the dgrad epilogue
         ctx.defer_mask = defer_mask       # our own ReLU backward is applied by the consumer's dgrad
         ctx.link = link
         ctx.bn_link = bn_link
-        ctx.save_for_backward(x, x2, utd43 if wino_d43 else (utd if wino_d else wpd),
+        ctx.save_for_backward(x, x2, ut2d if w2d else (utd43 if wino_d43 else (utd if wino_d else wpd)),
                               y if (act != L.ACT_NONE and not defer_mask) else None)
         ctx.wshape = tuple(weight.shape)
         # w_owner: the nn.Parameter that `weight` is a reshaped view of (Linear / Conv1d weights used as 1x1 convs): its
@@ -659,7 +713,7 @@ class _Conv2d(Function):
                         C.byref(g), st), extra=1, wino=ctx.wino_d), 'conv2d_wino_dgrad_bnred')
                     bl.sums = sums
                 else:
-                    fn = lib.dynmm_conv2d_wino43_dgrad if ctx.wino_d == 43 else lib.dynmm_conv2d_wino_dgrad
+                    fn = {22: lib.dynmm_conv2d_wino2d_dgrad, 43: lib.dynmm_conv2d_wino43_dgrad}.get(ctx.wino_d, lib.dynmm_conv2d_wino_dgrad)
                     L.check(_timed('dgrad', g, lambda: fn(_p(gyw), _p(wpd), _p(mask), _p(accum), _p(dx), C.byref(g), st),
                                    extra=extra, wino=ctx.wino_d), 'conv2d_wino_dgrad')
             else:
@@ -775,8 +829,10 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     # address + in-place version counter of every tensor they derive from (load_state_dict / optimizer steps bump
     # the versions) and the mutation generation above: a steady-state forward launches only the conv.
     srcs = [weight, conv_bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-    wino = _wino(g, False, x2, infer=True) and x.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 8 == 0)
-    slot = '_dynmm_eval_cache_wino' if wino else '_dynmm_eval_cache'
+    ok_ptrs = x.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 8 == 0)
+    wino2 = _wino2d(g, False, x2, infer=True) and ok_ptrs
+    wino = not wino2 and _wino(g, False, x2, infer=True) and ok_ptrs
+    slot = '_dynmm_eval_cache_wino2d' if wino2 else ('_dynmm_eval_cache_wino' if wino else '_dynmm_eval_cache')
     stamp = (_MUTATION_GEN[0],) + tuple((t.data_ptr(), t._version) for t in srcs if t is not None) + \
         ((float(bn.eps),) if bn is not None else ())
     hit = getattr(weight, slot, None)
@@ -791,7 +847,11 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
                                       _p(conv_bias), _p(scale), _p(shift), g.Co, bn.eps, st), 'bn_fold')
         else:
             shift = _chk(conv_bias, 'bias')
-        if wino:
+        if wino2:
+            wp = torch.empty(lib.dynmm_wino2d_packed_floats(g.Co, g.Ci), device=dev, dtype=torch.float32)
+            L.check(lib.dynmm_wino2d_pack(_p(weight), _p(wp), _p(scale), g.Co, g.Ci, 0, st), 'wino2d_pack')
+            scale = None
+        elif wino:
             # filter transforms of scale[co] * w: the folded BatchNorm factor rides in the operand, the kernel adds the shift
             wp = torch.empty(lib.dynmm_wino_packed_floats(g.Co, g.Ci, g.KH, g.KW), device=dev, dtype=torch.float32)
             L.check(lib.dynmm_wino_pack(_p(weight), _p(wp), _p(scale), g.Co, g.Ci, g.KH, g.KW, 0, st), 'wino_pack')
@@ -802,7 +862,11 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
         if not torch.cuda.is_current_stream_capturing():
             setattr(weight, slot, (stamp, (wp, scale, shift)))
     y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=dev, dtype=torch.float32)
-    if wino:
+    if wino2:
+        L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino2d_fwd(_p(x), _p(wp), _p(shift), _p(residual), _p(y), None, 0, C.byref(g),
+                                                                     ACT[act], st), extra=int(residual is not None), wino=22),
+                'conv2d_wino2d_fwd')
+    elif wino:
         L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd(_p(x), _p(wp), _p(shift), _p(residual), _p(y), C.byref(g),
                                                                    ACT[act], st), extra=int(residual is not None), wino=True),
                 'conv2d_wino_fwd')

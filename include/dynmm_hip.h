@@ -148,6 +148,29 @@ int dynmm_conv2d_wino_fwd_stats(const float* x, const float* ut, const float* bi
 int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
                             const dynmm_conv_geom* g, void* stream);
 
+/* ---- 3x3 convolutions by 2-D Winograd F(2x2, 3x3) (csrc/conv_wino2d.hip, v_mfma_f32_16x16x4_f32): sixteen channel contractions per
+ * 2x2 output tile — 4/9 of the direct convolution's matrix work, plain fp32, 1e-7-level error (src/models/resnet.py:66-84 BasicBlock,
+ * model.py:286,343-357 conv_out / decoder conv3x3).  Stride 1, padding 1, W % 4 == 0, N*H*W >= 256; forward: Ci % 4 == 0 >= 12,
+ * Co % 8 == 0 >= 24; input gradient: Ci % 64 == 0, Co % 4 == 0 >= 12 (dynmm_conv2d_wino2d_supported).  Operand ut
+ * (dynmm_wino2d_packed_floats floats, 16-byte aligned): U = G g G^T as [K][4][rows rounded up to 64][4], written by dynmm_wino2d_pack
+ * (scale: an eval-mode BatchNorm's per-channel factor folded into the forward operand; dgrad = 1: the flipped filter with the channel
+ * roles swapped) or, for many filters at once, dynmm_wino2d_pack_multi (descriptors {src, dst: float offsets; Co | Ci << 32;
+ * dgrad << 16 | first workgroup << 32}).
+ * fwd:   y = act(conv(x) + bias + residual); stats != NULL (act none, no residual, Co % 64 == 0): the per-channel sums of y and y^2 are
+ *        ADDED to stats [nslots][2][Co] (fp64, zeroed by the caller; nslots = dynmm_conv2d_wino2d_stats_slots) — the `sums` operand of
+ *        dynmm_bn_apply without a dynmm_bn_stats launch.
+ * dgrad: dx = [mask > 0] . conv_transpose(dy) + accum   (mask / accum like dx, optional). */
+int dynmm_conv2d_wino2d_supported(const dynmm_conv_geom* g, int dgrad);
+size_t dynmm_wino2d_packed_floats(int Co, int Ci);
+int dynmm_wino2d_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int dgrad, void* stream);
+int dynmm_wino2d_pack_multi_blocks(int Co, int Ci, int dgrad);
+int dynmm_wino2d_pack_multi(const float* src_base, float* dst_base, const void* desc, int ndesc, int total_blocks, void* stream);
+int dynmm_conv2d_wino2d_stats_slots(const dynmm_conv_geom* g);
+int dynmm_conv2d_wino2d_fwd(const float* x, const float* ut, const float* bias, const float* residual, float* y, double* stats,
+                            int nslots, const dynmm_conv_geom* g, int act, void* stream);
+int dynmm_conv2d_wino2d_dgrad(const float* dy, const float* ut, const float* mask, const float* accum, float* dx,
+                              const dynmm_conv_geom* g, void* stream);
+
 /* ---- input gradients by 1-D Winograd F(4,3) (csrc/conv_wino43.hip): four neighbouring outputs of a three-tap filter from six
  * multiplications — HALF of the direct convolution's matrix work (F(2,3) above: 2/3).  The transforms carry factors up to 8 and
  * 1/24: 1.7e-6 .. 2.8e-6 from fp64 in max-norm (direct fp32: 2e-7 .. 3e-7), which is why only the BACKWARD uses it.

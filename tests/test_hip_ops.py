@@ -594,6 +594,7 @@ def test_conv2d_winograd(ops, mode, case):
         g = ops._geom(xg, None, wg, (1, 1), p)
         assert lib.dynmm_conv2d_wino_supported(C.byref(g), 1) == 1
         assert ops._wino(g, True) and ops._wino(g, False) == (mode == 'all')
+        assert bool(lib.dynmm_conv2d_wino2d_supported(C.byref(g), 1)) == (k == (3, 3))
         link = ops.GradLink()
         ops.PROFILE = calls
         y = ops.conv2d(xg, wg, bg, 1, p, None, mask_input=True, link=link)
@@ -604,8 +605,12 @@ def test_conv2d_winograd(ops, mode, case):
         ops.PROFILE = None
     torch.cuda.synchronize()
     names = [c[0] for c in calls]
-    assert any(n.startswith('conv_wino43_dgrad' if (f43 and k[1] == 3) else 'conv_wino_dgrad') for n in names), names
-    assert any(n.startswith('conv_wino_fwd') for n in names) == (mode == 'all'), names
+    if k == (3, 3):        # 3x3 filters: the 2-D F(2x2,3x3) kernel (csrc/conv_wino2d.hip) in every mode
+        assert any(n.startswith('conv_wino2d_dgrad') for n in names), names
+        assert any(n.startswith('conv_wino2d_fwd') for n in names) == (mode == 'all'), names
+    else:
+        assert any(n.startswith('conv_wino43_dgrad' if (f43 and k[1] == 3) else 'conv_wino_dgrad') for n in names), names
+        assert any(n.startswith('conv_wino_fwd') for n in names) == (mode == 'all'), names
     assert rel(y, y_ref) < TOL
     assert rel(xg.grad, dx_ref) < GTOL
     assert rel(wg.grad, wr.grad) < GTOL and rel(bg.grad, br.grad) < GTOL
@@ -797,13 +802,20 @@ def test_winograd_operands_from_the_step_pack(ops):
     for w in ws:
         Co, Ci, KH, KW = w.shape
         g = L.ConvGeom(2, Ci, 16, 16, Co, 16, 16, KH, KW, 1, 1, KH // 2, KW // 2, Ci)
-        pw.register(w, g, True, False, True, True, True)
+        pw.register(w, g, True, False, True, True, True, KH * KW == 9, KH * KW == 9)
     pw.pack()
     torch.cuda.synchronize()
     for w in ws:
         Co, Ci, KH, KW = w.shape
-        wp, wpd, utf, utd, utd43 = pw.lookup(w, True, False, True, True, True)
+        k33 = KH * KW == 9
+        wp, wpd, utf, utd, utd43, ut2f, ut2d = pw.lookup(w, True, False, True, True, True, k33, k33)
         assert wpd is None and pw.lookup(w, True, True) is None          # the direct input-gradient layout was not requested
+        assert (ut2f is not None) == k33 and (k33 or pw.lookup(w, True, False, True, True, True, True) is None)
+        for dgrad, got in ((0, ut2f), (1, ut2d)) if k33 else ():         # the 2-D F(2x2,3x3) operands (csrc/conv_wino2d.hip)
+            ref = torch.zeros(lib.dynmm_wino2d_packed_floats(Co, Ci), device='cuda')
+            L.check(lib.dynmm_wino2d_pack(w.data_ptr(), ref.data_ptr(), None, Co, Ci, dgrad, st), 'wino2d_pack')
+            n_live = (Co if dgrad else Ci) * 4 * (((Ci if dgrad else Co) + 63) // 64 * 64) * 4
+            assert torch.equal(got[:n_live], ref[:n_live]), (tuple(w.shape), dgrad)
         ref43 = torch.empty(lib.dynmm_wino43_packed_floats(Co, Ci, KH, KW), device='cuda')
         L.check(lib.dynmm_wino43_pack(w.data_ptr(), ref43.data_ptr(), Co, Ci, KH, KW, st), 'wino43_pack')
         assert torch.equal(utd43, ref43), tuple(w.shape)
