@@ -356,15 +356,18 @@ def executed_fraction(name):
 
 
 def kernel_instance(name):
-    """The compiled kernel (template instance) a launch label runs on: the Winograd kernels serve every channel count, and the
-    horizontal form the 3x3 filters too, from one instance per tap axis (3x3 filters: an instance of their own) — the unit rocprofv3 reports and the roofline is quoted for."""
+    """The compiled kernel (template instance) a launch label runs on: the Winograd kernels serve every channel count from one
+    instance per tap axis (1x3 / 3x1: conv_wino.hip, conv_wino43.hip) or one per direction (3x3: conv_wino2d.hip) — the unit
+    rocprofv3 reports and the roofline is quoted for."""
     import re
+    m = re.match(r'conv_wino2d_(fwd|dgrad)<co\d+,3x3>', name)
+    if m:
+        return f'conv_wino2d_{m.group(1)}<3x3>'
     m = re.match(r'conv_wino(43)?_(fwd|dgrad)<co\d+,(\d)x(\d)(s2)?>', name)
     if not m:
         return name
     f43, kind, kh, kw, s2 = m.groups()
-    k33 = ',3x3' if (kh == '3' and kw == '3') else ''        # (a template flag of its own since round 5)
-    return f"conv_wino{f43 or ''}_{kind}<{'vertical' if kw == '1' else 'horizontal'}{k33}{',s2' if s2 else ''}>"
+    return f"conv_wino{f43 or ''}_{kind}<{'vertical' if kw == '1' else 'horizontal'}{',s2' if s2 else ''}>"
 
 
 def roofline_of(agg):

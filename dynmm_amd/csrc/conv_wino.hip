@@ -1,7 +1,7 @@
 // Three-tap convolutions by the 1-D Winograd minimal filtering algorithm F(2,3) on the fp32 matrix cores (round 4).
 //
-// The factorised 3x1 / 1x3 convolutions of every NonBottleneck1D block (FusionDynMM/src/models/resnet.py:124-147) and the
-// decoder's 3x3 convolutions (src/models/model.py:343-357) are 81 % + 12 % of the path's MACs.  Along
+// The factorised 3x1 / 1x3 convolutions of every NonBottleneck1D block (FusionDynMM/src/models/resnet.py:124-147) are 81 % of
+// the path's MACs (the decoder's 3x3 convolutions, 12 %, run on the 2-D form in conv_wino2d.hip).  Along
 // the tap axis two neighbouring outputs (y0, y1) of a 3-tap filter g over inputs d0..d3 are
 //     m1 = (d0 - d2) g0            m2 = (d1 + d2) (g0 + g1 + g2) / 2
 //     m4 = (d1 - d3) g2            m3 = (d2 - d1) (g0 - g1 + g2) / 2            y0 = m1 + m2 + m3,   y1 = m2 - m3 - m4
@@ -23,13 +23,12 @@
 // 128 x 64 / 64 x 128 tiles with 8 blocks per wave: slower at batch 32, removed in round 5.  What bounds the kernel:
 // profiles/r05_wino_bound.md.)
 //   * filter operand [tap row][ci][co][4 transforms]: a lane's four A values of a k-pair are ONE ds_read_b128;
-//   * horizontal taps (1x3, 3x3): the raw tile is [8 channels][2*pairs + 8] pixels (16-byte aligned quads, a 4-pixel halo
+//   * horizontal taps (1x3): the raw tile is [8 channels][2*pairs + 8] pixels (16-byte aligned quads, a 4-pixel halo
 //     either side); a lane reads (., d0) (d1, d2) (d3, .) as three conflict-free ds_read_b64;
 //   * vertical taps (3x1): the raw tile is [8 channels][4 input rows][pairs]: the four rows an output row pair needs
 //     (2x the output bytes through L2, where one gather per tap moves 3x);
 //   * zero padding: a value outside the image is replaced by 0 with a lane-constant select after the read (the load itself
-//     is never predicated: an out-of-image row is replaced by a mapped one); for the 3x3 filter a whole vertical tap
-//     outside the image points the reads at an all-zero slot.
+//     is never predicated: an out-of-image row is replaced by a mapped one).
 #include <stdlib.h>
 
 #include "common.h"
@@ -39,17 +38,17 @@ namespace dynmm {
 
 struct WinoArgs {
     const float* x;         // input [N, Ci, H, W]  (input gradient: dy, Ci = the convolution's Co)
-    const float* ut;        // transformed filters [KR][Ci][Co][4]
+    const float* ut;        // transformed filters [Ci][CoS][4]
     const float* shift;     // [Co] or nullptr (forward: bias)
     const float* residual;  // like y or nullptr.  forward: added before the activation; input gradient: added after the mask
     const float* mask;      // like y or nullptr (input gradient): y = mask > 0 ? y : 0
     float* y;               // [N, Co, H, W]
     double* stats;          // STATS: [nslots][2][Co] running sums of y and y^2 over (N, H, W) (BatchNorm batch statistics), or nullptr
     const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;   // BNRED: the BatchNorm whose output gradient this launch produces
+    const unsigned long long* bits;   // BNRED == 2: that BatchNorm's ReLU decisions, one bit per element (norm.hip mask_word layout)
     int nslots;             //        pixel tile p adds into slab p % nslots (4800 tiles on one address cost a C = 64 launch 18 %)
     int N, Ci, Co, H, W;
     int CoS;                // row stride of `ut` (Co rounded up to the 64-row tile: the pack writes zero rows)
-    int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
     int act;
     int MP;                 // output pairs
     int H2;                 // vertical taps: row pairs per image, (H + 1) / 2
@@ -80,13 +79,16 @@ __device__ __forceinline__ float quad_sum(float v) {            // sum over the 
 // conv3x1_2 consumes relu(bn1(.))).  `mask` carries c, the BatchNorm's INPUT: the epilogue re-derives [BN(c) > 0] with the
 // forward's own fma, and leaves the BatchNorm backward's two reductions, sum g.[z > 0] and sum g.[z > 0].xhat, in a.stats
 // (the `sums` of dynmm_bn_bwd_apply) — bn_bwd_reduce_kernel's launch and its pass over g and c are not needed.
-// KR3: a 3x3 filter (horizontal taps in the pair form, vertical taps looped as part of the reduction).  A template flag since
-// round 5: the three-tap launches (58 + 64 of every 64 + 67) carry none of the tap bookkeeping — no zero slot in LDS (4 workgroups
-// per CU fit where the registers allow), no row bits, a loader whose addresses advance by constant strides.
-template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, bool BNRED = false,
-          bool KR3 = false>
+// BNRED == 2 (round 5): the same for a BatchNorm + identity + ReLU (bn2 of a block, resnet.py:136-147) whose output feeds the
+// NEXT block and nothing else: this launch is that block's first convolution (3x1), `residual` the gradient of its identity
+// branch, so the epilogue holds the complete gradient g of out = relu(bn2(c) + identity).  The ReLU decision is not derivable
+// from c: `bits` carries the one-bit-per-element record the forward's normalise pass left (norm.hip).  The launch writes
+// g.[out > 0] (what bn_bwd_apply and the identity branch both consume: no second masked copy) and leaves the two reductions.
+// (3x3 filters ran here in round 4 — horizontal taps in the pair form, the vertical taps looped as part of the reduction, 2/3 of
+// the direct work; since round 5 they run on the 2-D form F(2x2,3x3) of conv_wino2d.hip at 4/9, and this kernel carries none
+// of the tap bookkeeping: no zero slot in LDS, no row bits, a loader whose addresses advance by constant strides.)
+template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, int BNRED = 0>
 __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
-    static_assert(!KR3 || (!VERT && !S2 && !BNRED), "3x3 filters run on the horizontal pair form");
     static_assert(!BNRED || (DGRAD && VERT && !S2 && MCO == 1 && TCO == 64 && !TAIL && !STATS), "BatchNorm reductions: vertical dgrad");
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
     static_assert(!STATS || (!DGRAD && !VERT && MCO == 1 && TCO == 64 && !TAIL), "statistics: the forward's small horizontal tile");
@@ -112,7 +114,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
 
     __shared__ __attribute__((aligned(16))) float As[S * A_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[S * B_STAGE];
-    __shared__ __attribute__((aligned(16))) float Zs[KR3 ? B_STAGE : 4];   // zeros: a vertical tap outside the image (3x3)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -127,13 +128,10 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     const int HW = a.H * a.W;
     const int HWin = a.Hin * a.Win;
     const int NC = a.Ci / BK;
-    const int nst = KR3 ? 3 * NC : NC;
-
-    auto dh_of = [&](int r) { return KR3 ? (DGRAD ? 1 - r : r - 1) : 0; };
+    const int nst = NC;
 
     // ---------------------------------------------------------------- loader state
     unsigned b_off[NIB];
-    unsigned b_rows = 0;                          // horizontal 3x3: bit 3*i + r: the quad's row shifted by tap r is inside the image
     bool b_act[NIB];
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
@@ -156,14 +154,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             int m = (S2 ? p0 : 2 * p0) - 4 + 4 * quad;
             m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
             const int n = m / HWin, rem = m - n * HWin;
-            const int h = rem / a.Win;
             b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HWin + (unsigned)rem) * 4u;
-            if constexpr (KR3) {
-                for (int r = 0; r < 3; ++r) {
-                    const int hh = h + dh_of(r);
-                    b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
-                }
-            }
         }
     }
     const unsigned a_voff = (unsigned)lane * 16u;
@@ -180,8 +171,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     unsigned l_adst = lds_a + (unsigned)(2 * wave * TCO * 4 * 4), l_bdst = lds_b + (unsigned)(wave * QPW * 4 * 4);
     const unsigned l_adst_end = l_adst + (unsigned)(S * A_STAGE * 4);
     int l_left = nst;                             // stages not yet requested
-    int l_r = 0, l_c = 0;                         // 3x3: vertical tap / channel chunk of the next request
-    unsigned l_shift = (unsigned)(dh_of(0) * a.W * 4);
     auto issue = [&]() {
         if (l_left > 0) {
 #pragma unroll
@@ -189,9 +178,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
                 dma16(a_ptr + (size_t)(i / IPR) * a_row + 64 * (i % IPR) * 4, a_voff, l_adst + (unsigned)i * 1024u);
 #pragma unroll
             for (int i = 0; i < NIB; ++i) {
-                unsigned voff = b_off[i];
-                if constexpr (KR3) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? l_shift : 0u;
-                if (b_act[i]) dma16(b_ptr, voff, l_bdst + (unsigned)i * 1024u);
+                if (b_act[i]) dma16(b_ptr, b_off[i], l_bdst + (unsigned)i * 1024u);
             }
             --l_left;
             a_ptr += a_step;
@@ -202,14 +189,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
                 l_adst -= (unsigned)(S * A_STAGE * 4);
                 l_bdst -= (unsigned)(S * B_STAGE * 4);
             }
-            if constexpr (KR3) {
-                if (++l_c == NC) {
-                    l_c = 0;
-                    ++l_r;
-                    b_ptr = a.x;
-                    l_shift = (unsigned)(dh_of(l_r) * a.W * 4);
-                }
-            }
         }
     };
 
@@ -219,7 +198,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     const bool pvalid = p < a.MP;
     int pn, prem;                                 // image and pixel offset (inside the image) of the pair's first output
     bool m0, m2, m3;                              // d0 / d2 / d3 lie inside the image
-    unsigned rbits = 7u;                          // horizontal 3x3: vertical tap r reads inside the image
     {
         const int pc = pvalid ? p : 0;
         if constexpr (VERT) {
@@ -239,13 +217,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             m0 = w > 0;
             m2 = true;
             m3 = S2 ? (w >> 1) + 1 < a.Win : w + 2 < a.W;         // (S2: e1, the next dy column, exists)
-            if constexpr (KR3) {
-                rbits = 0;
-                for (int r = 0; r < 3; ++r) {
-                    const int hh = h + dh_of(r);
-                    rbits |= (hh >= 0 && hh < a.H) ? (1u << r) : 0u;
-                }
-            }
         }
     }
     const int a_frag = (khalf * TCO + wave_co * WCO + l31) * 4;                          // + (2q * TCO + mi * 32) * 4
@@ -258,10 +229,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         for (int mi = 0; mi < MCO; ++mi)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][mi][j] = 0.f;
-
-    if constexpr (KR3) {
-        for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
-    }
 
     float4 fa[2][MCO];                            // [register set][mi]: U_0..U_3 of (k, co)
     float fd[2][4];                               // [register set]: raw d0..d3 of (k, pair)
@@ -336,13 +303,9 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     issue();
     wait_vm<2 * NI>();                            // (nst >= 3: the launcher requires >= 24 reduction channels)
     __syncthreads();
-    int cr = 0, cc = 0;                           // 3x3: vertical tap / chunk of the stage being consumed
     int c_a = 0, c_b = 0;                         // ring offsets (floats) of the stage being consumed
     const float* Ap = As;
     const float* Bp = Bs;
-    if constexpr (KR3) {
-        if (!(rbits & 1u)) Bp = Zs;               // this lane's row under vertical tap 0 is outside the image: all four d are 0
-    }
     read_raw(0, 0, Ap, Bp);
     transform(0);
     for (int s = 0; s < nst; ++s) {
@@ -375,10 +338,6 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             if (c_a == S * A_STAGE) { c_a = 0; c_b = 0; }
             Ap = As + c_a;
             Bp = Bs + c_b;
-            if constexpr (KR3) {
-                if (++cc == NC) { cc = 0; ++cr; }
-                if (!((rbits >> cr) & 1u)) Bp = Zs;
-            }
             read_raw(0, 0, Ap, Bp);
         }
         DYNMM_WINO_PHASE();
@@ -407,19 +366,38 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     };
     const int co_lim = a.Co - (co0 + wave_co * WCO + 4 * khalf);          // TAIL: channels of this lane below this are real
     auto live = [&](int b, int e) { return !TAIL || (b >> 1) * 32 + (e & 3) + 8 * (2 * (b & 1) + (e >> 2)) < co_lim; };
-    float k0[2][8], k1[2][8], r0[2][8], r1[2][8];
+    // (BNRED == 2 carries three operands per output — c, the identity gradient, the decision word: one register set, loaded at
+    // the top of its batch; with two the kernel spills at 3 workgroups per CU, whose other waves cover the latency instead)
+    constexpr int NSET = BNRED == 2 ? 1 : 2;
+    float k0[NSET][8], k1[NSET][8], r0[NSET][8], r1[NSET][8];
+    unsigned w0[NSET][8], w1[NSET][8];            // BNRED == 2: the 32-bit halves that hold the decisions
+    // bit of element i of a plane: word (i >> 8) * 4 + (i & 3) of the plane's groups, bit (i & 255) >> 2 (norm.hip)
+    const unsigned bit_groups = (unsigned)((HW + 255) >> 8);
+    auto bit_byte = [&](int i) { return (unsigned)(((i >> 8) * 4 + (i & 3)) * 8 + ((((i & 255) >> 2) >> 5) * 4)); };
+    const unsigned bit_off0 = bit_byte(prem), bit_off1 = bit_byte(prem + a.W);
+    const unsigned bit_sh0 = (unsigned)(((prem & 255) >> 2) & 31), bit_sh1 = (unsigned)((((prem + a.W) & 255) >> 2) & 31);
+    const unsigned bit_plane0 = (unsigned)(pn * a.Co + co0 + wave_co * WCO + 4 * khalf) * bit_groups * 32u;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {                 // (launches without epilogue operands never load: neutral values)
-        r0[0][e] = r1[0][e] = r0[1][e] = r1[1][e] = 0.f;
-        k0[0][e] = k1[0][e] = k0[1][e] = k1[1][e] = 1.f;
-    }
+    for (int e = 0; e < 8; ++e)                   // (launches without epilogue operands never load: neutral values)
+#pragma unroll
+        for (int q = 0; q < NSET; ++q) {
+            r0[q][e] = r1[q][e] = 0.f;
+            k0[q][e] = k1[q][e] = 1.f;
+        }
     auto load_batch = [&](int set, int b) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned off = off_of(b, e);
             r0[set][e] = r1[set][e] = 0.f;
             k0[set][e] = k1[set][e] = 1.f;
+            if constexpr (BNRED == 2) w0[set][e] = w1[set][e] = 0u;
             if (!pvalid || !live(b, e)) continue;
+            if constexpr (BNRED == 2) {
+                const char* wp_ = reinterpret_cast<const char*>(a.bits) + bit_plane0 +
+                                  (unsigned)((b >> 1) * 32 + (e & 3) + 8 * (2 * (b & 1) + (e >> 2))) * bit_groups * 32u;
+                w0[set][e] = *reinterpret_cast<const unsigned*>(wp_ + bit_off0);
+                w1[set][e] = y1_ok ? *reinterpret_cast<const unsigned*>(wp_ + bit_off1) : 0u;
+            }
             if constexpr (VERT) {
                 if (has_mask) {
                     k0[set][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_p) + off);
@@ -466,8 +444,12 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     float* const st_lds = As + 5 * TCO;           // STATS / BNRED: [batch 2][wave 4][row 32 = (khalf, e, statistic)][lane quad 8]
 #pragma unroll
     for (int b = 0; b < 2 * MCO; ++b) {
-        const int mi = b >> 1, h = b & 1, set = b & 1;
-        if (b + 1 < 2 * MCO && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        const int mi = b >> 1, h = b & 1, set = NSET == 2 ? (b & 1) : 0;
+        if constexpr (NSET == 2) {
+            if (b + 1 < 2 * MCO && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        } else {
+            if (b > 0) load_batch(0, b);
+        }
         float v0[8], v1[8];
         float q1[8], q2[8];                       // BNRED: this lane's contributions to the two reductions
 #pragma unroll
@@ -478,11 +460,16 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
             const float sh = sh_lds[cl];
             float y0 = S2 ? ma + sh : (ma + mb) + mc + sh;
             float y1 = S2 ? mb + sh : (mb - mc) - md + sh;
-            if constexpr (BNRED) {
+            if constexpr (BNRED != 0) {
                 const float4 cs = *reinterpret_cast<const float4*>(cst_lds + 4 * cl);
                 const float c0 = k0[set][e], c1 = k1[set][e];
-                y0 = (pvalid && fmaf(c0, cs.x, cs.y) > 0.f) ? y0 : 0.f;
-                y1 = (pvalid && y1_ok && fmaf(c1, cs.x, cs.y) > 0.f) ? y1 : 0.f;
+                if constexpr (BNRED == 2) {
+                    y0 = (pvalid && ((w0[set][e] >> bit_sh0) & 1u)) ? y0 + r0[set][e] : 0.f;
+                    y1 = (pvalid && y1_ok && ((w1[set][e] >> bit_sh1) & 1u)) ? y1 + r1[set][e] : 0.f;
+                } else {
+                    y0 = (pvalid && fmaf(c0, cs.x, cs.y) > 0.f) ? y0 : 0.f;
+                    y1 = (pvalid && y1_ok && fmaf(c1, cs.x, cs.y) > 0.f) ? y1 : 0.f;
+                }
                 q1[e] = y0 + y1;
                 q2[e] = fmaf(y0, fmaf(c0, cs.z, cs.w), y1 * fmaf(c1, cs.z, cs.w));
             } else if (DGRAD) {
@@ -549,26 +536,22 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     }
 }
 
-// Filter transforms.  w [Co][Ci][KH][KW] -> ut [KR][K][C][4] with (K, C) = (Ci, Co) for the forward operand and (Co, Ci)
-// for the input gradient's (whose taps run the other way along the Winograd axis: g0 <-> g2; the vertical taps of a 3x3
-// filter keep their index, the kernel walks them with the flipped offset).
+// Filter transforms.  w [Co][Ci][3 taps] -> ut [K][C][4] with (K, C) = (Ci, Co) for the forward operand and (Co, Ci)
+// for the input gradient's (whose taps run the other way along the Winograd axis: g0 <-> g2).
 __global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict__ w, float4* __restrict__ ut,
-                                                        const float* __restrict__ scale, int Co, int Ci, int KH, int KW,
-                                                        int dgrad) {
-    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
+                                                        const float* __restrict__ scale, int Co, int Ci, int dgrad) {
     const int K = dgrad ? Co : Ci, Cr = dgrad ? Ci : Co, Cc = (Cr + 63) & ~63;      // rows padded to the 64-row tile (zeros)
-    const size_t total = (size_t)KR * K * Cc;
+    const size_t total = (size_t)K * Cc;
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= total) return;
     const int c = (int)(o % Cc);
-    const int k = (int)((o / Cc) % K);
-    const int r = (int)(o / ((size_t)Cc * K));
+    const int k = (int)(o / Cc);
     if (c >= Cr) {
         ut[o] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const int co = dgrad ? k : c, ci = dgrad ? c : k;
-    const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    const float* g = w + ((size_t)co * Ci + ci) * 3;
     float g0 = g[0], g1 = g[1], g2 = g[2];
     if (dgrad == 2) {                             // stride-2 input gradient (polyphase): (W1, W2, W0, 0), no transform
         ut[o] = make_float4(g1, g2, g0, 0.f);
@@ -583,7 +566,7 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float* __restrict_
 }
 
 // Many filters in one launch (ops.PackedWeights: once per training step).  desc[d] = {src, dst: float offsets from the
-// two bases; Co | Ci << 32; KH | KW << 8 | dgrad << 16 | first workgroup << 32}.
+// two bases; Co | Ci << 32; KH | KW << 8 | dgrad << 16 | first workgroup << 32} (KH, KW: 3x1 or 1x3 — three taps either way).
 struct WinoPackDesc {
     long long src, dst;
     int Co, Ci, kk, blk0;
@@ -598,21 +581,19 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
         else hi = mid - 1;
     }
     const WinoPackDesc d = desc[lo];
-    const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff, dgrad = (d.kk >> 16) & 3;
-    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
+    const int dgrad = (d.kk >> 16) & 3;
     const int K = dgrad ? d.Co : d.Ci, Cr = dgrad ? d.Ci : d.Co, Cc = (Cr + 63) & ~63;
-    const size_t total = (size_t)KR * K * Cc;
+    const size_t total = (size_t)K * Cc;
     const size_t o = (size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
     if (o >= total) return;
     const int c = (int)(o % Cc);
-    const int k = (int)((o / Cc) % K);
-    const int r = (int)(o / ((size_t)Cc * K));
+    const int k = (int)(o / Cc);
     if (c >= Cr) {
         reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const int co = dgrad ? k : c, ci = dgrad ? c : k;
-    const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * 3;
     float g0 = g[0], g1 = g[1], g2 = g[2];
     if (dgrad == 2) {
         reinterpret_cast<float4*>(dst_base + d.dst)[o] = make_float4(g1, g2, g0, 0.f);
@@ -628,8 +609,8 @@ __global__ void __launch_bounds__(256) wino_pack_multi_kernel(const float* __res
 static bool wino_geom_ok(const dynmm_conv_geom* g, bool dgrad) {
     if (!g || g->c_split != g->Ci) return false;
     if (g->SH != 1 || g->SW != 1) return false;
-    const bool k13 = g->KH == 1 && g->KW == 3, k31 = g->KH == 3 && g->KW == 1, k33 = g->KH == 3 && g->KW == 3;
-    if (!(k13 || k31 || k33)) return false;
+    const bool k13 = g->KH == 1 && g->KW == 3, k31 = g->KH == 3 && g->KW == 1;      // (3x3: conv_wino2d.hip)
+    if (!(k13 || k31)) return false;
     if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
     if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
     const int rows = dgrad ? g->Ci : g->Co, red = dgrad ? g->Co : g->Ci;
@@ -675,26 +656,21 @@ static int launch_wino(WinoArgs& a, bool vert, bool dgrad, hipStream_t st, bool 
     // with 8 blocks per wave behind DYNMM_WINO_TILE=1: slower on every encoder shape but one at batch 32 — C = 256 / 512: 143-148
     // / 125-134 against 115-122 / 108-110 TFLOP/s algorithmic — and removed in round 5 with their six instantiations.)
     const bool tail = a.Co % 64 != 0;
-    const bool kr3 = a.KR == 3;
     a.n_co_tiles = ceil_div(a.Co, 64);
     a.n_p_tiles = ceil_div(a.MP, 64);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_p_tiles));
 #define DYNMM_WINO_LAUNCH(...) hipLaunchKernelGGL((conv_wino_kernel<64, 1, __VA_ARGS__>), grid, dim3(256), 0, st, a)
     if (a.stats && dgrad) {                       // BatchNorm backward reductions from the vertical input gradient
-        DYNMM_WINO_LAUNCH(true, true, false, false, false, true);
+        if (a.bits) DYNMM_WINO_LAUNCH(true, true, false, false, false, 2);
+        else DYNMM_WINO_LAUNCH(true, true, false, false, false, 1);
     } else if (a.stats) {                         // (the entry point admitted only what these instantiations serve)
-        if (kr3) DYNMM_WINO_LAUNCH(false, false, false, false, true, false, true);
-        else DYNMM_WINO_LAUNCH(false, false, false, false, true);
+        DYNMM_WINO_LAUNCH(false, false, false, false, true);
     } else if (tail) {
         if (vert) DYNMM_WINO_LAUNCH(true, false, false, true);
-        else if (kr3) DYNMM_WINO_LAUNCH(false, false, false, true, false, false, true);
         else DYNMM_WINO_LAUNCH(false, false, false, true);
     } else if (vert) {
         if (dgrad) DYNMM_WINO_LAUNCH(true, true);
         else DYNMM_WINO_LAUNCH(true, false);
-    } else if (kr3) {
-        if (dgrad) DYNMM_WINO_LAUNCH(false, true, false, false, false, false, true);
-        else DYNMM_WINO_LAUNCH(false, false, false, false, false, false, true);
     } else {
         if (dgrad) DYNMM_WINO_LAUNCH(false, true);
         else DYNMM_WINO_LAUNCH(false, false);
@@ -715,21 +691,21 @@ extern "C" int dynmm_conv2d_wino_supported(const dynmm_conv_geom* g, int dgrad) 
 
 extern "C" size_t dynmm_wino_packed_floats(int Co, int Ci, int KH, int KW) {
     if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
-    // either operand: [KR][K][rows rounded up to 64][4]
+    if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1))) return 0;
+    // either operand: [K][rows rounded up to 64][4]
     const size_t fwd = (size_t)Ci * ((Co + 63) & ~63), dg = (size_t)Co * ((Ci + 63) & ~63);
-    return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * (fwd > dg ? fwd : dg) * 4;
+    return (fwd > dg ? fwd : dg) * 4;
 }
 
 extern "C" int dynmm_wino_pack(const float* w, float* ut, const float* scale, int Co, int Ci, int KH, int KW, int dgrad,
                                void* stream) {
     (void)hipGetLastError();
     if (!w || !ut || Co <= 0 || Ci <= 0 || (scale && dgrad) || dgrad < 0 || dgrad > 2) return DYNMM_EINVAL;
-    if (dgrad == 2 && KH == 3 && KW == 3) return DYNMM_EUNSUPPORTED;
-    if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
+    if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1))) return DYNMM_EUNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
     const size_t total = dynmm_wino_packed_floats(Co, Ci, KH, KW) / 4;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<float4*>(ut), scale, Co, Ci, KH, KW, dgrad);
+                       reinterpret_cast<float4*>(ut), scale, Co, Ci, dgrad);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -761,15 +737,21 @@ extern "C" int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const floa
     a.x = x; a.ut = ut; a.shift = bias; a.residual = residual; a.mask = nullptr; a.y = y;
     a.N = g->N; a.Ci = g->Ci; a.Co = g->Co; a.H = g->H; a.W = g->W;
     a.CoS = (g->Co + 63) & ~63;
-    a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = act;
     return launch_wino(a, g->KW == 1, false, (hipStream_t)stream);
 }
 
 extern "C" int dynmm_conv2d_wino_dgrad_bnred_supported(const dynmm_conv_geom* g) {
-    // 3x1 stride-1 input gradient on the pair kernel; few enough pixel tiles that their atomics on one address do not serialise
-    return (wino_geom_ok(g, true) && g->KH == 3 && g->KW == 1 && g->Ci % 64 == 0 &&
-            ceil_div(g->N * ((g->H + 1) / 2) * g->W, 64) <= 2400) ? 1 : 0;
+    // 3x1 stride-1 input gradient on the pair kernel
+    return (wino_geom_ok(g, true) && g->KH == 3 && g->KW == 1 && g->Ci % 64 == 0) ? 1 : 0;
+}
+
+extern "C" int dynmm_conv2d_wino_dgrad_bnred_slots(const dynmm_conv_geom* g) {
+    // thousands of pixel tiles adding to one address serialise (measured on the forward's statistics: 4800 tiles on one
+    // address cost a C = 64 launch 18 %): pixel tile p adds into slab p % slots, <= 600 tiles per address up to 8 slabs
+    if (!dynmm_conv2d_wino_dgrad_bnred_supported(g)) return 0;
+    const int s = ceil_div(g->N * ((g->H + 1) / 2) * g->W, 64) / 600;
+    return s < 1 ? 1 : (s > 8 ? 8 : s);
 }
 
 extern "C" int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, const float* bn_x, const float* bn_mean,
@@ -783,11 +765,31 @@ extern "C" int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, c
         return DYNMM_EUNSUPPORTED;
     WinoArgs a{};
     a.x = dy; a.ut = ut; a.shift = nullptr; a.residual = nullptr; a.mask = bn_x; a.y = dx;
-    a.stats = sums; a.nslots = 1;
+    a.stats = sums; a.nslots = dynmm_conv2d_wino_dgrad_bnred_slots(g);
     a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_gamma = bn_gamma; a.bn_beta = bn_beta;
     a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;
     a.CoS = (a.Co + 63) & ~63;
-    a.KR = 1;
+    a.act = DYNMM_ACT_NONE;
+    a.Hin = g->Ho; a.Win = g->Wo;
+    return launch_wino(a, true, true, (hipStream_t)stream);
+}
+
+extern "C" int dynmm_conv2d_wino_dgrad_bnred2(const float* dy, const float* ut, const float* accum, const float* bn_x,
+                                              const unsigned long long* relu_bits, const float* bn_mean, const float* bn_invstd,
+                                              double* sums, float* dx, const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (!dy || !ut || !bn_x || !relu_bits || !bn_mean || !bn_invstd || !sums || !dx || !g) return DYNMM_EINVAL;
+    if (!dynmm_conv2d_wino_dgrad_bnred_supported(g) || (g->H * g->W) % 4 != 0) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut)) & 15u) return DYNMM_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(bn_x) | reinterpret_cast<uintptr_t>(accum) |
+         reinterpret_cast<uintptr_t>(sums) | reinterpret_cast<uintptr_t>(relu_bits)) & 7u)
+        return DYNMM_EUNSUPPORTED;
+    WinoArgs a{};
+    a.x = dy; a.ut = ut; a.shift = nullptr; a.residual = accum; a.mask = bn_x; a.y = dx;
+    a.stats = sums; a.nslots = dynmm_conv2d_wino_dgrad_bnred_slots(g); a.bits = relu_bits;
+    a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_gamma = bn_invstd; a.bn_beta = bn_invstd;      // (gamma / beta: BNRED == 1 only)
+    a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;
+    a.CoS = (a.Co + 63) & ~63;
     a.act = DYNMM_ACT_NONE;
     a.Hin = g->Ho; a.Win = g->Wo;
     return launch_wino(a, true, true, (hipStream_t)stream);
@@ -815,7 +817,6 @@ extern "C" int dynmm_conv2d_wino_fwd_stats(const float* x, const float* ut, cons
     a.x = x; a.ut = ut; a.shift = bias; a.residual = nullptr; a.mask = nullptr; a.y = y; a.stats = stats; a.nslots = nslots;
     a.N = g->N; a.Ci = g->Ci; a.Co = g->Co; a.H = g->H; a.W = g->W;
     a.CoS = g->Co;
-    a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = DYNMM_ACT_NONE;
     return launch_wino(a, false, false, (hipStream_t)stream);
 }
@@ -833,7 +834,6 @@ extern "C" int dynmm_conv2d_wino_dgrad(const float* dy, const float* ut, const f
     a.x = dy; a.ut = ut; a.shift = nullptr; a.residual = accum; a.mask = mask; a.y = dx;
     a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;         // the roles of the channel counts swap
     a.CoS = (a.Co + 63) & ~63;
-    a.KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     a.act = DYNMM_ACT_NONE;
     a.Hin = g->Ho; a.Win = g->Wo;                                             // (stride 2: dy is half as high / wide as dx)
     return launch_wino(a, g->KW == 1, true, (hipStream_t)stream, s2);

@@ -1,4 +1,4 @@
-// Input gradients of the stride-1 three-tap / 3x3 convolutions by the 1-D Winograd algorithm F(4,3) on the fp32 matrix cores:
+// Input gradients of the stride-1 1x3 convolutions by the 1-D Winograd algorithm F(4,3) on the fp32 matrix cores:
 // FOUR neighbouring outputs of a three-tap filter from SIX multiplications (direct: twelve; F(2,3), conv_wino.hip: eight), i.e.
 // half of the direct convolution's matrix work.  With d0..d5 the six inputs under an output quad and g the (flipped) filter:
 //     V = B^T d :  4d0-5d2+d4 | (d4-4d2)+(d3-4d1) | (d4-4d2)-(d3-4d1) | (d4-d2)+2(d3-d1) | (d4-d2)-2(d3-d1) | 4d1-5d3+d5
@@ -8,17 +8,18 @@
 // measured against fp64 (scratch/r4/wino43_numerics.py; tests/test_hip_ops.py on the GPU) the result is 1.7e-6 .. 2.8e-6 from
 // the truth in max-norm where a direct fp32 sum is 2e-7 .. 3e-7.  That is why this form serves the BACKWARD only — an input
 // gradient is compared with its fp64 value at 2e-4 (GTOL) and enters a gradient whose fp32 conditioning noise is 1e-2 (DESIGN.md
-// section 1); forward passes (F(2,3), conv_wino.hip) never see it.  Horizontal taps only (1x3, and 3x3 with the vertical taps looped): the
-// vertical form of round 4 — six input rows per four output rows — measured slower than F(2,3) and was removed in round 5.
+// section 1); forward passes (F(2,3), conv_wino.hip) never see it.  Horizontal taps only: the vertical form of round 4 — six
+// input rows per four output rows — measured slower than F(2,3) and was removed in round 5; 3x3 filters (round 4: this form with
+// the vertical taps looped, 1/2 of the direct work) run on the 2-D F(2x2,3x3) of conv_wino2d.hip (4/9) since round 5.
 //
 // Structure = conv_wino.hip's small tile: 64 co x 64 quads per workgroup, a wave owns 32 co x 32 quads x 6 transforms = 6
 // accumulator blocks (96 registers, two workgroups per CU); operands by direct global -> LDS loads into a 3-slot ring (8 channels
 // per stage), fragments of k-pair q + 1 read under the 6 MFMAs of k-pair q (across stage boundaries too), phases pinned.
-//   * filter operand: two planes [tap row][ci][co][4] (U0..U3) and [tap row][ci][co][2] (U4, U5): one ds_read_b128 + one
+//   * filter operand: two planes [ci][co][4] (U0..U3) and [ci][co][2] (U4, U5): one ds_read_b128 + one
 //     ds_read_b64 per k-pair;
 //   * horizontal taps: raw tile [8 channels][4 * quads + 8] pixels (16-byte quads, 4-pixel halo either side), a lane reads
 //     d0 | (d1..d4) | d5;
-//   * zero padding by lane-constant selects on the raw values (a column outside the image), a whole vertical tap of a 3x3 filter outside the image reads a zero slot;
+//   * zero padding by lane-constant selects on the raw values (a column outside the image);
 //   * epilogue: output transform, ReLU mask of the producer, accumulated residual gradient; horizontal quads are 16-byte
 //     stores; the epilogue operands of batch b + 1 (4 channels x 4 outputs) are requested before batch b is stored.
 #include <stdlib.h>
@@ -30,19 +31,16 @@ namespace dynmm {
 
 struct Wino43Args {
     const float* x;         // input [N, Ci, H, W] (the convolution's dy: Ci = its Co)
-    const float* ut4;       // filter transforms U0..U3  [KR][Ci][Co][4]
-    const float* ut2;       //                   U4, U5  [KR][Ci][Co][2]
+    const float* ut4;       // filter transforms U0..U3  [Ci][Co][4]
+    const float* ut2;       //                   U4, U5  [Ci][Co][2]
     const float* residual;  // like y or nullptr: added after the mask
     const float* mask;      // like y or nullptr: y = mask > 0 ? y : 0
     float* y;               // [N, Co, H, W]
     int N, Ci, Co, H, W;
-    int KR;                 // 3: 3x3 filter (vertical taps looped as part of the reduction); else 1
     int MQ;                 // output quads
     int n_co_tiles, n_q_tiles;
 };
 
-// KR3: 3x3 filter (a template flag since round 5, as in conv_wino.hip: the three-tap launches carry no tap bookkeeping)
-template <bool KR3 = false>
 __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a) {
     constexpr int BK = 8, S = 3, TCO = 64, TQ = 64, NT = 6;
     constexpr int A4_STAGE = BK * TCO * 4, A2_STAGE = BK * TCO * 2;         // floats
@@ -57,7 +55,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     __shared__ __attribute__((aligned(16))) float A4s[S * A4_STAGE];
     __shared__ __attribute__((aligned(16))) float A2s[S * A2_STAGE];
     __shared__ __attribute__((aligned(16))) float Bs[S * B_STAGE];
-    __shared__ __attribute__((aligned(16))) float Zs[KR3 ? B_STAGE : 4];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -71,12 +68,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     const int q0 = (lin / a.n_co_tiles) * TQ;
     const int HW = a.H * a.W;
     const int NC = a.Ci / BK;
-    const int nst = KR3 ? 3 * NC : NC;
-    auto dh_of = [&](int r) { return KR3 ? 1 - r : 0; };       // (input gradient: the vertical taps run the other way)
+    const int nst = NC;
 
     // ---------------------------------------------------------------- loader state
     unsigned b_off[NIB];
-    unsigned b_rows = 0;
     bool b_act[NIB];
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
@@ -88,14 +83,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         int m = 4 * q0 - 4 + 4 * quad;
         m = m < 0 ? 0 : (m > M - 4 ? M - 4 : m);
         const int n = m / HW, rem = m - n * HW;
-        const int h = rem / a.W;
         b_off[i] = ((unsigned)(n * a.Ci + k) * (unsigned)HW + (unsigned)rem) * 4u;
-        if constexpr (KR3) {
-            for (int r = 0; r < 3; ++r) {
-                const int hh = h + dh_of(r);
-                b_rows |= (hh >= 0 && hh < a.H) ? (1u << (3 * i + r)) : 0u;
-            }
-        }
     }
     const unsigned a4_voff = (unsigned)lane * 16u;
     const unsigned a2_voff = (unsigned)((lane >> 5) * a.Co * 8 + (lane & 31) * 16);      // two 512-byte rows per instruction
@@ -112,8 +100,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     unsigned l_bdst = lds_b + (unsigned)(wave * QPW * 4 * 4);
     const unsigned l_a4dst_end = l_a4dst + (unsigned)(S * A4_STAGE * 4);
     int l_left = nst;
-    int l_r = 0, l_c = 0;
-    unsigned l_shift = (unsigned)(dh_of(0) * a.W * 4);
     auto issue = [&]() {
         if (l_left > 0) {
             dma16(a4_ptr, a4_voff, l_a4dst);
@@ -121,9 +107,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
             dma16(a2_ptr, a2_voff, l_a2dst);
 #pragma unroll
             for (int i = 0; i < NIB; ++i) {
-                unsigned voff = b_off[i];
-                if constexpr (KR3) voff += ((b_rows >> (3 * i + l_r)) & 1u) ? l_shift : 0u;
-                if (b_act[i]) dma16(b_ptr, voff, l_bdst + (unsigned)i * 1024u);
+                if (b_act[i]) dma16(b_ptr, b_off[i], l_bdst + (unsigned)i * 1024u);
             }
             --l_left;
             a4_ptr += a4_step;
@@ -137,14 +121,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
                 l_a2dst -= (unsigned)(S * A2_STAGE * 4);
                 l_bdst -= (unsigned)(S * B_STAGE * 4);
             }
-            if constexpr (KR3) {
-                if (++l_c == NC) {
-                    l_c = 0;
-                    ++l_r;
-                    b_ptr = a.x;
-                    l_shift = (unsigned)(dh_of(l_r) * a.W * 4);
-                }
-            }
         }
     };
 
@@ -154,7 +130,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     const bool qvalid = qg < a.MQ;
     int pn, prem;                                 // image and pixel offset of the quad's first output
     bool dv[6];                                   // d_j lies inside the image
-    unsigned rbits = 7u;
     {
         const int pc = qvalid ? qg : 0;
         const int m = 4 * pc;
@@ -165,13 +140,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         for (int j = 0; j < 6; ++j) dv[j] = true;
         dv[0] = w > 0;
         dv[5] = w + 4 < a.W;
-        if constexpr (KR3) {
-            rbits = 0;
-            for (int r = 0; r < 3; ++r) {
-                const int hh = h + dh_of(r);
-                rbits |= (hh >= 0 && hh < a.H) ? (1u << r) : 0u;
-            }
-        }
     }
     const int a4_frag = (khalf * TCO + wave_co * 32 + l31) * 4;            // + 2q * TCO * 4
     const int a2_frag = (khalf * TCO + wave_co * 32 + l31) * 2;            // + 2q * TCO * 2
@@ -182,10 +150,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-    if constexpr (KR3) {
-        for (int i = t; i < B_STAGE; i += 256) Zs[i] = 0.f;
-    }
 
     float4 fa4[2];
     float2 fa2[2];
@@ -226,14 +190,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     issue();
     wait_vm<2 * NI>();
     __syncthreads();
-    int cr = 0, cc = 0;
     int c_a4 = 0, c_a2 = 0, c_b = 0;              // ring offsets (floats) of the stage being consumed
     const float* A4p = A4s;
     const float* A2p = A2s;
     const float* Bp = Bs;
-    if constexpr (KR3) {
-        if (!(rbits & 1u)) Bp = Zs;
-    }
     read_raw(0, 0, A4p, A2p, Bp);
     transform(0);
     for (int s = 0; s < nst; ++s) {
@@ -268,10 +228,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
             A4p = A4s + c_a4;
             A2p = A2s + c_a2;
             Bp = Bs + c_b;
-            if constexpr (KR3) {
-                if (++cc == NC) { cc = 0; ++cr; }
-                if (!((rbits >> cr) & 1u)) Bp = Zs;
-            }
             read_raw(0, 0, A4p, A2p, Bp);
         }
         DYNMM_W43_PHASE();
@@ -347,7 +303,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     }
 }
 
-// Filter transforms of the input gradient: w [Co][Ci][KH][KW] -> ut4 [KR][Co][Ci][4], ut2 [KR][Co][Ci][2] (reduction = the
+// Filter transforms of the input gradient: w [Co][Ci][1][3] -> ut4 [Co][Ci][4], ut2 [Co][Ci][2] (reduction = the
 // convolution's Co, rows = its Ci; the taps run the other way along the Winograd axis).
 __device__ __forceinline__ void wino43_u(float g0, float g1, float g2, float4& u4, float2& u2) {
     const float s = g0 + g2;
@@ -370,15 +326,10 @@ __global__ void __launch_bounds__(256) wino43_pack_multi_kernel(const float* __r
         else hi = mid - 1;
     }
     const Wino43PackDesc d = desc[lo];
-    const int KH = d.kk & 0xff, KW = (d.kk >> 8) & 0xff;
-    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
-    const size_t total = (size_t)KR * d.Co * d.Ci;
+    const size_t total = (size_t)d.Co * d.Ci;
     const size_t o = (size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
     if (o >= total) return;
-    const int ci = (int)(o % d.Ci);
-    const int co = (int)((o / d.Ci) % d.Co);
-    const int r = (int)(o / ((size_t)d.Ci * d.Co));
-    const float* g = src_base + d.src + ((size_t)co * d.Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    const float* g = src_base + d.src + o * 3;    // o = co * Ci + ci
     float4 u4;
     float2 u2;
     wino43_u(g[2], g[1], g[0], u4, u2);           // flipped taps
@@ -386,16 +337,11 @@ __global__ void __launch_bounds__(256) wino43_pack_multi_kernel(const float* __r
     reinterpret_cast<float2*>(dst_base + d.dst + total * 4)[o] = u2;
 }
 
-__global__ void __launch_bounds__(256) wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ ut, int Co, int Ci, int KH,
-                                                          int KW) {
-    const int KR = (KH == 3 && KW == 3) ? 3 : 1;
-    const size_t total = (size_t)KR * Co * Ci;
+__global__ void __launch_bounds__(256) wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ ut, int Co, int Ci) {
+    const size_t total = (size_t)Co * Ci;
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= total) return;
-    const int ci = (int)(o % Ci);
-    const int co = (int)((o / Ci) % Co);
-    const int r = (int)(o / ((size_t)Ci * Co));
-    const float* g = w + ((size_t)co * Ci + ci) * (KH * KW) + (KR == 3 ? 3 * r : 0);
+    const float* g = w + o * 3;                   // o = co * Ci + ci
     float4 u4;
     float2 u2;
     wino43_u(g[2], g[1], g[0], u4, u2);
@@ -406,8 +352,7 @@ __global__ void __launch_bounds__(256) wino43_pack_kernel(const float* __restric
 static bool wino43_geom_ok(const dynmm_conv_geom* g) {
     if (!g || g->c_split != g->Ci) return false;
     if (g->SH != 1 || g->SW != 1) return false;
-    const bool k13 = g->KH == 1 && g->KW == 3, k33 = g->KH == 3 && g->KW == 3;      // horizontal taps only (a vertical form was
-    if (!(k13 || k33)) return false;                                                // measured slower in round 4 and removed in round 5)
+    if (!(g->KH == 1 && g->KW == 3)) return false;      // horizontal taps (vertical: measured slower; 3x3: conv_wino2d.hip)
     if (g->PH != g->KH / 2 || g->PW != g->KW / 2 || g->H != g->Ho || g->W != g->Wo) return false;
     if (g->W % 4 != 0 || g->W < 4 || g->H < 2) return false;
     if (g->Ci % 64 != 0 || g->Co % 8 != 0 || g->Co < 24) return false;       // rows = Ci (64-row tile), reduction = Co
@@ -423,18 +368,17 @@ using namespace dynmm;
 extern "C" int dynmm_conv2d_wino43_supported(const dynmm_conv_geom* g) { return wino43_geom_ok(g) ? 1 : 0; }
 
 extern "C" size_t dynmm_wino43_packed_floats(int Co, int Ci, int KH, int KW) {
-    if (Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return 0;
-    return (size_t)((KH == 3 && KW == 3) ? 3 : 1) * Co * Ci * 6;
+    if (Co <= 0 || Ci <= 0 || KH != 1 || KW != 3) return 0;
+    return (size_t)Co * Ci * 6;
 }
 
 extern "C" int dynmm_wino43_pack(const float* w, float* ut, int Co, int Ci, int KH, int KW, void* stream) {
     (void)hipGetLastError();
     if (!w || !ut || Co <= 0 || Ci <= 0) return DYNMM_EINVAL;
-    if (!((KH == 1 && KW == 3) || (KH == 3 && KW == 1) || (KH == 3 && KW == 3))) return DYNMM_EUNSUPPORTED;
+    if (!(KH == 1 && KW == 3)) return DYNMM_EUNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ut) & 15u) return DYNMM_EINVAL;
     const size_t total = dynmm_wino43_packed_floats(Co, Ci, KH, KW) / 6;
-    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ut, Co, Ci,
-                       KH, KW);
+    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)ceil_div_sz(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ut, Co, Ci);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
@@ -463,17 +407,14 @@ extern "C" int dynmm_conv2d_wino43_dgrad(const float* dy, const float* ut, const
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(dx) |
          reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(accum)) & 15u)
         return DYNMM_EUNSUPPORTED;
-    const int KR = (g->KH == 3 && g->KW == 3) ? 3 : 1;
     Wino43Args a{};
-    a.x = dy; a.ut4 = ut; a.ut2 = ut + (size_t)KR * g->Co * g->Ci * 4; a.residual = accum; a.mask = mask; a.y = dx;
+    a.x = dy; a.ut4 = ut; a.ut2 = ut + (size_t)g->Co * g->Ci * 4; a.residual = accum; a.mask = mask; a.y = dx;
     a.N = g->N; a.Ci = g->Co; a.Co = g->Ci; a.H = g->H; a.W = g->W;          // the roles of the channel counts swap
-    a.KR = KR;
     a.MQ = a.N * a.H * a.W / 4;
     a.n_co_tiles = a.Co / 64;
     a.n_q_tiles = ceil_div(a.MQ, 64);
     dim3 grid((unsigned)(a.n_co_tiles * a.n_q_tiles));
-    if (KR == 3) hipLaunchKernelGGL((conv_wino43_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_wino43_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_wino43_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }

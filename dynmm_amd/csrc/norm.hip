@@ -229,7 +229,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const bool remask = act != DYNMM_ACT_NONE && y == nullptr && mask_bits == nullptr;
     const float sc = remask ? gamma[c] * is : 0.f;
     const float sh = remask ? fmaf(-mu, sc, beta[c]) : 0.f;
-    const float sg = (float)sums[c], sgx = (float)sums[C + c];
+    // (training = the number of slabs [n][2][C] the two sums arrive in: 1 from bn_bwd_reduce, the slots of a convolution's
+    // input-gradient epilogue otherwise — conv_wino.hip BNRED; summed here in slab order by every workgroup alike)
+    double sg_d = sums[c], sgx_d = sums[C + c];
+    for (int s = 1; s < training; ++s) {
+        sg_d += sums[(size_t)(2 * s) * C + c];
+        sgx_d += sums[(size_t)(2 * s + 1) * C + c];
+    }
+    const float sg = (float)sg_d, sgx = (float)sgx_d;
     if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
         if (dgamma) dgamma[c] = sgx;
         if (dbeta) dbeta[c] = sg;

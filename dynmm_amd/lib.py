@@ -56,7 +56,9 @@ SIGNATURES = {
     'dynmm_wino_pack_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     'dynmm_conv2d_wino_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
     'dynmm_conv2d_wino_dgrad_bnred_supported': (c_i, [_GP]),
+    'dynmm_conv2d_wino_dgrad_bnred_slots': (c_i, [_GP]),
     'dynmm_conv2d_wino_dgrad_bnred': (c_i, [c_f] * 9 + [_GP, c_f]),
+    'dynmm_conv2d_wino_dgrad_bnred2': (c_i, [c_f] * 9 + [_GP, c_f]),
     'dynmm_conv2d_wino_fwd_stats_supported': (c_i, [_GP]),
     'dynmm_conv2d_wino_fwd_stats_slots': (c_i, [_GP]),
     'dynmm_conv2d_wino_fwd_stats': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, _GP, c_f]),

@@ -50,24 +50,31 @@ class NonBottleneck1D(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes, eps=1e-3)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, chain=False):
+        """chain: x is the output of the previous NonBottleneck1D block and this block is its only consumer (the stage loops
+        below say so) — the previous block's bn2 backward reductions then come out of this block's first input-gradient launch."""
         # Backward fusions (forward results unchanged): the ReLU backward of each 3x1 conv is applied in
         # the dgrad epilogue of the 1x3 conv that consumes it, and the identity branch's gradient is
         # added in the dgrad epilogue of the first conv instead of a separate autograd add pass.
         fuse_bwd = torch.is_grad_enabled() and x.requires_grad
         link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
+        in_link = getattr(x, '_bn_out_link', None) if (chain and link is not None) else None
         xd = x
         if self.downsample is not None:
             x, xd = ops.fan_out(x, 2)            # x feeds the first conv AND the down-sample conv: one fused gradient sum
         c = self.conv3x1_1
-        y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link)
+        y = ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, link=link, bn_link=in_link)
         # bn1 + ReLU feed conv3x1_2 and nothing else: its input-gradient launch also does bn1's backward reductions (ops.BNLink)
         bnl = ops.BNLink() if (fuse_bwd and self.bn1.training) else None
         y = conv_bn_act(y, self.conv1x3_1, self.bn1, 'relu', mask_input=fuse_bwd, bwd_link=bnl)
         c = self.conv3x1_2
         y = ops.conv2d(y, c.weight, c.bias, c.stride, c.padding, 'relu', defer_mask=fuse_bwd, bn_link=bnl)
         idt = x if self.downsample is None else conv_bn_act(xd, self.downsample[0], self.downsample[1])
-        return conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link)
+        out_link = ops.BNLink() if (fuse_bwd and self.bn2.training) else None
+        out = conv_bn_act(y, self.conv1x3_2, self.bn2, 'relu', residual=idt, mask_input=fuse_bwd, res_link=link, bwd_link=out_link)
+        if out_link is not None and out_link.bits is not None:
+            out._bn_out_link = out_link            # picked up by the next block of the stage (chain=True), by nothing else
+        return out
 
 
 class BasicBlock(nn.Module):
@@ -82,7 +89,7 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, chain=False):
         fuse_bwd = torch.is_grad_enabled() and x.requires_grad
         link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
         xd = x
@@ -108,7 +115,7 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * self.expansion)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, chain=False):
         fuse_bwd = torch.is_grad_enabled() and x.requires_grad
         link = ops.GradLink() if (fuse_bwd and self.downsample is None) else None
         xd = x
@@ -163,8 +170,8 @@ class ResNetEncoder(nn.Module):
         return conv_bn_act(x, self.conv1, self.bn1, 'relu')
 
     def _stage(self, x, j):
-        for blk in getattr(self, f'layer{j}'):
-            x = blk(x)
+        for i, blk in enumerate(getattr(self, f'layer{j}')):
+            x = blk(x, chain=i > 0)               # (block i > 0 is the only consumer of block i - 1's output)
         return x
 
     def forward_layer1(self, x):

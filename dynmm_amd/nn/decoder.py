@@ -33,8 +33,8 @@ class DecoderModule(nn.Module):
 
     def forward(self, x, skip):
         y = self.conv3x3(x)
-        for blk in self.decoder_blocks:
-            y = blk(y)
+        for i, blk in enumerate(self.decoder_blocks):
+            y = blk(y, chain=i > 0)
         side = None
         if self.training:
             s = self.side_output

@@ -42,18 +42,19 @@ def _chk(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Three-tap / 3x3 convolutions by 1-D Winograd F(2,3) (csrc/conv_wino.hip: 2/3 of the matrix-core work, fp32) — forward (training
-# and inference), input gradients and weight gradients of every stride-1 1x3 / 3x1 / 3x3 convolution the kernels' geometry rules
-# admit; everything else (and a pass switched off here) runs on the operand-ring / tile kernels, which therefore stay in the
-# library either way.  These are MODULE ATTRIBUTES — caller options used by the parity tests (tests/test_hip_ops.py:
-# test_conv2d_winograd runs every mode) — not environment switches:
+# Winograd convolutions on the fp32 matrix cores: the stride-1 1x3 / 3x1 convolutions by 1-D F(2,3) (csrc/conv_wino.hip: 2/3 of the
+# direct matrix work), the 3x3 ones by 2-D F(2x2,3x3) (csrc/conv_wino2d.hip: 4/9) — forward (training and inference) and input
+# gradients of every convolution the kernels' geometry rules admit; the weight gradients by the three-tap form of
+# csrc/conv_wgrad_v6.hip / conv_wgrad_wino_vt.hip.  Everything else (and a pass switched off here) runs on the operand-ring / tile
+# kernels, which therefore stay in the library either way.  These are MODULE ATTRIBUTES — caller options used by the parity tests
+# (tests/test_hip_ops.py: test_conv2d_winograd runs every mode) — not environment switches:
 #   WINO        'all' (default) | 'dgrad' (input gradients only: direct training forward) | 'fwd' | '0'.  The training forward in
 #               the Winograd form is closer to the fp64 result than the direct kernels on every shape tried (1.0e-6 vs 1.35e-6 on
 #               the decoder module's outputs); inference always takes it when WINO != '0'.
 #   WINO_DGRAD  '43h' (default): F(4,3) (csrc/conv_wino43.hip: 1/2 of the work, 1e-6 .. 4e-6 from fp64) for the input gradients of
-#               the horizontal-tap filters 1x3 / 3x3, F(2,3) for the vertical ones | '23': F(2,3) everywhere.  (A vertical F(4,3)
-#               form existed in round 4 — six input rows per four output rows through b32 reads, 72.37 ms against 71.63 — and was
-#               removed in round 5.)
+#               the 1x3 filters, F(2,3) for the 3x1 ones | '23': F(2,3) for both.  (A vertical F(4,3) form existed in round 4 — six
+#               input rows per four output rows through b32 reads, 72.37 ms against 71.63 — and was removed in round 5.  3x3
+#               filters take the 2-D form under either value.)
 #   CONV_BN_STATS  BatchNorm batch statistics from the epilogue of the convolution that feeds the BatchNorm (conv_wino.hip STATS)
 #               instead of a bn_stats launch + a pass over the conv output.
 WINO = 'all'
@@ -82,7 +83,7 @@ _WINO2D_OK = {}
 
 def _wino2d(g, dgrad, x2=None, infer=False):
     """does this pass of this (3x3) convolution run on the 2-D Winograd kernel (csrc/conv_wino2d.hip: 4/9 of the direct matrix work)?
-    Same switches as _wino; where it applies it replaces the 1-D forms (horizontal F(2,3) with looped vertical taps, F(4,3))."""
+    Same WINO switch as _wino (round 4 ran 3x3 filters on the 1-D forms with the vertical taps looped: 2/3 and 1/2; removed)."""
     if WINO == '0' or x2 is not None or g.KH != 3 or g.KW != 3:
         return False
     if not infer and ((WINO == 'dgrad' and not dgrad) or (WINO == 'fwd' and dgrad)):
@@ -413,11 +414,19 @@ class BNLink:
     """Joins a training-mode BatchNorm + ReLU to the single convolution that consumes its output, for the backward pass: the
     convolution's input-gradient launch (csrc/conv_wino.hip BNRED) also leaves the BatchNorm backward's two reductions, and the
     BatchNorm's backward then starts at its apply pass.  batch_norm_act fills `x, mean, invstd, gamma, beta` in the forward; the
-    convolution's backward fills `sums` when its kernel took the job (it runs first: gradients flow consumer -> producer)."""
-    __slots__ = ('x', 'mean', 'invstd', 'gamma', 'beta', 'sums')
+    convolution's backward fills `sums` when its kernel took the job (it runs first: gradients flow consumer -> producer).
+
+    Second form (`bits` set; BNRED == 2): the BatchNorm adds an identity branch before the ReLU (bn2 of a residual block) and its
+    output feeds the NEXT block and nothing else — that block's first convolution (this link's consumer) and its identity branch,
+    whose gradient that convolution's input-gradient epilogue absorbs (GradLink).  The launch then holds the complete gradient g
+    of the BatchNorm's output: it masks it with the forward's one-bit ReLU decisions, writes g.[out > 0] and leaves the two
+    reductions; `premasked` tells the BatchNorm's backward that its incoming gradient already carries the mask (its apply pass
+    runs without the bits, and the identity branch's gradient IS that tensor: no second masked copy is written)."""
+    __slots__ = ('x', 'mean', 'invstd', 'gamma', 'beta', 'sums', 'bits', 'premasked')
 
     def __init__(self):
-        self.x = self.mean = self.invstd = self.gamma = self.beta = self.sums = None
+        self.x = self.mean = self.invstd = self.gamma = self.beta = self.sums = self.bits = None
+        self.premasked = False
 
 
 BN_BWD_FUSE = True       # (module attribute: tests switch it to compare with the bn_bwd_reduce path)
@@ -572,7 +581,7 @@ class _Conv2d(Function):
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         y = torch.empty((g.N, g.Co, g.Ho, g.Wo), device=x.device, dtype=torch.float32)
         # (the Winograd kernels read their input with 16-byte loads; an input off that grid takes the direct kernels)
-        w2f = _wino2d(g, False, x2) and x.data_ptr() % 16 == 0          # 3x3: the 2-D form replaces the 1-D ones where it applies
+        w2f = _wino2d(g, False, x2) and x.data_ptr() % 16 == 0          # 3x3: the 2-D form; 1x3 / 3x1: the 1-D ones
         w2d = need_dx and _wino2d(g, True, x2)
         wino_f = not w2f and _wino(g, False, x2) and x.data_ptr() % 16 == 0
         wino_d = need_dx and not w2d and _wino(g, True, x2)
@@ -701,11 +710,25 @@ class _Conv2d(Function):
                 gyw = gy if gy.data_ptr() % 16 == 0 else gy.clone()
                 mask, accum = (t if (t is None or t.data_ptr() % 16 == 0) else t.clone() for t in (mask, accum))
                 bl = ctx.bn_link
-                if (bl is not None and bl.x is not None and ctx.wino_d == 23 and mask is None and accum is None and
+                if (bl is not None and bl.x is not None and bl.bits is not None and ctx.wino_d == 23 and mask is None and
+                        bl.x.data_ptr() % 8 == 0 and (g.H * g.W) % 4 == 0 and
+                        lib.dynmm_conv2d_wino_dgrad_bnred_supported(C.byref(g))):
+                    # x = relu(BN(c) + identity), this convolution and the identity branch behind `accum` its only consumers: the
+                    # complete gradient of that output is formed here — mask it with the forward's decisions and leave the
+                    # BatchNorm's backward reductions with the link
+                    sums, zeroed = _zero_sums(2 * g.Ci * lib.dynmm_conv2d_wino_dgrad_bnred_slots(C.byref(g)), dx.device)
+                    if not zeroed:
+                        sums.zero_()
+                    L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_wino_dgrad_bnred2(
+                        _p(gyw), _p(wpd), _p(accum), _p(bl.x), _p(bl.bits), _p(bl.mean), _p(bl.invstd), _p(sums), _p(dx),
+                        C.byref(g), st), extra=2, wino=ctx.wino_d), 'conv2d_wino_dgrad_bnred2')
+                    bl.sums, bl.premasked = sums, True
+                elif (bl is not None and bl.x is not None and bl.bits is None and ctx.wino_d == 23 and mask is None and
+                        accum is None and
                         bl.x.data_ptr() % 8 == 0 and lib.dynmm_conv2d_wino_dgrad_bnred_supported(C.byref(g))):
                     # x = relu(BN(c)) of a training-mode BatchNorm: mask by [BN(c) > 0] here and leave that BatchNorm's backward
                     # reductions with the link (its backward, which runs next, skips its reduction pass)
-                    sums, zeroed = _zero_sums(2 * g.Ci, dx.device)
+                    sums, zeroed = _zero_sums(2 * g.Ci * lib.dynmm_conv2d_wino_dgrad_bnred_slots(C.byref(g)), dx.device)
                     if not zeroed:
                         sums.zero_()
                     L.check(_timed('dgrad', g, lambda: lib.dynmm_conv2d_wino_dgrad_bnred(
@@ -757,7 +780,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=None, x2=None, mask_in
       link       : GradLink whose residual-branch gradient is added in the dgrad epilogue.
     bn_stats: the output goes straight into a training-mode batch_norm_act: where the forward kernel can, it leaves the BatchNorm's
     batch statistics with the output (`y._bn_sums`) and batch_norm_act skips its statistics pass.
-    bn_link: x is the output of batch_norm_act(..., 'relu', bwd_link=bn_link) and this convolution is its only consumer (BNLink)."""
+    bn_link: x is the output of batch_norm_act(..., 'relu', bwd_link=bn_link) and this convolution is its only consumer — or, for a
+    BatchNorm with an identity branch, its only consumer besides the identity branch behind `link` (BNLink, both forms)."""
     if not torch.is_grad_enabled() and isinstance(weight, torch.nn.Parameter) and w_owner is None:
         # inference: the packed weight is cached on the parameter (conv2d_fused_eval) instead of re-laid-out per call
         # (the factorised blocks' conv -> ReLU pairs were 83 pack launches per forward of config P)
@@ -951,8 +975,9 @@ class _BatchNormAct(Function):
         ctx.training = training
         ctx.link = link
         ctx.bwd_link = None
-        if bwd_link is not None and training and act == L.ACT_RELU and residual is None:
+        if bwd_link is not None and training and act == L.ACT_RELU and (residual is None or bits is not None):
             bwd_link.x, bwd_link.mean, bwd_link.invstd, bwd_link.gamma, bwd_link.beta = x, mean, invstd, gamma, beta
+            bwd_link.bits = bits if residual is not None else None
             ctx.bwd_link = bwd_link
         ctx.has_res = residual is not None
         # ReLU without residual: the backward re-derives the mask from x (bit-identical to this forward's
@@ -974,22 +999,25 @@ class _BatchNormAct(Function):
         HW = H * W
         dev = x.device
         bl = ctx.bwd_link
+        act = ctx.act
         if bl is not None and bl.sums is not None:
             sums, bl.sums = bl.sums, None          # left by the consumer convolution's input-gradient launch (BNLink)
+            if bl.premasked:                       # ... which also applied the ReLU decisions to gy (BNRED == 2)
+                act, bits, y = L.ACT_NONE, None, None
         else:
             sums, zeroed = _zero_sums(2 * Cc, dev)
             L.check(lib.dynmm_bn_bwd_reduce(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
                                             N, Cc, HW, ctx.act, zeroed, _p(bits), st), 'bn_bwd_reduce')
         if bl is not None:
-            bl.x = None
+            bl.x = bl.bits = None
         dx = torch.empty_like(x)
         need_res = ctx.has_res and ctx.needs_input_grad[5]
-        dres = torch.empty_like(x) if (need_res and ctx.act != L.ACT_NONE) else None
+        dres = torch.empty_like(x) if (need_res and act != L.ACT_NONE) else None
         dgamma, dgamma_ret = _grad_dst(ctx.g_param)
         dbeta, dbeta_ret = _grad_dst(ctx.b_param)
         L.check(lib.dynmm_bn_bwd_apply(_p(gy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
                                        _p(dx), _p(dres), _p(dgamma), _p(dbeta), N, Cc, HW,
-                                       int(ctx.training), ctx.act, _p(bits), st), 'bn_bwd_apply')
+                                       (sums.numel() // (2 * Cc)) if ctx.training else 0, act, _p(bits), st), 'bn_bwd_apply')
         if need_res and dres is None:
             dres = gy            # no activation: the residual branch receives the gradient unchanged
         if ctx.link is not None and dres is not None:

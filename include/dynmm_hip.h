@@ -102,16 +102,16 @@ int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask
                        float* dx, float* dx2, const dynmm_conv_geom* g, void* stream);
 
 /* ---- three-tap convolutions by 1-D Winograd F(2,3) on the fp32 matrix cores (csrc/conv_wino.hip) ----
- * Stride-1, same-padded 1x3 / 3x1 / 3x3 convolutions with W % 4 == 0 whose GEMM has rows % 64 == 0 and a reduction of a multiple
- * of 8 (>= 24) channels — (rows, reduction) = (Co, Ci) forward, (Ci, Co) input gradient — (the factorised convolutions
- * of resnet.py:124-147 and the decoder's 3x3 convolutions, model.py:343-357): four channel contractions per output PAIR
+ * Stride-1, same-padded 1x3 / 3x1 convolutions with W % 4 == 0 whose GEMM has rows % 64 == 0 (forward: % 8, >= 24) and a
+ * reduction of a multiple of 8 (>= 24) channels — (rows, reduction) = (Co, Ci) forward, (Ci, Co) input gradient — (the factorised
+ * convolutions of resnet.py:124-147; 3x3 filters: the 2-D form below): four channel contractions per output PAIR
  * along the tap axis instead of six, i.e. 2/3 of the direct convolution's matrix work, in fp32 (error vs fp64 of the same
  * class as a direct fp32 sum: 2e-7 .. 4e-7 rms).  dynmm_conv2d_wino_supported(g, dgrad) = 1 when that pass qualifies;
  * = 2 (dgrad only) for the STRIDE-2 three-tap convolutions — 3x1 stride (2,1) / 1x3 stride (1,2), resnet.py:104-107 in the first block
  * of stages 2-4 — whose input gradient runs on the same pair kernel in polyphase form (dx[2j] = W1^T dy[j], dx[2j+1] = W2^T dy[j] +
  * W0^T dy[j+1]: the direct operation count, 8-byte stores); their operand is dynmm_wino_pack(..., dgrad = 2) = (W1, W2, W0, 0).
- * Operand: the filter transforms ut[KR][K][C][4] (KR = 3 for 3x3, else 1; (K, C) = (Ci, Co) forward, (Co, Ci) input
- * gradient), dynmm_wino_packed_floats floats, 16-byte aligned, written by dynmm_wino_pack or — many filters in ONE launch —
+ * Operand: the filter transforms ut[K][C rounded up to 64][4] ((K, C) = (Ci, Co) forward, (Co, Ci) input gradient),
+ * dynmm_wino_packed_floats floats (0 for any other filter shape), 16-byte aligned, written by dynmm_wino_pack or — many filters in ONE launch —
  * by dynmm_wino_pack_multi: desc (device memory) = ndesc records of 4 int64 words { src, dst : float offsets from
  * src_base / dst_base (dst % 4 == 0) ; Co | Ci << 32 ; KH | KW << 8 | dgrad (0, 1, 2) << 16 | first_workgroup << 32 }, first
  * workgroups being the running sum of dynmm_wino_pack_multi_blocks.
@@ -130,14 +130,25 @@ int dynmm_conv2d_wino_fwd(const float* x, const float* ut, const float* bias, co
                           const dynmm_conv_geom* g, int act, void* stream);
 /* The input gradient of a 3x1 convolution whose input is z = relu(BN(c)) (resnet.py:131-135 conv3x1_2 after bn1 + ReLU), together
  * with that BatchNorm's backward reductions: dx = the convolution's input gradient masked by [BN(c) > 0] (re-derived from c = bn_x
- * with bn_apply's own fma), and sums[0][ch] += sum dx, sums[1][ch] += sum dx * xhat over (N, H, W) — the `sums` operand of
- * dynmm_bn_bwd_apply (fp64 [2][Ci], zeroed by the caller) without a dynmm_bn_bwd_reduce launch. */
+ * with bn_apply's own fma), and sums[s][0][ch] += sum dx, sums[s][1][ch] += sum dx * xhat over (N, H, W) — the `sums` operand of
+ * dynmm_bn_bwd_apply (fp64 [slots][2][Ci], zeroed by the caller; pixel tile p adds into slab p % slots, slots =
+ * dynmm_conv2d_wino_dgrad_bnred_slots(g) = dynmm_bn_bwd_apply's `training`) without a dynmm_bn_bwd_reduce launch. */
 int dynmm_conv2d_wino_dgrad_bnred_supported(const dynmm_conv_geom* g);
+int dynmm_conv2d_wino_dgrad_bnred_slots(const dynmm_conv_geom* g);
 int dynmm_conv2d_wino_dgrad_bnred(const float* dy, const float* ut, const float* bn_x, const float* bn_mean,
                                   const float* bn_invstd, const float* bn_gamma, const float* bn_beta, double* sums, float* dx,
                                   const dynmm_conv_geom* g, void* stream);
+/* The same for a BatchNorm + identity + ReLU (resnet.py:136-147: out = relu(bn2(c) + identity)) whose output feeds the next block and
+ * nothing else: this launch is that block's first 3x1 convolution, `accum` the gradient of its identity branch (or NULL), so the
+ * epilogue holds the complete gradient of `out`.  dx = (conv_transpose(dy, w) + accum) * [out > 0] with the decisions read from
+ * relu_bits (the record dynmm_bn_apply left: dynmm_bn_relu_bits_words), sums as above with xhat = (bn_x - mean) * invstd.  The
+ * BatchNorm's backward continues with dynmm_bn_bwd_apply(act = NONE) on dx, which is also the identity branch's gradient.
+ * Geometry: dynmm_conv2d_wino_dgrad_bnred_supported and H * W % 4 == 0. */
+int dynmm_conv2d_wino_dgrad_bnred2(const float* dy, const float* ut, const float* accum, const float* bn_x,
+                                   const unsigned long long* relu_bits, const float* bn_mean, const float* bn_invstd,
+                                   double* sums, float* dx, const dynmm_conv_geom* g, void* stream);
 /* The forward of a convolution that feeds a training-mode BatchNorm (resnet.py:110,118 `bn1` / `bn2` after conv1x3_*;
- * model_utils.py:11-23 ConvBNAct), horizontal taps (1x3, 3x3), Co % 64 == 0, no activation: y as dynmm_conv2d_wino_fwd, and the
+ * model_utils.py:11-23 ConvBNAct), 1x3 taps (3x3: dynmm_conv2d_wino2d_fwd's stats), Co % 64 == 0, no activation: y as dynmm_conv2d_wino_fwd, and the
  * per-channel sums of y and y^2 over (N, H, W) ADDED to stats [nslots][2][Co] (fp64, zeroed by the caller; pixel tile p adds into
  * slab p % nslots, nslots = dynmm_conv2d_wino_fwd_stats_slots(g): thousands of tiles on one address serialise) from the kernel's
  * epilogue — the `sums` operand of dynmm_bn_apply (training = nslots) without a dynmm_bn_stats launch. */
@@ -174,8 +185,8 @@ int dynmm_conv2d_wino2d_dgrad(const float* dy, const float* ut, const float* mas
 /* ---- input gradients by 1-D Winograd F(4,3) (csrc/conv_wino43.hip): four neighbouring outputs of a three-tap filter from six
  * multiplications — HALF of the direct convolution's matrix work (F(2,3) above: 2/3).  The transforms carry factors up to 8 and
  * 1/24: 1.7e-6 .. 2.8e-6 from fp64 in max-norm (direct fp32: 2e-7 .. 3e-7), which is why only the BACKWARD uses it.
- * Same convolutions as above with Ci % 64 == 0, Co % 8 == 0 >= 24, N*H*W >= 256 (dynmm_conv2d_wino43_supported); every tensor
- * 16-byte aligned.  Operand ut (dynmm_wino43_packed_floats floats): U0..U3 [KR][Co][Ci][4] followed by U4, U5 [KR][Co][Ci][2],
+ * The stride-1 1x3 convolutions with Ci % 64 == 0, Co % 8 == 0 >= 24, N*H*W >= 256 (dynmm_conv2d_wino43_supported); every tensor
+ * 16-byte aligned.  Operand ut (dynmm_wino43_packed_floats floats): U0..U3 [Co][Ci][4] followed by U4, U5 [Co][Ci][2],
  * written by dynmm_wino43_pack or, for many filters in ONE launch, dynmm_wino43_pack_multi (descriptor as dynmm_wino_pack_multi's,
  * without the dgrad bit).
  *   dx = conv_transpose(dy, w) * [mask > 0] + accum */
@@ -254,7 +265,9 @@ int dynmm_bn_bwd_reduce(const float* g, const float* y, const float* x,
                         double* sums, int N, int C, int HW, int act, int sums_are_zero,
                         const unsigned long long* relu_bits, void* stream);
 /* dx = gamma*invstd*(g_eff - sum_g/M - xhat*sum_gx/M) (training) or gamma*invstd*g_eff (eval);
- * d_residual = g_eff (optional); dgamma/dbeta from sums. */
+ * d_residual = g_eff (optional); dgamma/dbeta from sums.  training = 0 (eval) or the number n >= 1 of slabs the sums arrive in,
+ * sums[n][2][C] (1 from dynmm_bn_bwd_reduce; dynmm_conv2d_wino_dgrad_bnred_slots from a convolution's epilogue) — the same
+ * convention as dynmm_bn_apply's. */
 int dynmm_bn_bwd_apply(const float* g, const float* y, const float* x,
                        const float* mean, const float* invstd, const float* gamma, const float* beta,
                        const double* sums, float* dx, float* d_residual,

@@ -60,23 +60,23 @@ def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr, steps_
                 'conv_wgrad_v6<co64,1x3>': ('conv_wgrad_v6_kernel<1, 3, 3, false>', 2),
                 'conv_wgrad_v6<co64,3x3>': ('conv_wgrad_v6_kernel<1, 3, 3, true>', 2),
                 'conv_wgrad_v6<co64,3x1>': ('conv_wgrad_wino_vt_kernel<1>', 2),
-                # Winograd kernels (conv_wino.hip / conv_wino43.hip; 16 B/lane direct-to-LDS streams).  keys = bench.py's
-                # kernel_instance(); template arguments <TCO, MCO, VERT, DGRAD, S2, TAIL, STATS, BNRED, KR3>: a label that several
-                # compiled instances serve (the training forward before a BatchNorm runs the STATS instance, the input gradient
-                # behind relu(BN(.)) the BNRED one) lists them all — the record is their launch-weighted mean
-                'conv_wino_fwd<horizontal>': (['conv_wino_kernel<64, 1, false, false, false, false, false, false, false>',
-                                               'conv_wino_kernel<64, 1, false, false, false, false, true, false, false>'], 2),
-                'conv_wino_fwd<horizontal,3x3>': (['conv_wino_kernel<64, 1, false, false, false, false, false, false, true>',
-                                                   'conv_wino_kernel<64, 1, false, false, false, false, true, false, true>',
-                                                   'conv_wino_kernel<64, 1, false, false, false, true, false, false, true>'], 2),
-                'conv_wino_fwd<vertical>': (['conv_wino_kernel<64, 1, true, false, false, false, false, false, false>'], 2),
-                'conv_wino_dgrad<horizontal>': (['conv_wino_kernel<64, 1, false, true, false, false, false, false, false>'], 2),
-                'conv_wino_dgrad<vertical>': (['conv_wino_kernel<64, 1, true, true, false, false, false, false, false>',
-                                               'conv_wino_kernel<64, 1, true, true, false, false, false, true, false>'], 2),
-                'conv_wino_dgrad<horizontal,s2>': (['conv_wino_kernel<64, 1, false, true, true, false, false, false, false>'], 2),
-                'conv_wino_dgrad<vertical,s2>': (['conv_wino_kernel<64, 1, true, true, true, false, false, false, false>'], 2),
-                'conv_wino43_dgrad<horizontal>': (['conv_wino43_kernel<false>'], 2),
-                'conv_wino43_dgrad<horizontal,3x3>': (['conv_wino43_kernel<true>'], 2),
+                # Winograd kernels (conv_wino.hip / conv_wino43.hip / conv_wino2d.hip; 16 B/lane direct-to-LDS streams).  keys =
+                # bench.py's kernel_instance(); conv_wino_kernel's template arguments are <TCO, MCO, VERT, DGRAD, S2, TAIL, STATS,
+                # BNRED>, conv_wino2d_kernel's <DGRAD, TAIL, STATS>: a label that several compiled instances serve (the training
+                # forward before a BatchNorm runs the STATS instance, the input gradient behind relu(BN(.)) the BNRED one, the
+                # 40-class conv_out the TAIL one) lists them all — the record is their launch-weighted mean
+                'conv_wino_fwd<horizontal>': (['conv_wino_kernel<64, 1, false, false, false, false, false, false>',
+                                               'conv_wino_kernel<64, 1, false, false, false, false, true, false>'], 2),
+                'conv_wino_fwd<vertical>': (['conv_wino_kernel<64, 1, true, false, false, false, false, false>'], 2),
+                'conv_wino_dgrad<horizontal>': (['conv_wino_kernel<64, 1, false, true, false, false, false, false>'], 2),
+                'conv_wino_dgrad<vertical>': (['conv_wino_kernel<64, 1, true, true, false, false, false, false>',
+                                               'conv_wino_kernel<64, 1, true, true, false, false, false, true>'], 2),
+                'conv_wino_dgrad<horizontal,s2>': (['conv_wino_kernel<64, 1, false, true, true, false, false, false>'], 2),
+                'conv_wino_dgrad<vertical,s2>': (['conv_wino_kernel<64, 1, true, true, true, false, false, false>'], 2),
+                'conv_wino43_dgrad<horizontal>': (['conv_wino43_kernel('], 2),
+                'conv_wino2d_fwd<3x3>': (['conv_wino2d_kernel<false, false, false>', 'conv_wino2d_kernel<false, true, false>',
+                                          'conv_wino2d_kernel<false, false, true>'], 2),
+                'conv_wino2d_dgrad<3x3>': (['conv_wino2d_kernel<true, false, false>'], 2),
                 # the operand-ring kernels stream 16 B/lane (global_load_lds_dwordx4): the guide's x2 correction applies
                 'conv_igemm_v5_fwd<128x64,kw3>': ('conv_igemm_v5_kernel<128, 64, 64, 32, 3, false', 2),
                 'conv_igemm_v5_fwd<128x64,kw1>': ('conv_igemm_v5_kernel<128, 64, 64, 32, 1, false', 2),

@@ -566,8 +566,9 @@ WINO_CASES = [
 @pytest.mark.parametrize('mode', ['dgrad', 'all', 'dgrad43'])
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_conv2d_winograd(ops, mode, case):
-    """csrc/conv_wino.hip (1-D Winograd F(2,3), fp32 MFMA) through ops.conv2d: the forward (mode 'all') and the input gradient
-    with both epilogue operands (ReLU mask of the producer, residual-branch gradient) against a float64 PyTorch reference at
+    """csrc/conv_wino.hip (1-D Winograd F(2,3), fp32 MFMA; 1x3 / 3x1), conv_wino43.hip (F(4,3), 1x3 input gradients) and
+    conv_wino2d.hip (2-D F(2x2,3x3); 3x3) through ops.conv2d: the forward (mode 'all') and the input gradient with both epilogue
+    operands (ReLU mask of the producer, residual-branch gradient) against a float64 PyTorch reference at
     the SAME bars as the direct kernels (TOL / GTOL), weight and bias gradients unchanged; and the kernel really ran."""
     import ctypes as C
     N, Ci, H, W, Co, k = case
@@ -581,9 +582,9 @@ def test_conv2d_winograd(ops, mode, case):
     y_ref.backward(gy.double())
     dx_ref = xr.grad * (x > 0) + dres.double()
     old, old_d = ops.WINO, ops.WINO_DGRAD
-    # 'dgrad43' = the product default WINO_DGRAD = '43h': the input gradient of the horizontal-tap filters (1x3, 3x3) by F(4,3)
-    # (csrc/conv_wino43.hip: half of the direct matrix work, 1e-6 .. 4e-6 from fp64 — held to the same GTOL), the vertical ones by
-    # F(2,3); the other two modes pin F(2,3) everywhere
+    # 'dgrad43' = the product default WINO_DGRAD = '43h': the input gradient of the 1x3 filters by F(4,3) (csrc/conv_wino43.hip:
+    # half of the direct matrix work, 1e-6 .. 4e-6 from fp64 — held to the same GTOL), the 3x1 ones by F(2,3); the other two modes
+    # pin F(2,3) for both; 3x3 filters take the 2-D kernel in every mode
     f43 = mode == 'dgrad43'
     ops.WINO, ops.WINO_DGRAD = ('dgrad' if f43 else mode), ('43h' if f43 else '23')
     mode = 'dgrad' if f43 else mode
@@ -592,9 +593,11 @@ def test_conv2d_winograd(ops, mode, case):
     try:
         xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
         g = ops._geom(xg, None, wg, (1, 1), p)
-        assert lib.dynmm_conv2d_wino_supported(C.byref(g), 1) == 1
-        assert ops._wino(g, True) and ops._wino(g, False) == (mode == 'all')
-        assert bool(lib.dynmm_conv2d_wino2d_supported(C.byref(g), 1)) == (k == (3, 3))
+        k33 = k == (3, 3)
+        assert lib.dynmm_conv2d_wino_supported(C.byref(g), 1) == (0 if k33 else 1)       # each filter shape has ONE Winograd home
+        assert bool(lib.dynmm_conv2d_wino2d_supported(C.byref(g), 1)) == k33
+        for sel in (ops._wino2d, ops._wino):
+            assert sel(g, True) == (k33 == (sel is ops._wino2d)) and sel(g, False) == (sel(g, True) and mode == 'all')
         link = ops.GradLink()
         ops.PROFILE = calls
         y = ops.conv2d(xg, wg, bg, 1, p, None, mask_input=True, link=link)
@@ -689,15 +692,16 @@ class _CallSpy:
 @pytest.mark.parametrize('case,fits', [((3, 128, 15, 20, 128), True),        # odd H: the last row pair has one live row
                                        ((2, 64, 24, 32, 128), True),
                                        ((7, 64, 6, 12, 64), True),           # 252 pairs: a ragged last pixel tile
-                                       ((8, 64, 120, 160, 64), True),        # 1200 pixel tiles: the C = 64 stage at batch 8
-                                       ((17, 64, 120, 160, 64), False)])     # 2550 tiles > 2400: the rule sends it down the unfused path
+                                       ((8, 64, 120, 160, 64), True),        # 1200 pixel tiles: the C = 64 stage at batch 8, 2 slabs
+                                       ((17, 64, 120, 160, 64), True),       # 2550 tiles: 4 slabs (<= 600 tiles add to one address)
+                                       ((3, 96, 15, 20, 128), False)])       # 96 rows: not a multiple of the 64-row tile -> unfused path
 def test_batchnorm_backward_reductions_from_the_consumer_dgrad(ops, case, fits):
     """relu(BN(c)) -> conv3x1 (resnet.py:127-135: bn1 -> conv3x1_2): with ops.BNLink the convolution's input-gradient launch
     (dynmm_conv2d_wino_dgrad_bnred, csrc/conv_wino.hip BNRED) masks by [BN(c) > 0] from c itself and leaves the BatchNorm
     backward's two reductions — fp64 atomics, one per channel, statistic and tile — so bn_bwd_reduce is not launched.  Checked
     through the C ABI against float64 autograd: every gradient to GTOL, the two reductions (= dbeta, dgamma) to 1e-6 of their
-    absolute sums, fused == unfused; a spy asserts which path ran (the link consumed on the fused one), on both sides of the
-    2400-tile rule."""
+    absolute sums, fused == unfused; a spy asserts which path ran (the link consumed on the fused one), with one and with several
+    slabs of sums (dynmm_conv2d_wino_dgrad_bnred_slots), and for a geometry the kernel does not take."""
     import torch.nn as nn
     N, Ci, H, W, Co = case
     torch.manual_seed(N * 1000 + Ci + Co)
@@ -792,7 +796,8 @@ def test_conv2d_stride2_input_gradient_on_the_pair_kernel(ops, case):
 
 def test_winograd_operands_from_the_step_pack(ops):
     """ops.PackedWeights: the filter transforms written by the ONE dynmm_wino_pack_multi launch of a step equal the per-conv
-    packs bit for bit, for both directions and all three filter shapes; geometries outside the kernel's rules are refused."""
+    packs bit for bit, for both directions and all three filter shapes (1x3: F(2,3) + F(4,3); 3x1: F(2,3); 3x3: 2-D); geometries
+    outside the kernels' rules are refused."""
     import ctypes as C
     from dynmm_amd import lib as L
     lib = ops._lib()
@@ -802,24 +807,32 @@ def test_winograd_operands_from_the_step_pack(ops):
     for w in ws:
         Co, Ci, KH, KW = w.shape
         g = L.ConvGeom(2, Ci, 16, 16, Co, 16, 16, KH, KW, 1, 1, KH // 2, KW // 2, Ci)
-        pw.register(w, g, True, False, True, True, True, KH * KW == 9, KH * KW == 9)
+        k33 = KH * KW == 9
+        pw.register(w, g, True, False, not k33, not k33, KW == 3 and not k33, k33, k33)
     pw.pack()
     torch.cuda.synchronize()
     for w in ws:
         Co, Ci, KH, KW = w.shape
         k33 = KH * KW == 9
-        wp, wpd, utf, utd, utd43, ut2f, ut2d = pw.lookup(w, True, False, True, True, True, k33, k33)
+        h13 = KW == 3 and not k33
+        wp, wpd, utf, utd, utd43, ut2f, ut2d = pw.lookup(w, True, False, not k33, not k33, h13, k33, k33)
         assert wpd is None and pw.lookup(w, True, True) is None          # the direct input-gradient layout was not requested
-        assert (ut2f is not None) == k33 and (k33 or pw.lookup(w, True, False, True, True, True, True) is None)
+        assert (ut2f is not None) == k33 and (k33 or pw.lookup(w, True, False, True, True, h13, True) is None)
+        assert (utf is None) == k33 and (not k33 or pw.lookup(w, True, False, True) is None)
+        assert lib.dynmm_wino_packed_floats(Co, Ci, KH, KW) == (0 if k33 else 4 * max(Ci * ((Co + 63) // 64 * 64), Co * ((Ci + 63) // 64 * 64)))
+        assert lib.dynmm_wino43_packed_floats(Co, Ci, KH, KW) == (6 * Co * Ci if h13 else 0)
         for dgrad, got in ((0, ut2f), (1, ut2d)) if k33 else ():         # the 2-D F(2x2,3x3) operands (csrc/conv_wino2d.hip)
             ref = torch.zeros(lib.dynmm_wino2d_packed_floats(Co, Ci), device='cuda')
             L.check(lib.dynmm_wino2d_pack(w.data_ptr(), ref.data_ptr(), None, Co, Ci, dgrad, st), 'wino2d_pack')
             n_live = (Co if dgrad else Ci) * 4 * (((Ci if dgrad else Co) + 63) // 64 * 64) * 4
             assert torch.equal(got[:n_live], ref[:n_live]), (tuple(w.shape), dgrad)
-        ref43 = torch.empty(lib.dynmm_wino43_packed_floats(Co, Ci, KH, KW), device='cuda')
-        L.check(lib.dynmm_wino43_pack(w.data_ptr(), ref43.data_ptr(), Co, Ci, KH, KW, st), 'wino43_pack')
-        assert torch.equal(utd43, ref43), tuple(w.shape)
-        for dgrad, got in ((0, utf), (1, utd)):
+        if h13:
+            ref43 = torch.empty(lib.dynmm_wino43_packed_floats(Co, Ci, KH, KW), device='cuda')
+            L.check(lib.dynmm_wino43_pack(w.data_ptr(), ref43.data_ptr(), Co, Ci, KH, KW, st), 'wino43_pack')
+            assert torch.equal(utd43, ref43), tuple(w.shape)
+        else:
+            assert utd43 is None
+        for dgrad, got in ((0, utf), (1, utd)) if not k33 else ():
             ref = torch.empty(lib.dynmm_wino_packed_floats(Co, Ci, KH, KW), device='cuda')
             L.check(lib.dynmm_wino_pack(w.data_ptr(), ref.data_ptr(), None, Co, Ci, KH, KW, dgrad, st), 'wino_pack')
             assert torch.equal(got, ref), (tuple(w.shape), dgrad)
@@ -1075,3 +1088,101 @@ def test_grouped_weight_gradients(ops, case):
         assert torch.equal(x, y)
     s_w, _ = run(1)                                   # a "group" of one = the ordinary launch
     assert rel(s_w[0], ref_w[0]) < GTOL
+
+
+@pytest.mark.parametrize('case', [(3, 128, 15, 20), (2, 64, 24, 32), (7, 64, 6, 12), (2, 256, 30, 40), (8, 64, 120, 160)])
+def test_bn2_backward_reductions_kernel_vs_float64(ops, case):
+    """dynmm_conv2d_wino_dgrad_bnred2 through the C ABI (csrc/conv_wino.hip BNRED == 2): dx = (conv_transpose(dy, w) + accum) . [out > 0]
+    with the decisions read from the one-bit record dynmm_bn_apply wrote, and the BatchNorm backward's two reductions over dx —
+    against float64 with the SAME decisions (they are an input here): dx to GTOL, the reductions to 1e-6 of their absolute sums;
+    a NULL accum is a zero one; the last case spreads its 1200 pixel tiles over two slabs of sums."""
+    import ctypes as C
+    from dynmm_amd import lib as L
+    lib = ops._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    N, Cc, H, W = case
+    HW = H * W
+    c, idt = rnd(N, Cc, H, W, seed=1), rnd(N, Cc, H, W, seed=2)
+    w = rnd(Cc, Cc, 3, 1, seed=3, scale=(3 * Cc) ** -0.5)
+    dy, acc = rnd(N, Cc, H, W, seed=4), rnd(N, Cc, H, W, seed=5)
+    bn = torch.nn.BatchNorm2d(Cc, eps=1e-3).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    # the forward's own record: out = relu(BN(c) + idt) by dynmm_bn_apply with the bits requested
+    cg = c.cuda().requires_grad_(True)
+    out = ops.batch_norm_act(cg, bn, 'relu', residual=idt.cuda().requires_grad_(True))
+    x_, y_, gamma, mean, invstd, beta, bits = out.grad_fn.saved_tensors
+    assert bits is not None
+    m = (out.detach() > 0).double().cpu()
+    g = L.ConvGeom(N, Cc, H, W, Cc, H, W, 3, 1, 1, 1, 1, 0, Cc)
+    assert lib.dynmm_conv2d_wino_dgrad_bnred_supported(C.byref(g)) == 1
+    ut = torch.empty(lib.dynmm_wino_packed_floats(Cc, Cc, 3, 1), device='cuda')
+    w_g = w.cuda()
+    L.check(lib.dynmm_wino_pack(w_g.data_ptr(), ut.data_ptr(), None, Cc, Cc, 3, 1, 1, st), 'wino_pack')
+    convT = torch.nn.grad.conv2d_input((N, Cc, H, W), w.double(), dy.double(), 1, (1, 0))
+    xhat = (c.double() - mean.double().cpu().view(1, -1, 1, 1)) * invstd.double().cpu().view(1, -1, 1, 1)
+    dy_g, acc_g = dy.cuda(), acc.cuda()
+    for accum in (acc, None):
+        ref = (convT + (accum.double() if accum is not None else 0.0)) * m
+        ns = lib.dynmm_conv2d_wino_dgrad_bnred_slots(C.byref(g))
+        assert ns == (2 if N * ((H + 1) // 2) * W >= 2 * 600 * 64 else 1)
+        slabs = torch.zeros(ns, 2, Cc, device='cuda', dtype=torch.float64)
+        dx = torch.full((N, Cc, H, W), float('nan'), device='cuda')
+        L.check(lib.dynmm_conv2d_wino_dgrad_bnred2(dy_g.data_ptr(), ut.data_ptr(), acc_g.data_ptr() if accum is not None else None,
+                                                   cg.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr(), slabs.data_ptr(),
+                                                   dx.data_ptr(), C.byref(g), st), 'bnred2')
+        torch.cuda.synchronize()
+        sums = slabs.sum(0)
+        assert ns == 1 or bool((slabs[1] != 0).any())
+        assert rel(dx, ref) < GTOL
+        assert ((sums[0].cpu() - ref.sum((0, 2, 3))).abs() / ref.abs().sum((0, 2, 3))).max() < 1e-6
+        assert ((sums[1].cpu() - (ref * xhat).sum((0, 2, 3))).abs() / (ref * xhat).abs().sum((0, 2, 3))).max() < 1e-6
+
+
+@pytest.mark.parametrize('case,fits', [((3, 128, 15, 20), True), ((2, 64, 24, 32), True), ((2, 64, 24, 33), False)])
+def test_bn2_backward_reductions_from_the_next_block(ops, case, fits):
+    """Two chained NonBottleneck1D blocks (resnet.py:87-147) as the encoder stages run them (chain=True): the input-gradient launch of
+    block 1's first convolution masks the complete gradient of block 0's output with the forward's decisions and leaves bn2's two
+    reductions (ops.BNLink second form) — bn_bwd_reduce is not launched for it, and its apply pass runs without bits and writes no
+    second masked copy.  Same gradients as the unfused path (same forward, same decisions) to 1e-5; a spy asserts which path ran;
+    a width off the kernel's rules takes the unfused path."""
+    from dynmm_amd.nn.blocks import NonBottleneck1D
+    N, Cc, H, W = case
+    torch.manual_seed(N * 100 + Cc)
+    b0, b1 = NonBottleneck1D(Cc, Cc).cuda().train(), NonBottleneck1D(Cc, Cc).cuda().train()
+    x = rnd(N, Cc, H, W, seed=1).relu_().cuda()
+    gy = rnd(N, Cc, H, W, seed=2).cuda()
+    lib = ops._lib()
+    old = ops.BN_BWD_FUSE
+    named = [(f'b{j}.{n}', q) for j, m in enumerate((b0, b1)) for n, q in m.named_parameters()]
+    params = [q for _, q in named]
+
+    def run(fuse):
+        ops.BN_BWD_FUSE = fuse
+        for m in (b0, b1):
+            m.bn1.reset_running_stats()
+            m.bn2.reset_running_stats()
+        for q in params:
+            q.grad = None
+        xi = x.clone().requires_grad_(True)
+        with _CallSpy(lib, 'dynmm_conv2d_wino_dgrad_bnred2', 'dynmm_conv2d_wino_dgrad_bnred', 'dynmm_bn_bwd_reduce') as spy:
+            y = b1(b0(xi), chain=True)
+            y.backward(gy)
+            torch.cuda.synchronize()
+        return [xi.grad.clone()] + [q.grad.clone() for q in params], y.detach().clone(), dict(spy.count)
+    try:
+        (ga, ya, ca), (gb, yb, cb) = run(False), run(True)
+    finally:
+        ops.BN_BWD_FUSE = old
+    assert torch.equal(ya, yb)
+    assert ca == {'dynmm_conv2d_wino_dgrad_bnred2': 0, 'dynmm_conv2d_wino_dgrad_bnred': 0, 'dynmm_bn_bwd_reduce': 4}, ca
+    if fits:       # bn1 of both blocks through BNRED, bn2 of block 0 through BNRED == 2, bn2 of block 1 (nobody downstream) on its own
+        assert cb == {'dynmm_conv2d_wino_dgrad_bnred2': 1, 'dynmm_conv2d_wino_dgrad_bnred': 2, 'dynmm_bn_bwd_reduce': 1}, cb
+    else:
+        assert cb['dynmm_conv2d_wino_dgrad_bnred2'] == 0 and cb['dynmm_bn_bwd_reduce'] >= 2, cb
+    for name, a, b in zip(['x'] + [n for n, _ in named], ga, gb):
+        if name.endswith(('conv1x3_1.bias', 'conv1x3_2.bias')):      # a bias in front of a training-mode BatchNorm: analytically zero,
+            assert a.abs().max() < 1e-3 and b.abs().max() < 1e-3     # what is left is rounding noise on either path
+            continue
+        assert rel(b, a) < 1e-5, name
