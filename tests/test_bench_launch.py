@@ -82,4 +82,4 @@ def test_roofline_kernel_names_match_the_pmc_summary():
     assert bench.executed_fraction('conv_wino_dgrad<co128,1x3s2>') == 1.0 and bench.executed_fraction('conv_igemm_fwd<128x64>') == 1.0
     # the committed record carries the kernel the last bench line named
     rec = json.load(open(os.path.join(root, 'profiles', 'pmc_dominant_kernel.json')))
-    assert 'conv_wino43_dgrad<horizontal>' in rec and rec['conv_wino43_dgrad<horizontal>']['launches_per_step'] == 80
+    assert 'conv_wino43_dgrad<horizontal>' in rec and rec['conv_wino43_dgrad<horizontal>']['launches_per_step'] == 76
