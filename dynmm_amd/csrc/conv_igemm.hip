@@ -1409,6 +1409,26 @@ extern "C" int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp
     return launch_igemm<false>(a, (hipStream_t)stream);
 }
 
+// The 7x7 / stride-2 stem convolution (resnet.py:216-217) with the batch statistics of the BatchNorm that follows it
+// (resnet.py:229) from the kernel's own epilogue: conv_small.hip, conv_stem_fwd_kernel<CI, STATS>.
+extern "C" int dynmm_conv2d_stem_fwd_stats_supported(const dynmm_conv_geom* g) {
+    if (!geom_ok(g) || g->c_split < g->Ci) return 0;
+    SmallConvArgs s{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g->N, g->Ci, g->H, g->W, g->Co, g->Ho, g->Wo, g->KH, g->KW,
+                    g->SH, g->SW, g->PH, g->PW, g->c_split, round_k(g->Ci), (g->Co + 3) & ~3, DYNMM_ACT_NONE};
+    return stem_conv_fwd_eligible(s, nullptr) ? 1 : 0;
+}
+
+extern "C" int dynmm_conv2d_stem_fwd_stats(const float* x, const float* wp_fwd, const float* bias, float* y, double* stats,
+                                           const dynmm_conv_geom* g, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !wp_fwd || !y || !stats || !geom_ok(g)) return DYNMM_EINVAL;
+    if (!dynmm_conv2d_stem_fwd_stats_supported(g)) return DYNMM_EUNSUPPORTED;
+    SmallConvArgs s{x, nullptr, wp_fwd, nullptr, bias, y, g->N, g->Ci, g->H, g->W, g->Co, g->Ho, g->Wo, g->KH, g->KW,
+                    g->SH, g->SW, g->PH, g->PW, g->c_split, round_k(g->Ci), (g->Co + 3) & ~3, DYNMM_ACT_NONE};
+    s.stats = stats;
+    return launch_stem_conv_fwd(s, (hipStream_t)stream);
+}
+
 extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const float* mask,
                                   const float* accum, float* dx, float* dx2,
                                   const dynmm_conv_geom* g, void* stream) {

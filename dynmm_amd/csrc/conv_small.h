@@ -12,6 +12,7 @@ struct SmallConvArgs {
     const float* shift;
     float* y;
     int N, Ci, H, W, Co, Ho, Wo, KH, KW, SH, SW, PH, PW, c_split, CiR, CoP, act;
+    double* stats = nullptr;   // stem forward only: [2][Co] per-channel sums of y and y^2 ADDED here (BatchNorm batch statistics)
 };
 
 struct StemWgradArgs {

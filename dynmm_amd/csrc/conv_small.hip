@@ -363,7 +363,11 @@ int launch_co8_wgrad(const float* x, const float* x2, const float* dy, float* dw
 // lane) lives in registers for the lifetime of the persistent workgroup.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CI>
+// STATS (round 5): the stem convolution feeds a training-mode BatchNorm (resnet.py:229-231): a lane keeps running sums of y and
+// y^2 of the values it stores (8 channels: fp32 over its ~20 tiles x 2 rows x 4 columns), summed over the 16 lanes that share a
+// channel at the end of the persistent loop and added to a.stats with one fp64 atomic per wave, channel and statistic — what
+// bn_stats_kernel would produce with a launch and a 629 MB pass of its own.
+template <int CI, bool STATS = false>
 __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(const SmallConvArgs a) {
     constexpr int KS = 7, S = 2, PAD = 3, KW8 = 8;
     constexpr int TRW = 4, TCW = 64;                   // output tile
@@ -423,6 +427,12 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
                 dst[e] = 0.f;
         }
     };
+
+    float st1[2][4], st2[2][4];                     // STATS: [q][ps] sums of channel mi*32 + 16q + 4ps + (lane >> 4)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) st1[q][ps] = st2[q][ps] = 0.f;
 
     int buf = 0;
     if ((int)blockIdx.x < tiles) fetch_patch(blockIdx.x, patch2[0]);
@@ -490,12 +500,23 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
                         const int c = mi * 32 + 16 * q + cl;
                         const float4 v = *reinterpret_cast<const float4*>(ostage + cl * OP + col);
                         float* yr = a.y + (((size_t)n * a.Co + c) * a.Ho + oh) * a.Wo + ow0 + col;
-                        if (vec_out && ow0 + col + 3 < a.Wo) *reinterpret_cast<float4*>(yr) = v;
-                        else {
-                            if (ow0 + col < a.Wo) yr[0] = v.x;
-                            if (ow0 + col + 1 < a.Wo) yr[1] = v.y;
-                            if (ow0 + col + 2 < a.Wo) yr[2] = v.z;
-                            if (ow0 + col + 3 < a.Wo) yr[3] = v.w;
+                        if (vec_out && ow0 + col + 3 < a.Wo) {
+                            *reinterpret_cast<float4*>(yr) = v;
+                            if constexpr (STATS) {
+                                st1[q][ps] += (v.x + v.y) + (v.z + v.w);
+                                st2[q][ps] += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+                            }
+                        } else {
+                            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (ow0 + col + k < a.Wo) {
+                                    yr[k] = e[k];
+                                    if constexpr (STATS) {
+                                        st1[q][ps] += e[k];
+                                        st2[q][ps] = fmaf(e[k], e[k], st2[q][ps]);
+                                    }
+                                }
                         }
                     }
                 }
@@ -504,6 +525,24 @@ __global__ void __launch_bounds__(256, CI == 1 ? 3 : 2) conv_stem_fwd_kernel(con
             }
         __builtin_amdgcn_s_waitcnt(0);                                  // the next patch has landed (this wave's part)
         __syncthreads();                                                // ... everyone's; this patch / output staging is free
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                float s1 = st1[q][ps], s2 = st2[q][ps];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {                      // the 16 lanes of a row share the channel
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if ((lane & 15) == 0) {
+                    const int c = mi * 32 + 16 * q + 4 * ps + (lane >> 4);
+                    atomicAdd(a.stats + c, (double)s1);
+                    atomicAdd(a.stats + a.Co + c, (double)s2);
+                }
+            }
     }
 }
 
@@ -714,7 +753,13 @@ int launch_stem_conv_fwd(const SmallConvArgs& a_in, hipStream_t st) {
     const int resident = a.Ci == 1 ? 3 : 2;             // workgroups per CU = waves per SIMD (register-bound)
     const long cap = (long)cus * resident;
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
-    if (a.Ci == 3)
+    if (a.stats) {
+        if (a.act != DYNMM_ACT_NONE) return DYNMM_EUNSUPPORTED;          // statistics of the convolution's own output
+        if (a.Ci == 3)
+            hipLaunchKernelGGL((conv_stem_fwd_kernel<3, true>), dim3(grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_stem_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.Ci == 3)
         hipLaunchKernelGGL((conv_stem_fwd_kernel<3>), dim3(grid), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((conv_stem_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, a);

@@ -48,6 +48,8 @@ SIGNATURES = {
     'dynmm_pack_weight_multi': (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     'dynmm_pack_weight_multi_blocks': (c_i, [c_i] * 5),
     'dynmm_conv2d_fwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_i, c_f]),
+    'dynmm_conv2d_stem_fwd_stats_supported': (c_i, [_GP]),
+    'dynmm_conv2d_stem_fwd_stats': (c_i, [c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_dgrad': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, _GP, c_f]),
     'dynmm_conv2d_wino_supported': (c_i, [_GP, c_i]),
     'dynmm_wino_packed_floats': (c_sz, [c_i, c_i, c_i, c_i]),

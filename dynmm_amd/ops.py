@@ -55,8 +55,9 @@ def _chk(t, name='tensor'):
 #               the 1x3 filters, F(2,3) for the 3x1 ones | '23': F(2,3) for both.  (A vertical F(4,3) form existed in round 4 — six
 #               input rows per four output rows through b32 reads, 72.37 ms against 71.63 — and was removed in round 5.  3x3
 #               filters take the 2-D form under either value.)
-#   CONV_BN_STATS  BatchNorm batch statistics from the epilogue of the convolution that feeds the BatchNorm (conv_wino.hip STATS)
-#               instead of a bn_stats launch + a pass over the conv output.
+#   CONV_BN_STATS  BatchNorm batch statistics from the epilogue of the convolution that feeds the BatchNorm (conv_wino.hip STATS,
+#               conv_wino2d.hip, and the two 7x7 stems: conv_small.hip conv_stem_fwd_kernel<CI, STATS>) instead of a bn_stats launch
+#               + a pass over the conv output.
 WINO = 'all'
 WINO_DGRAD = '43h'
 CONV_BN_STATS = True
@@ -646,6 +647,15 @@ class _Conv2d(Function):
         elif wino_f:
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_wino_fwd(_p(x), _p(utf), _p(bias), None, _p(y), C.byref(g), act, st),
                            wino=True), 'conv2d_wino_fwd')
+        elif (stats is not None and act == L.ACT_NONE and x2 is None and
+                lib.dynmm_conv2d_stem_fwd_stats_supported(C.byref(g))):
+            # a ResNet stem feeding its training-mode BatchNorm: the batch statistics come out of the convolution's epilogue
+            sums, zeroed = _zero_sums(2 * g.Co, x.device)
+            if not zeroed:
+                sums.zero_()
+            L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_stem_fwd_stats(_p(x), _p(wp), _p(bias), _p(y), _p(sums),
+                                                                             C.byref(g), st)), 'conv2d_stem_fwd_stats')
+            stats['sums'] = sums
         else:
             L.check(_timed('fwd', g, lambda: lib.dynmm_conv2d_fwd(_p(x), _p(x2), _p(wp), None, _p(bias), None, _p(y),
                                                                   C.byref(g), act, st)), 'conv2d_fwd')
@@ -1372,7 +1382,7 @@ class _StemBNFusePool(Function):
 
     @staticmethod
     def forward(ctx, xr, xd, gam_r, bet_r, rm_r, rv_r, nbt_r, gam_d, bet_d, rm_d, rv_d, nbt_d, mom_r, eps_r, mom_d,
-                eps_d, use_se, *params):
+                eps_d, use_se, pre_r, pre_d, *params):
         lib = _lib()
         st = _stream()
         xr, xd = _chk(xr, 'x_rgb'), _chk(xd, 'x_depth')
@@ -1386,10 +1396,13 @@ class _StemBNFusePool(Function):
         note_mutation()
         tr = torch.empty((4, Cc), **f32)                 # scale_r, shift_r, scale_d, shift_d
         stats = torch.empty((4, Cc), **f32)              # mean_r, invstd_r, mean_d, invstd_d
-        for k, (x, gam, bet, rm, rv, nbt, mom, eps) in enumerate(((xr, gam_r, bet_r, rm_r, rv_r, nbt_r, mom_r, eps_r),
-                                                                  (xd, gam_d, bet_d, rm_d, rv_d, nbt_d, mom_d, eps_d))):
-            sums, zeroed = _zero_sums(2 * Cc, dev)
-            L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, zeroed, st), 'bn_stats')
+        for k, (x, gam, bet, rm, rv, nbt, mom, eps, pre) in enumerate(((xr, gam_r, bet_r, rm_r, rv_r, nbt_r, mom_r, eps_r, pre_r),
+                                                                       (xd, gam_d, bet_d, rm_d, rv_d, nbt_d, mom_d, eps_d, pre_d))):
+            if pre is not None:                  # left by the stem convolution's epilogue (dynmm_conv2d_stem_fwd_stats)
+                sums = pre
+            else:
+                sums, zeroed = _zero_sums(2 * Cc, dev)
+                L.check(lib.dynmm_bn_stats(_p(x), _p(sums), N, Cc, HW, zeroed, st), 'bn_stats')
             L.check(lib.dynmm_bn_finalize(_p(sums), _p(gam), _p(bet), _p(rm), _p(rv), _p(stats[2 * k]), _p(stats[2 * k + 1]),
                                           _p(nbt), _p(tr[2 * k]), _p(tr[2 * k + 1]), N, Cc, HW, eps, mom, st), 'bn_finalize')
         sr = sd = hr = hd = gr = gd = None
@@ -1462,7 +1475,7 @@ class _StemBNFusePool(Function):
             outs.append((dx, dgamma_ret, dbeta_ret))
         _grads_enqueued()
         (dxr, dgr, dbr), (dxd, dgd, dbd) = outs
-        return (dxr, dxd, dgr, dbr, None, None, None, dgd, dbd, None, None, None, None, None, None, None, None,
+        return (dxr, dxd, dgr, dbr, None, None, None, dgd, dbd, None, None, None, None, None, None, None, None, None, None,
                 *dparams_ret)
 
 
@@ -1473,10 +1486,14 @@ def stem_bn_fuse_pool(x_rgb, bn_rgb, x_depth, bn_depth, se_params=None):
         nbt = bn.num_batches_tracked
         if nbt.dtype != torch.int64 or not nbt.is_cuda:
             raise L.DynmmHipError('BatchNorm num_batches_tracked must be an int64 tensor on the HIP device')
+    pre = []
+    for x in (x_rgb, x_depth):          # conv2d(..., bn_stats=True) hangs the statistics on its output (one slab of [2][C] doubles)
+        p = getattr(x, '_bn_sums', None)
+        pre.append(p if (p is not None and p.numel() == 2 * x.shape[1]) else None)
     return _StemBNFusePool.apply(x_rgb, x_depth, bn_rgb.weight, bn_rgb.bias, bn_rgb.running_mean, bn_rgb.running_var,
                                  bn_rgb.num_batches_tracked, bn_depth.weight, bn_depth.bias, bn_depth.running_mean,
                                  bn_depth.running_var, bn_depth.num_batches_tracked, float(bn_rgb.momentum),
-                                 float(bn_rgb.eps), float(bn_depth.momentum), float(bn_depth.eps), use_se,
+                                 float(bn_rgb.eps), float(bn_depth.momentum), float(bn_depth.eps), use_se, pre[0], pre[1],
                                  *(tuple(se_params) if use_se else ()))
 
 

@@ -93,6 +93,14 @@ int dynmm_conv2d_fwd(const float* x, const float* x2, const float* wp_fwd,
                      const float* scale, const float* shift, const float* residual,
                      float* y, const dynmm_conv_geom* g, int act, void* stream);
 
+/* The ResNet stem convolution (7x7, stride 2, padding 3, Ci 1 | 3 -> 64: src/models/resnet.py:216-217 conv1) feeding a
+ * training-mode BatchNorm (resnet.py:229 bn1): y = conv(x) + bias as dynmm_conv2d_fwd, and the per-channel sums of y and y^2 over
+ * (N, H, W) ADDED to stats [2][Co] (fp64, zeroed by the caller) from the kernel's epilogue — the `sums` operand of
+ * dynmm_bn_finalize / dynmm_bn_apply without a dynmm_bn_stats launch and its pass over y (629 MB per stem at batch 32). */
+int dynmm_conv2d_stem_fwd_stats_supported(const dynmm_conv_geom* g);
+int dynmm_conv2d_stem_fwd_stats(const float* x, const float* wp_fwd, const float* bias, float* y, double* stats,
+                                const dynmm_conv_geom* g, void* stream);
+
 /* dx = conv_transpose(dy, w) * [mask > 0] + accum   (mask, accum optional, shaped like x):
  * the autograd "input gradient" of the conv above, with the ReLU backward of the producer of x and
  * the gradient arriving over a residual branch fused into the epilogue (saves the separate

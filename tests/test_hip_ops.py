@@ -668,6 +668,77 @@ def test_conv_epilogue_batchnorm_statistics(ops, case):
         assert rel(b[i], a[i]) < 2e-4, i
 
 
+@pytest.mark.parametrize('case', [(3, 3, 40, 56), (2, 1, 40, 56), (2, 3, 37, 131), (3, 1, 30, 70), (4, 3, 96, 128)])
+def test_stem_conv_epilogue_batchnorm_statistics(ops, case):
+    """The 7x7 / stride-2 stem convolution with bn_stats=True (csrc/conv_small.hip conv_stem_fwd_kernel<CI, STATS>): the
+    statistics of bn1 come out of the persistent kernel's epilogue.  Through the C ABI against float64 (sums to 1e-6, the output
+    bit-identical to the plain launch), then the two consumers — batch_norm_act and stem_bn_fuse_pool — against their two-pass
+    forms, with a spy that no dynmm_bn_stats launch is left.  Shapes: whole tiles, ragged rows / columns (Ho % 4, Wo % 64,
+    Wo % 4 != 0), more tiles than resident workgroups."""
+    import ctypes as C
+    import torch.nn as nn
+    from dynmm_amd import lib as L
+    lib = L.load()
+    N, Ci, H, W = case
+    torch.manual_seed(7 * N + Ci)
+    conv = nn.Conv2d(Ci, 64, 7, stride=2, padding=3, bias=(Ci == 1)).cuda()
+    x = (rnd(N, Ci, H, W, seed=1) + 0.25).cuda()
+    y_ref = F.conv2d(x.double(), conv.weight.double(), None if conv.bias is None else conv.bias.double(), 2, 3)
+    g = ops._geom(x, None, conv.weight, (2, 2), (3, 3))
+    assert lib.dynmm_conv2d_stem_fwd_stats_supported(C.byref(g))
+    st = torch.cuda.current_stream().cuda_stream
+    wp = torch.empty(lib.dynmm_packed_weight_floats(64, Ci, 7, 7, 0), device='cuda')
+    L.check(lib.dynmm_pack_weight(ops._p(conv.weight.detach()), ops._p(wp), None, 64, Ci, 7, 7, st), 'pack')
+    y0, y1 = torch.empty(N, 64, g.Ho, g.Wo, device='cuda'), torch.empty(N, 64, g.Ho, g.Wo, device='cuda')
+    sums = torch.zeros(2, 64, device='cuda', dtype=torch.float64)
+    bias = None if conv.bias is None else conv.bias.detach()
+    L.check(lib.dynmm_conv2d_fwd(ops._p(x), None, ops._p(wp), None, ops._p(bias), None, ops._p(y0), C.byref(g), L.ACT_NONE, st), 'fwd')
+    L.check(lib.dynmm_conv2d_stem_fwd_stats(ops._p(x), ops._p(wp), ops._p(bias), ops._p(y1), ops._p(sums), C.byref(g), st), 'stats')
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert rel(y1, y_ref) < TOL
+    M = N * g.Ho * g.Wo
+    assert rel(sums[0] / M, y_ref.mean((0, 2, 3))) < 1e-6
+    assert rel(sums[1] / M, (y_ref * y_ref).mean((0, 2, 3))) < 1e-6
+
+    # consumer 1: batch_norm_act (the unfused stem of ESANet / SkipESANet, resnet.py:229-231)
+    bn = nn.BatchNorm2d(64).cuda().train()
+    old = ops.CONV_BN_STATS
+
+    def run(flag):
+        ops.CONV_BN_STATS = flag
+        bn.reset_running_stats()
+        with _CallSpy(lib, 'dynmm_bn_stats', 'dynmm_conv2d_stem_fwd_stats') as spy:
+            y = ops.conv2d(x, conv.weight, conv.bias, 2, 3, None, bn_stats=True)
+            assert hasattr(y, '_bn_sums') == flag
+            z = ops.batch_norm_act(y, bn, 'relu')
+        assert spy.count == ({'dynmm_bn_stats': 0, 'dynmm_conv2d_stem_fwd_stats': 1} if flag else
+                             {'dynmm_bn_stats': 1, 'dynmm_conv2d_stem_fwd_stats': 0}), spy.count
+        return z.detach(), bn.running_mean.clone(), bn.running_var.clone()
+    try:
+        a, b = run(False), run(True)
+    finally:
+        ops.CONV_BN_STATS = old
+    assert rel(b[0], a[0]) < 1e-5 and rel(b[1], a[1]) < 1e-6 and rel(b[2], a[2]) < 1e-6
+
+    # consumer 2: the fused stem tail of SkipGateESANet (ops.stem_bn_fuse_pool), both stems from their epilogues
+    if g.Ho % 2 == 0 and ops.stem_bn_fuse_supported(g.Ho, g.Wo, bn, bn):
+        convd = nn.Conv2d(1, 64, 7, stride=2, padding=3, bias=False).cuda()
+        xd = (rnd(N, 1, H, W, seed=3) - 0.1).cuda()
+        bns = [nn.BatchNorm2d(64).cuda().train() for _ in range(4)]
+
+        def tail(flag, br, bd):
+            with _CallSpy(lib, 'dynmm_bn_stats') as spy:
+                yr = ops.conv2d(x, conv.weight, conv.bias, 2, 3, None, bn_stats=flag)
+                yd = ops.conv2d(xd, convd.weight, None, 2, 3, None, bn_stats=flag)
+                o, dp = ops.stem_bn_fuse_pool(yr, br, yd, bd, None)
+            assert spy.count['dynmm_bn_stats'] == (0 if flag else 2)
+            return o.detach(), dp.detach(), br.running_var.clone(), bd.running_var.clone()
+        a, b = tail(False, bns[0], bns[1]), tail(True, bns[2], bns[3])
+        for u, v in zip(a, b):
+            assert rel(v, u) < 1e-5
+
+
 class _CallSpy:
     """Count the calls of C-ABI entry points (the ctypes function objects of the loaded library are replaced by counting
     wrappers for the duration of the block)."""
