@@ -264,22 +264,6 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
                 acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1, v3, acc[mi][3], 0, 0, 0);
             }
         }
-        return;
-    
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            float b0, b1, b2;
-            b0 = pp == 0 ? bx[S][16] : (pp == 4 ? bx[S][17] : bx[S][3 + pp]);
-            b1 = bx[S][4 + pp];
-            b2 = pp == 3 ? bx[S][18] : (pp == 7 ? bx[S][19] : bx[S][5 + pp]);
-        
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][mi][pp], b0, acc[mi][0], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi) acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][mi][pp], b1, acc[mi][1], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < MCO; ++mi) acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][mi][pp], b2, acc[mi][2], 0, 0, 0);
-        }
     };
 
     // ---------------------------------------------------------------- prologue: request stages 0 .. 2, read the set of step 0

@@ -217,9 +217,11 @@ class SkipGateESANet(nn.Module):
         if ops.stem_bn_fuse_supported((rgb.shape[2] + 1) // 2, (rgb.shape[3] + 1) // 2, er.bn1, ed.bn1):
             # training: stem BatchNorm + ReLU are applied on load by the fusion / pooling kernels (never written)
             c_r, c_d = er.conv1, ed.conv1
-            # (bn_stats: the batch statistics of bn1 come out of the stem convolution's epilogue where the kernel can)
-            r = ops.conv2d(rgb, c_r.weight, c_r.bias, c_r.stride, c_r.padding, bn_stats=True)
-            d = ops.conv2d(depth, c_d.weight, c_d.bias, c_d.stride, c_d.padding, bn_stats=True)
+            # (bn_stats: the batch statistics of bn1 come out of the stem convolution's epilogue where the kernel can;
+            #  stem_bn_defer + this order — depth stem first — make the backward run BN backward rgb -> weight gradient rgb
+            #  (asynchronous, the longer one) -> BN backward depth -> weight gradient depth at the end of the step)
+            d = ops.stem_bn_defer(ops.conv2d(depth, c_d.weight, c_d.bias, c_d.stride, c_d.padding, bn_stats=True), ed.bn1)
+            r = ops.stem_bn_defer(ops.conv2d(rgb, c_r.weight, c_r.bias, c_r.stride, c_r.padding, bn_stats=True), er.bn1)
             r, d = ops.stem_bn_fuse_pool(r, er.bn1, d, ed.bn1, self._se(0))
         else:
             r, d = self._stem_unfused(rgb, depth)

@@ -1091,7 +1091,12 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
         p = [t.cuda().requires_grad_(True) for t in prm] if prm else None
         if fused:
             assert ops.stem_bn_fuse_supported(H, W, *bns)
-            o, dp = ops.stem_bn_fuse_pool(xr, bns[0], xd, bns[1], p)
+            if fused == 'deferred':      # each stem's BatchNorm backward runs in its own autograd node (ops.stem_bn_defer)
+                xd_, xr_ = ops.stem_bn_defer(xd, bns[1]), ops.stem_bn_defer(xr, bns[0])
+                assert hasattr(xr_, '_stem_slot') and hasattr(xd_, '_stem_slot')
+                o, dp = ops.stem_bn_fuse_pool(xr_, bns[0], xd_, bns[1], p)
+            else:
+                o, dp = ops.stem_bn_fuse_pool(xr, bns[0], xd, bns[1], p)
         else:
             yr, yd = ops.batch_norm_act(xr, bns[0], 'relu'), ops.batch_norm_act(xd, bns[1], 'relu')
             yd1, yd2 = ops.fan_out(yd, 2)
@@ -1107,6 +1112,39 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
         assert torch.equal(x, y)
     for i, (x, y) in enumerate(zip(a[3], b[3])):
         assert rel(x, y) < 2e-4, i
+    c = run('deferred')                  # the same kernels in another order (fp64-atomic order in the reductions aside)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    for x, y in zip(a[2], c[2]):
+        assert torch.equal(x, y)
+    for i, (x, y) in enumerate(zip(a[3], c[3])):
+        assert rel(x, y) < 1e-6, i
+
+
+def test_weight_gradient_streams_have_least_priority(ops):
+    """ops.low_priority_stream / the weight-gradient pool: streams of the least priority the device offers (created through the
+    runtime, wrapped as torch streams), usable like any torch stream (event ordering against the current stream)."""
+    import ctypes as C
+    hip = C.CDLL('libamdhip64.so')
+    least, greatest = C.c_int(0), C.c_int(0)
+    assert hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0
+    old = list(ops._WGRAD_POOL)
+    ops._WGRAD_POOL.clear()
+    try:
+        streams = [ops._wgrad_stream() for _ in range(ops.WGRAD_STREAMS)]
+        assert len({s.cuda_stream for s in streams}) == ops.WGRAD_STREAMS
+        for s in streams:
+            got = C.c_int(-99)
+            assert hip.hipStreamGetPriority(C.c_void_p(s.cuda_stream), C.byref(got)) == 0
+            assert got.value == max(least.value, 0), (got.value, least.value, greatest.value)
+        a = rnd(1 << 20, seed=1).cuda()
+        s = streams[0]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            b = a * 2.0
+        torch.cuda.current_stream().wait_stream(s)
+        assert torch.equal(b, a + a)
+    finally:
+        ops._WGRAD_POOL[:] = old
 
 
 @pytest.mark.parametrize('case', [(4, 128, 24, 32, 128, (3, 1), (1, 0), True),      # three-tap kernel, vertical taps
