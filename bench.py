@@ -344,7 +344,7 @@ def kernel_timing(step_fn, model):
 
 def executed_fraction(name):
     """matrix-core FLOP executed per algorithmic (direct-convolution) FLOP of a launch"""
-    if 's2' in name:                 # polyphase stride-2 input gradients on the pair kernel: no Winograd arithmetic
+    if 's2' in name:                 # stride 2 — polyphase input gradients on the pair kernel, conv_wgrad_s2: no Winograd arithmetic
         return 1.0
     if 'wino2d' in name:
         return 4.0 / 9.0

@@ -1,6 +1,7 @@
 // Weight gradient of the horizontal three-tap convolutions (1x3, stride 1, 'same' padding: resnet.py:104-117) and, one vertical
 // tap per workgroup, of the 3x3 convolutions (resnet.py:66-84, model.py:343-357) on the fp32 matrix cores in the Winograd pair
-// form, operand tiles by direct global -> LDS loads ("v6").  The 3x1 convolutions take conv_wgrad_wino_vt.hip.  (Rounds 3-4 also
+// form, operand tiles by direct global -> LDS loads ("v6").  The 3x1 convolutions take conv_wgrad_wino_vt.hip, the stride-2
+// three-tap ones conv_wgrad_s2.hip (the same pipeline, direct form).  (Rounds 3-4 also
 // carried the direct form — three contractions per pixel, horizontal and vertical — behind DYNMM_WGRAD_WINO=0; removed in round 5.)
 //
 // dW[co][tap][ci] = sum_pix dY[co][pix] * X[ci][pix + tap shift]: M = co, N = (tap, ci), reduction over pixels.
@@ -318,8 +319,13 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     }
 }
 
+// (conv_wgrad_s2.hip) the stride-2 three-tap convolutions of the first block of a stage, direct form on the same pipeline
+bool wgrad_s2_shape_ok(const dynmm_conv_geom* g);
+void launch_wgrad_s2(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t st);
+
 // geometry only (pointer alignment is the launcher's business)
 bool wgrad_v6_shape_ok(const dynmm_conv_geom* g) {
+    if (wgrad_s2_shape_ok(g)) return true;
     const bool h_taps = g->KH == 1 && g->KW == 3 && g->PH == 0 && g->PW == 1;
     const bool v_taps = g->KH == 3 && g->KW == 1 && g->PH == 1 && g->PW == 0;
     const bool k33 = g->KH == 3 && g->KW == 3 && g->PH == 1 && g->PW == 1 && g->H >= 2;
@@ -339,7 +345,7 @@ int wgrad_v6_tco(const dynmm_conv_geom* g) { return g->Co % 128 == 0 ? 128 : 64;
 // workgroups per CU the launcher compiles the kernel for; the plan sizes one residency round with it.  Vertical taps
 // (conv_wgrad_wino_vt.hip): 2.  Horizontal taps: 128-row tiles hold 128 accumulators (2 waves per SIMD), 64-row tiles half of that (3).
 int wgrad_v6_occupancy(const dynmm_conv_geom* g) {
-    if (g->KH == 3 && g->KW == 1) return 2;
+    if (g->KH == 3 && g->KW == 1) return 2;         // (stride 1: the Winograd pair positions; stride 2: three X row sets per stage)
     return g->Co % 128 == 0 ? 2 : 3;
 }
 
@@ -350,7 +356,9 @@ void launch_wgrad_wino_vt(const WgradArgs& a, const WgradGroup& grp, dim3 grid, 
 void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int occ, hipStream_t st) {
     (void)occ;
     const bool two = a.Co % 128 == 0;
-    if (a.KH == 3 && a.KW == 1) {                   // vertical taps: pair positions (conv_wgrad_wino_vt.hip)
+    if (a.SH == 2 || a.SW == 2) {                   // stride-2 three-tap convolutions: direct form (conv_wgrad_s2.hip)
+        launch_wgrad_s2(a, grp, grid, st);
+    } else if (a.KH == 3 && a.KW == 1) {                   // vertical taps: pair positions (conv_wgrad_wino_vt.hip)
         launch_wgrad_wino_vt(a, grp, grid, st);
     } else if (a.KH == 3 && a.KW == 3) {            // one vertical tap per workgroup, horizontal Winograd pairs
         if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, 3, 2, true>), grid, dim3(256), 0, st, a, grp);

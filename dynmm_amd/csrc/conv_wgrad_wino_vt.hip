@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
 // does conv_wgrad_v6's launcher hand this (v6-eligible) geometry to the kernel above?  (the plan needs to know: its
 // reduction runs over pair positions in steps of 8, not over pixels in steps of 16)
 bool wgrad_wino_vt_on(const dynmm_conv_geom* g) {
-    return g->KH == 3 && g->KW == 1;
+    return g->KH == 3 && g->KW == 1 && g->SH == 1;          // (stride 2: conv_wgrad_s2.hip, 16-pixel steps)
 }
 
 int wgrad_wino_vt_units(const dynmm_conv_geom* g) { return g->N * ((g->H + 1) / 2) * g->W; }

@@ -360,7 +360,9 @@ def _timed(kind, g, call, nprob=1, extra=0, wino=False):
     name = f'conv_wgrad<co{_tile(co).split("x")[0]}>' if kind == 'wgrad' else f'conv_igemm_{kind}<{_tile(co, m)}{generic}>'
     if kind == 'wgrad':
         variant = _lib().dynmm_conv2d_wgrad_variant(C.byref(g))
-        if variant == 6:                                    # conv_wgrad_v6.hip: one template instance per tile height and tap axis
+        if variant == 6 and (g.SH == 2 or g.SW == 2):       # conv_wgrad_s2.hip: the stride-2 three-tap convolutions, direct form
+            name = f'conv_wgrad_s2<co{128 if g.Co % 128 == 0 else 64},{g.KH}x{g.KW}>'
+        elif variant == 6:                                  # conv_wgrad_v6.hip: one template instance per tile height and tap axis
             name = f'conv_wgrad_v6<co{128 if g.Co % 128 == 0 else 64},{g.KH}x{g.KW}>'
         elif variant == 4:
             name = 'conv_wgrad_v4<co128>'                   # the vectorised 128x128 kernel (conv_igemm.hip: wgrad_v4_shape_ok)

@@ -60,6 +60,8 @@ def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr, steps_
                 'conv_wgrad_v6<co64,1x3>': ('conv_wgrad_v6_kernel<1, 3, 3, false>', 2),
                 'conv_wgrad_v6<co64,3x3>': ('conv_wgrad_v6_kernel<1, 3, 3, true>', 2),
                 'conv_wgrad_v6<co64,3x1>': ('conv_wgrad_wino_vt_kernel<1>', 2),
+                'conv_wgrad_s2<co128,3x1>': ('conv_wgrad_s2_kernel<2, true, 2>', 2),
+                'conv_wgrad_s2<co128,1x3>': ('conv_wgrad_s2_kernel<2, false, 2>', 2),
                 # Winograd kernels (conv_wino.hip / conv_wino43.hip / conv_wino2d.hip; 16 B/lane direct-to-LDS streams).  keys =
                 # bench.py's kernel_instance(); conv_wino_kernel's template arguments are <TCO, MCO, VERT, DGRAD, S2, TAIL, STATS,
                 # BNRED>, conv_wino2d_kernel's <DGRAD, TAIL, STATS>: a label that several compiled instances serve (the training

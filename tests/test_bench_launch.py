@@ -73,13 +73,14 @@ def test_roofline_kernel_names_match_the_pmc_summary():
     labels = ['conv_wino43_dgrad<co128,1x3>', 'conv_wino43_dgrad<co64,1x3>', 'conv_wino2d_dgrad<co128,3x3>',
               'conv_wino_fwd<co128,1x3>', 'conv_wino_fwd<co64,3x1>', 'conv_wino2d_fwd<co64,3x3>', 'conv_wino_dgrad<co128,3x1>',
               'conv_wino_dgrad<co128,1x3s2>', 'conv_wino_dgrad<co64,3x1s2>', 'conv_wgrad_v6<co128,1x3>', 'conv_wgrad_v6<co64,3x1>',
-              'conv_wgrad_v6<co64,3x3>', 'conv_igemm_v5_fwd<128x64,kw1>']
+              'conv_wgrad_v6<co64,3x3>', 'conv_wgrad_s2<co128,3x1>', 'conv_wgrad_s2<co128,1x3>', 'conv_igemm_v5_fwd<128x64,kw1>']
     for lb in labels:
         assert bench.kernel_instance(lb) in keys, (lb, bench.kernel_instance(lb))
     assert bench.executed_fraction('conv_wino43_dgrad<co128,1x3>') == 0.5
     assert abs(bench.executed_fraction('conv_wino_fwd<co64,1x3>') - 2 / 3) < 1e-12
     assert abs(bench.executed_fraction('conv_wino2d_fwd<co64,3x3>') - 4 / 9) < 1e-12
     assert bench.executed_fraction('conv_wino_dgrad<co128,1x3s2>') == 1.0 and bench.executed_fraction('conv_igemm_fwd<128x64>') == 1.0
+    assert bench.executed_fraction('conv_wgrad_s2<co128,3x1>') == 1.0          # stride 2: the direct form
     # the committed record carries the kernel the last bench line named
     rec = json.load(open(os.path.join(root, 'profiles', 'pmc_dominant_kernel.json')))
     assert 'conv_wino43_dgrad<horizontal>' in rec and rec['conv_wino43_dgrad<horizontal>']['launches_per_step'] == 76

@@ -72,6 +72,13 @@ CONV_CASES = [
     (5, 64, 17, 20, 64, (3, 1), (1, 1), (1, 0), True, 'relu'),       # vertical taps, 64-row tile, M = 1700, odd H
     (2, 128, 9, 16, 256, (3, 1), (1, 1), (1, 0), True, None),        # narrowest rows (one step = one row), 2 co tiles x 2 ci tiles
     (1, 192, 8, 24, 64, (1, 3), (1, 1), (0, 1), False, None),        # 3 ci tiles, no bias, a step straddles rows
+    # stride-2 three-tap weight-gradient kernel (conv_wgrad_s2.hip): the first block of a stage, Wo % 4 == 0 >= 16, Ci, Co % 64 == 0
+    (3, 256, 30, 40, 512, (3, 1), (2, 1), (1, 0), True, None),       # rows of 40: steps straddle rows; 4 x 4 tiles, several splits
+    (3, 512, 15, 40, 512, (1, 3), (1, 2), (0, 1), True, None),       # Wo = 20, 300-pixel images: ragged M = 900, steps straddle images
+    (2, 64, 24, 32, 64, (3, 1), (2, 1), (1, 0), False, 'relu'),      # 64-row tile, no bias
+    (2, 64, 24, 64, 64, (1, 3), (1, 2), (0, 1), True, None),         # 64-row tile (3 workgroups per CU)
+    (1, 64, 120, 160, 128, (3, 1), (2, 1), (1, 0), True, None),      # the stage-2 shape at batch 1
+    (1, 128, 60, 160, 128, (1, 3), (1, 2), (0, 1), True, None),
     # ... 3x3 filters on the same kernel, one vertical tap per workgroup (round 5: BasicBlock / decoder conv3x3 weight gradients)
     (3, 64, 17, 20, 64, (3, 3), (1, 1), (1, 1), True, None),         # 64-row tile, odd H, M = 1020: steps straddle rows AND images
     (2, 128, 9, 16, 256, (3, 3), (1, 1), (1, 1), True, 'relu'),      # narrowest rows: every step is one image row, 2 x 2 x 3 k-tiles
@@ -1152,29 +1159,32 @@ def test_weight_gradient_streams_have_least_priority(ops):
                                   (3, 128, 15, 20, 256, (1, 3), (0, 1), True),      # ... horizontal taps, M = 900 (ragged)
                                   (2, 128, 12, 16, 128, (1, 1), (0, 0), True),      # vectorised 128x128 kernel
                                   (4, 128, 24, 32, 128, (3, 3), (1, 1), False),       # 3x3 on the three-tap kernel (tap rows as k-tiles)
-                                  (3, 64, 15, 20, 64, (3, 3), (1, 1), True)])          # ... 64-row tile, bias, ragged M = 900
+                                  (3, 64, 15, 20, 64, (3, 3), (1, 1), True),           # ... 64-row tile, bias, ragged M = 900
+                                  (3, 128, 30, 40, 256, (3, 1), (1, 0), True, (2, 1)),  # stride-2 kernel (conv_wgrad_s2.hip), vertical taps
+                                  (3, 128, 15, 40, 128, (1, 3), (0, 1), True, (1, 2))]) # ... horizontal taps, ragged M = 900
 def test_grouped_weight_gradients(ops, case):
     """dynmm_conv2d_wgrad_group through the C ABI: 3 same-geometry convolutions in one launch against fp64 torch (and
     the bias gradients that ride along), bit-identical between two calls, and the n = 1 / not-groupable fallbacks."""
     import ctypes as C
     from dynmm_amd import lib as L
     lib = L.load()
-    N, Ci, H, W, Co, k, pad, bias = case
+    N, Ci, H, W, Co, k, pad, bias, *rest = case
+    stride = rest[0] if rest else (1, 1)
     st = torch.cuda.current_stream().cuda_stream
     xs = [rnd(N, Ci, H, W, seed=10 + i).cuda() for i in range(3)]
     w0 = torch.empty(Co, Ci, *k)
-    g = ops._geom(xs[0], None, w0, (1, 1), pad)
+    g = ops._geom(xs[0], None, w0, stride, pad)
     dys = [rnd(N, Co, g.Ho, g.Wo, seed=20 + i).cuda() for i in range(3)]
     ref_w, ref_b = [], []
     for x, dy in zip(xs, dys):
         xd = x.double().cpu()
         wd = torch.zeros(Co, Ci, *k, dtype=torch.float64, requires_grad=True)
-        y = F.conv2d(xd, wd, None, 1, pad)
+        y = F.conv2d(xd, wd, None, stride, pad)
         y.backward(dy.double().cpu())
         ref_w.append(wd.grad)
         ref_b.append(dy.double().cpu().sum((0, 2, 3)))
     assert lib.dynmm_conv2d_wgrad_groupable(C.byref(g)) in (1, 2)
-    if k != (1, 1) and Ci % 64 == 0 and Co % 64 == 0 and W % 4 == 0 and W >= 16:
+    if k != (1, 1) and Ci % 64 == 0 and Co % 64 == 0 and W % 4 == 0 and g.Wo >= 16:
         assert lib.dynmm_conv2d_wgrad_variant(C.byref(g)) == 6          # conv_wgrad_v6.hip (Winograd pairs), 3x3 included
 
     def run(n):
