@@ -67,6 +67,9 @@ def encoder_stage_pair(model, j, r_in, d_in):
     side = model._side
     main = torch.cuda.current_stream()
     capturing = torch.cuda.is_current_stream_capturing()
+    # (Round 5 measured letting the depth chain run a fusion AHEAD of the RGB chain — its stream waiting for `main` at stage 1 only,
+    # its convolutions beside the fusion kernels: 63.45 against 63.21 ms in lockstep on 4 alternating pairs; two same-shape
+    # launches side by side fill the chip better than staggered ones.  Not kept.)
     side.wait_stream(main)
     if not capturing:
         d_in.record_stream(side)         # allocated on `main`, read on the side stream
@@ -262,6 +265,9 @@ class SkipGateESANet(nn.Module):
                 host_branch = [int(v) for v in list(self.branch_override)[:bs]]
                 force = self._force_tensor(host_branch, rgb.device)
             (r, r_gate), (d, d_gate) = ops.fan_out(r, 2), ops.fan_out(d, 2)    # gate convs + first encoder stage
+            # (the gate's kernels on a stream of their own beside encoder stage 1 — they are first read by the fusion at the END of
+            #  stage 1 — were measured in rounds 3 and 5: +-0.1 ms then, 73.4 against 62.95 ms per step now, 4 alternating pairs (the
+            #  gate's backward nodes then run on a third stream in the middle of the stage-1 backward; cause not pursued).  Not kept.)
             pooled = self.gate_layer.features(r_gate, d_gate)
             weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate, force)
         if self.save_weight_info:

@@ -67,14 +67,15 @@ def main(fetch_csv, write_csv, sq_csv, out_md, out_json, dominant_substr, steps_
                 # BNRED>, conv_wino2d_kernel's <DGRAD, TAIL, STATS>: a label that several compiled instances serve (the training
                 # forward before a BatchNorm runs the STATS instance, the input gradient behind relu(BN(.)) the BNRED one, the
                 # 40-class conv_out the TAIL one) lists them all — the record is their launch-weighted mean
-                'conv_wino_fwd<horizontal>': (['conv_wino_kernel<64, 1, false, false, false, false, false, false>',
-                                               'conv_wino_kernel<64, 1, false, false, false, false, true, false>'], 2),
-                'conv_wino_fwd<vertical>': (['conv_wino_kernel<64, 1, true, false, false, false, false, false>'], 2),
-                'conv_wino_dgrad<horizontal>': (['conv_wino_kernel<64, 1, false, true, false, false, false, false>'], 2),
-                'conv_wino_dgrad<vertical>': (['conv_wino_kernel<64, 1, true, true, false, false, false, false>',
-                                               'conv_wino_kernel<64, 1, true, true, false, false, false, true>'], 2),
-                'conv_wino_dgrad<horizontal,s2>': (['conv_wino_kernel<64, 1, false, true, true, false, false, false>'], 2),
-                'conv_wino_dgrad<vertical,s2>': (['conv_wino_kernel<64, 1, true, true, true, false, false, false>'], 2),
+                'conv_wino_fwd<horizontal>': (['conv_wino_kernel<64, 1, false, false, false, false, false, 0>',
+                                               'conv_wino_kernel<64, 1, false, false, false, false, true, 0>'], 2),
+                'conv_wino_fwd<vertical>': (['conv_wino_kernel<64, 1, true, false, false, false, false, 0>'], 2),
+                'conv_wino_dgrad<horizontal>': (['conv_wino_kernel<64, 1, false, true, false, false, false, 0>'], 2),
+                'conv_wino_dgrad<vertical>': (['conv_wino_kernel<64, 1, true, true, false, false, false, 0>',
+                                               'conv_wino_kernel<64, 1, true, true, false, false, false, 1>',
+                                               'conv_wino_kernel<64, 1, true, true, false, false, false, 2>'], 2),
+                'conv_wino_dgrad<horizontal,s2>': (['conv_wino_kernel<64, 1, false, true, true, false, false, 0>'], 2),
+                'conv_wino_dgrad<vertical,s2>': (['conv_wino_kernel<64, 1, true, true, true, false, false, 0>'], 2),
                 'conv_wino43_dgrad<horizontal>': (['conv_wino43_kernel('], 2),
                 'conv_wino2d_fwd<3x3>': (['conv_wino2d_kernel<false, false, false>', 'conv_wino2d_kernel<false, true, false>',
                                           'conv_wino2d_kernel<false, false, true>'], 2),
