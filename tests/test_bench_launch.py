@@ -84,3 +84,5 @@ def test_roofline_kernel_names_match_the_pmc_summary():
     # the committed record carries the kernel the last bench line named
     rec = json.load(open(os.path.join(root, 'profiles', 'pmc_dominant_kernel.json')))
     assert 'conv_wino43_dgrad<horizontal>' in rec and rec['conv_wino43_dgrad<horizontal>']['launches_per_step'] == 76
+    assert 'conv_wino_dgrad<vertical>' in rec and rec['conv_wino_dgrad<vertical>']['launches_per_step'] == 76     # (BNRED 0 | 1 | 2 instances)
+    assert rec['conv_wgrad_s2<co128,3x1>']['launches_per_step'] == 6
