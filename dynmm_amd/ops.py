@@ -1533,8 +1533,9 @@ class _StemBNDeferred(Function):
     def backward(ctx, g):
         fn = ctx.slot.pop('bwd', None)
         if fn is None:
-            raise L.DynmmHipError('stem_bn_defer: the deferred BatchNorm backward was not prepared (the tensor did not go '
-                                  'into stem_bn_fuse_pool, or the graph was walked twice)')
+            # nothing was left here: the consumer ran the BatchNorm backward itself (only ONE of the two stems was deferred, or
+            # the tensor went elsewhere) and `g` is the real gradient
+            return g, None, None, None
         dx, dgam, dbet = fn()
         return dx, dgam, dbet, None
 

@@ -1102,6 +1102,8 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
                 xd_, xr_ = ops.stem_bn_defer(xd, bns[1]), ops.stem_bn_defer(xr, bns[0])
                 assert hasattr(xr_, '_stem_slot') and hasattr(xd_, '_stem_slot')
                 o, dp = ops.stem_bn_fuse_pool(xr_, bns[0], xd_, bns[1], p)
+            elif fused == 'one deferred':    # only one stem wrapped: the fused node does both BatchNorm backwards itself
+                o, dp = ops.stem_bn_fuse_pool(ops.stem_bn_defer(xr, bns[0]), bns[0], xd, bns[1], p)
             else:
                 o, dp = ops.stem_bn_fuse_pool(xr, bns[0], xd, bns[1], p)
         else:
@@ -1124,6 +1126,10 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
     for x, y in zip(a[2], c[2]):
         assert torch.equal(x, y)
     for i, (x, y) in enumerate(zip(a[3], c[3])):
+        assert rel(x, y) < 1e-6, i
+    d = run('one deferred')
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+    for i, (x, y) in enumerate(zip(a[3], d[3])):
         assert rel(x, y) < 1e-6, i
 
 
