@@ -417,6 +417,21 @@ def roofline_of(agg):
                                   for k, v in sorted(agg.items())}}
 
 
+def dependent_kernel_interval_us(device, n=2000):
+    """Box diagnostic: the time one DEPENDENT, empty kernel costs on a stream (n one-element adds back to back): dispatch + completion
+    latency of the box, the floor under each of the step's ~890 launches.  The same tree measured 62.6 ... 65.2 ms per step on boxes
+    whose isolated per-kernel rates were identical; this figure travels with the line so a reader can tell."""
+    x = torch.zeros(1, device=device)
+    for _ in range(200):
+        x.add_(1.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        x.add_(1.0)
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / n * 1e6, 2)
+
+
 def timed(step, steps, warmup, world, device):
     for _ in range(warmup):
         step()
@@ -830,6 +845,7 @@ def main():
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
                        'winograd': {'passes': ops.WINO, 'input_gradients': ops.WINO_DGRAD, 'weight_gradients': True},
+                       'dependent_kernel_interval_us': dependent_kernel_interval_us(device),
                        'dp': dp_info},
             'whole_step': {'net': f'{"SkipGateESANet" if args.model == "gate" else "SkipESANet"} R34-'
                                   f'{"NBt1D" if args.config == "P" else "BasicBlock"} SE-add (config {args.config})',
