@@ -139,8 +139,13 @@ def low_priority_stream():
     BatchNorm backward -> input gradient), whose workgroups the dispatcher now takes first — 7 alternating pairs of runs on one
     box: -0.18 ms per step on average, never slower (round 5; the opposite, high-priority chains, cost +0.75 ms in round 3)."""
     if not _HIP_RT:
-        _HIP_RT.append(C.CDLL('libamdhip64.so'))
+        # the runtime that is ALREADY mapped in this process (torch's), by its path: a bare dlopen('libamdhip64.so') could bring a
+        # second runtime in, whose streams mean nothing to the first
+        mapped = sorted(L._mapped_hip_runtimes())
+        _HIP_RT.append(C.CDLL(mapped[0]) if len(mapped) == 1 else None)
     hip = _HIP_RT[0]
+    if hip is None:
+        return torch.cuda.Stream()
     torch.cuda.current_stream()                     # (makes sure the device context exists)
     least, greatest = C.c_int(0), C.c_int(0)
     if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value <= 0:

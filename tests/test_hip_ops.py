@@ -1137,7 +1137,10 @@ def test_weight_gradient_streams_have_least_priority(ops):
     """ops.low_priority_stream / the weight-gradient pool: streams of the least priority the device offers (created through the
     runtime, wrapped as torch streams), usable like any torch stream (event ordering against the current stream)."""
     import ctypes as C
-    hip = C.CDLL('libamdhip64.so')
+    from dynmm_amd import lib as L
+    mapped = sorted(L._mapped_hip_runtimes())
+    assert len(mapped) == 1, mapped
+    hip = C.CDLL(mapped[0])                     # the runtime of this process (torch's)
     least, greatest = C.c_int(0), C.c_int(0)
     assert hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0
     old = list(ops._WGRAD_POOL)
