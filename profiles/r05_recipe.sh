@@ -15,7 +15,7 @@ python profiles/summarize_rocpd.py $O/multi/bench_results.db $O/multi.md > /dev/
 python scratch/gantt.py $O/multi/bench_results.db > $O/gantt_multi.txt 2>&1
 python scratch/gantt.py $O/single/bench_results.db > $O/gantt_single.txt 2>&1
 # which kernels run while NO matrix-core kernel does (the exposed HBM / latency-bound time of the 3-stream step), in time order
-python scratch/r5/exposed.py $O/multi/bench_results.db > $O/exposed.txt 2>&1
+python profiles/exposed_kernels.py $O/multi/bench_results.db > $O/exposed.txt 2>&1
 if [ "$1" != "trace" ]; then
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 1 $B --no-kernel-timing --single-stream > $O/pmc_fetch.log 2>&1

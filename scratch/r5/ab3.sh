@@ -11,6 +11,6 @@ done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/multi3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing > $GRAFT_REPO_ROOT/$O/multi3_stdout.log 2>&1
 cd $GRAFT_REPO_ROOT
-python scratch/r5/exposed.py $O/multi3/bench_results.db > $O/exposed3.txt 2>&1
+python profiles/exposed_kernels.py $O/multi3/bench_results.db > $O/exposed3.txt 2>&1
 rm -rf $O/multi3
 head -12 $O/exposed3.txt; tail -25 $O/exposed3.txt
