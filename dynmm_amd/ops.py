@@ -122,7 +122,9 @@ DIRECT_GRAD = False
 # the main backward chain and fills its ramp-up / tail bubbles.  Tensors it reads are kept alive in
 # _INFLIGHT until join_async() (call it after backward, on the stream that consumes the gradients).
 ASYNC_WGRAD = False
-WGRAD_STREAMS = 2        # weight-gradient side streams (scratch/r4/knob_sweep.sh: 1 / 2 / 3 within 0.4 ms)
+WGRAD_STREAMS = 2        # weight-gradient side streams.  With the null stream and the depth-encoder stream that makes the FOUR busy
+                         # streams the runtime's hardware queues hold: a third one costs 10 ms per step (profiles/r05_ab_runs.md:
+                         # 74.5 against 63.7 ms; one stream: 64.6)
 _WGRAD_POOL = []
 _WGRAD_RR = [0]
 _INFLIGHT = []
