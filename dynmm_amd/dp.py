@@ -55,6 +55,13 @@ class GradBucketReducer:
         self._works = []
         self.overlap = overlap and (self.world > 1 or self.force)
         self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda') else None
+        # RCCL: the bucket all-reduces are issued as stream-ordered collectives (async_op=False: the process group enqueues them on
+        # the CURRENT stream, no stream of its own) on one of the weight-gradient streams the step already uses.  A stream of
+        # their own — the first design: `_comm_stream` + the process group's internal stream — makes a fifth / sixth busy stream,
+        # which costs the step 10 ms on this part (profiles/r05_ab_runs.md: 74.0 against 63.2 ms with ONE rank's collectives
+        # forced on; the same as a third weight-gradient stream or a stream for the gate).  Other backends (gloo: tests) keep the
+        # asynchronous form.
+        self._stream_ordered = bool(dev.type == 'cuda' and dist.is_initialized() and dist.get_backend(process_group) == 'nccl')
         self._hooks = []
         self._streams = [dict() for _ in self.buckets]      # per bucket: producer streams seen this step
         self.active = True                                   # False: gradient hooks are ignored (tests: un-reduced pass)
@@ -91,7 +98,16 @@ class GradBucketReducer:
             e = self._total + 1                          # + the loss slot
         chunk = self._store[s:e]
         self.launch_log.append((b, where))
-        if self._comm_stream is not None:
+        if self._stream_ordered:
+            from . import ops
+            cs = self._comm_stream = ops.exchange_stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            for st in self._streams[b].values():         # side streams that wrote into this bucket (wgrad queue, depth encoder)
+                if st.cuda_stream != cs.cuda_stream:
+                    cs.wait_stream(st)
+            with torch.cuda.stream(cs):
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+        elif self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             for st in self._streams[b].values():         # side streams that wrote into this bucket (wgrad queue, depth encoder)
                 self._comm_stream.wait_stream(st)

@@ -166,6 +166,14 @@ def _wgrad_stream():
     return _WGRAD_POOL[_WGRAD_RR[0]]
 
 
+def exchange_stream():
+    """The stream the data-parallel gradient exchange is enqueued on (dp.GradBucketReducer): the LAST weight-gradient stream —
+    not a stream of its own, see WGRAD_STREAMS."""
+    while len(_WGRAD_POOL) < max(1, WGRAD_STREAMS):
+        _WGRAD_POOL.append(low_priority_stream())
+    return _WGRAD_POOL[-1]
+
+
 def join_async():
     flush_wgrad_groups()
     if _INFLIGHT:

@@ -111,7 +111,7 @@ def test_real_model_two_ranks_overlap_and_exact_mean():
 
 def _rccl_worker(port, q):
     """one rank over the 'nccl' (= RCCL) backend: the collective is trivial, the code path is not — communicator
-    creation on the selected device, async all-reduce of every bucket on the communication stream DURING backward,
+    creation on the selected device, stream-ordered all-reduce of every bucket on a weight-gradient stream DURING backward,
     stream joins, division by the world size, fused optimizer."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
                       DYNMM_DP_FORCE_COLLECTIVES='1')
@@ -138,6 +138,10 @@ def _rccl_worker(port, q):
     red.finish()
     torch.cuda.synchronize()
     flat = red.flat.clone()
+    # the exchange is stream-ordered on one of the step's own streams (a fifth busy stream costs the step 10 ms: dp.py)
+    from dynmm_amd import ops
+    assert red._stream_ordered and red._comm_stream.cuda_stream == ops.exchange_stream().cuda_stream
+    assert red._comm_stream.cuda_stream in [s_.cuda_stream for s_ in ops._WGRAD_POOL] and not red._works
     q.put(('ok', launched, len(red.buckets), bool(torch.isfinite(flat).all().item()), float(flat.abs().sum().item())))
     dist.destroy_process_group()
 
