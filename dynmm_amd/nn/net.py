@@ -267,7 +267,7 @@ class SkipGateESANet(nn.Module):
             (r, r_gate), (d, d_gate) = ops.fan_out(r, 2), ops.fan_out(d, 2)    # gate convs + first encoder stage
             # (the gate's kernels on a stream of their own beside encoder stage 1 — they are first read by the fusion at the END of
             #  stage 1 — were measured in rounds 3 and 5: +-0.1 ms then, 73.4 against 62.95 ms per step now, 4 alternating pairs (the
-            #  gate's backward nodes then run on a third stream in the middle of the stage-1 backward; cause not pursued).  Not kept.)
+            #  cause: a FIFTH busy stream, see ops.WGRAD_STREAMS; on an existing stream — the last weight-gradient one — 64.05 against 63.77).  Not kept.)
             pooled = self.gate_layer.features(r_gate, d_gate)
             weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate, force)
         if self.save_weight_info:
