@@ -5,7 +5,9 @@ Design for MI355X: gradients live in a single flat fp32 buffer (129.6 MB for con
 few large buckets; every parameter's `.grad` is a view into it, so autograd accumulates in place and
 no flatten/unflatten copies exist.  xGMI is point-to-point, so a ring all-reduce is bound by one link
 (~153 GB/s/dir): a few ~32 MB buckets keep each collective far above the latency floor while letting
-the first buckets (decoder grads, produced first) fly on a side stream under the rest of backward.
+the first buckets (decoder grads, produced first) fly under the rest of backward — as stream-ordered collectives
+on one of the step's two weight-gradient streams, not on a stream of their own (the step holds four busy streams; a fifth
+costs it 10 ms: GradBucketReducer.__init__).
 BatchNorm statistics stay per replica (DDP semantics; the reference has no SyncBN).
 
 Works with any torch.distributed backend: `nccl` (= RCCL) on GPUs, `gloo` on CPU for the
