@@ -151,6 +151,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
+    // The halo values d0 / d5 of a quad are element 3 / element 0 of the NEIGHBOURING lanes' quads: they come by a register
+    // exchange (v_mov_b32 dpp wave_shr:1 / wave_shl:1), not from LDS — as two ds_read_b32 at a 16-byte lane stride they were 4-way
+    // bank conflicts (bank = (a / 4) mod 32: 8 banks for 32 lanes), 16 LDS cycles per k-pair beside the 4 of the quad's own
+    // ds_read_b128 (round 5: conflict cycles 0.60 of the LDS-active ones).  Only the first / last lane of a wave's 32 quads has
+    // no neighbour in the wave (the other wave's quad or the tile halo): ONE ds_read_b32 per k-pair serves both, every other
+    // lane reading lane 0's address (a broadcast) — 2 LDS cycles.
+    const bool edge_lo = l31 == 0, edge_hi = l31 == 31;
+    const int e_frag = khalf * PIXW + (edge_hi ? 4 * lq + 8 : 4 * (wave_q * 32) + 3);
     float4 fa4[2];
     float2 fa2[2];
     float fd[2][6], fv[2][6];
@@ -159,13 +167,18 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         fa2[set] = *reinterpret_cast<const float2*>(A2p + a2_frag + 2 * q * TCO * 2);
         const float* b = Bp + b_frag + 2 * q * PIXW;
         const float4 u = *reinterpret_cast<const float4*>(b + 1);
-        fd[set][0] = b[0];
+        fd[set][0] = Bp[e_frag + 2 * q * PIXW];      // the edge lanes' halo value (d0 of lane 0, d5 of lane 31)
         fd[set][1] = u.x; fd[set][2] = u.y; fd[set][3] = u.z; fd[set][4] = u.w;
-        fd[set][5] = b[5];
-    
     };
     auto transform = [&](int set) {
         float d[6];
+        {
+            const float edge = fd[set][0];
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, fd[set][4]), 0x138, 0xf, 0xf, false));   // wave_shr:1
+            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, fd[set][1]), 0x130, 0xf, 0xf, false));   // wave_shl:1
+            fd[set][0] = edge_lo ? edge : lo;
+            fd[set][5] = edge_hi ? edge : hi;
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) d[j] = dv[j] ? fd[set][j] : 0.f;
         const float p = fmaf(-4.f, d[2], d[4]), q_ = fmaf(-4.f, d[1], d[3]);

@@ -20,7 +20,22 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, params, bucket_mb=32.0, overlap=True, process_group=None):
+    EXCHANGE_MODES = ('wgrad', 'depth', 'comm')
+
+    def __init__(self, params, bucket_mb=32.0, overlap=True, process_group=None, exchange='wgrad'):
+        """exchange (RCCL only; other backends always use asynchronous collectives): where the bucket all-reduces are enqueued —
+          'wgrad'  stream-ordered on the LAST weight-gradient stream of ops.stream_plan() (least priority; default),
+          'depth'  stream-ordered on the depth-encoder stream of the plan (normal priority; idle during the decoder's backward,
+                   on the dependent chain during the encoders'),
+          'comm'   asynchronous collectives from a communication stream of their own (the classic DDP arrangement: the process
+                   group's internal stream does the work) — a FIFTH and sixth busy stream, which costs a single rank 10 ms per
+                   step on this part (profiles/r05_ab_runs.md), but the one arrangement whose behaviour at world > 1 is
+                   common knowledge.
+        None of the three has run at world > 1 on hardware (no multi-GPU node in any round); the choice is a constructor
+        argument (engine.TrainStep(exchange=...), bench.py --dp-exchange) so the first real run can compare them."""
+        if exchange not in self.EXCHANGE_MODES:
+            raise ValueError(f'exchange must be one of {self.EXCHANGE_MODES}, got {exchange!r}')
+        self.exchange = exchange
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -56,14 +71,27 @@ class GradBucketReducer:
             self._count[self._bucket_of[p]] += 1
         self._works = []
         self.overlap = overlap and (self.world > 1 or self.force)
-        self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == 'cuda') else None
+        self._comm_stream = None        # created on first use (never for the stream-ordered modes: a torch pool stream would be a
+                                        # stream outside ops.stream_plan())
+        self._dev = dev
         # RCCL: the bucket all-reduces are issued as stream-ordered collectives (async_op=False: the process group enqueues them on
-        # the CURRENT stream, no stream of its own) on one of the weight-gradient streams the step already uses.  A stream of
+        # the CURRENT stream, no stream of its own) on one of the streams the step already uses.  A stream of
         # their own — the first design: `_comm_stream` + the process group's internal stream — makes a fifth / sixth busy stream,
         # which costs the step 10 ms on this part (profiles/r05_ab_runs.md: 74.0 against 63.2 ms with ONE rank's collectives
         # forced on; the same as a third weight-gradient stream or a stream for the gate).  Other backends (gloo: tests) keep the
         # asynchronous form.
-        self._stream_ordered = bool(dev.type == 'cuda' and dist.is_initialized() and dist.get_backend(process_group) == 'nccl')
+        nccl = bool(dev.type == 'cuda' and dist.is_initialized() and dist.get_backend(process_group) == 'nccl')
+        self._stream_ordered = nccl and exchange != 'comm'
+        if self._stream_ordered:
+            # "async_op=False runs on the current stream" is the behaviour of ProcessGroupNCCL since torch 2.8 (before, a
+            # synchronous collective still ran on the group's internal stream and the current stream waited for it: correct
+            # results, but the fifth stream is back).  Refuse silently-different behaviour.
+            ver = tuple(int(x) for x in torch.__version__.split('+')[0].split('.')[:2])
+            if ver < (2, 8):
+                raise RuntimeError(f"GradBucketReducer(exchange={exchange!r}) needs torch >= 2.8 (stream-ordered collectives with "
+                                   f"async_op=False); this is torch {torch.__version__}: pass exchange='comm'")
+            from . import ops
+            ops.stream_plan(dev)            # the plan's streams exist before any capture / first backward
         self._hooks = []
         self._streams = [dict() for _ in self.buckets]      # per bucket: producer streams seen this step
         self.active = True                                   # False: gradient hooks are ignored (tests: un-reduced pass)
@@ -102,14 +130,16 @@ class GradBucketReducer:
         self.launch_log.append((b, where))
         if self._stream_ordered:
             from . import ops
-            cs = self._comm_stream = ops.exchange_stream()
+            cs = self._comm_stream = ops.exchange_stream() if self.exchange == 'wgrad' else ops.side_stream()
             cs.wait_stream(torch.cuda.current_stream())
             for st in self._streams[b].values():         # side streams that wrote into this bucket (wgrad queue, depth encoder)
                 if st.cuda_stream != cs.cuda_stream:
                     cs.wait_stream(st)
             with torch.cuda.stream(cs):
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
-        elif self._comm_stream is not None:
+        elif self._dev.type == 'cuda':
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self._dev)
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             for st in self._streams[b].values():         # side streams that wrote into this bucket (wgrad queue, depth encoder)
                 self._comm_stream.wait_stream(st)

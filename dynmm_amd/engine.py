@@ -282,15 +282,16 @@ class TrainStep:
 
     def __init__(self, model, class_weight, lr, momentum=0.9, weight_decay=1e-4, loss_ratio=0.0,
                  flop_budget=0.0, use_graph=False, bucket_mb=32.0, multi_stream=True, optimizer='SGD',
-                 overlap=True, fuse_tail=None, prepack=True):
+                 overlap=True, fuse_tail=None, prepack=True, exchange='wgrad'):
         self.model = model
+        ops.stream_plan(next(model.parameters()).device)      # the step's side streams exist before any capture
         self.cw = torch.as_tensor(class_weight, dtype=torch.float32, device=next(model.parameters()).device)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError('TrainStep: the model has no trainable parameter')
         trainable = [p for _, p in named]
         self.flatp = FlatParameters(trainable)
-        self.reducer = dp.GradBucketReducer(trainable, bucket_mb=bucket_mb, overlap=overlap and not use_graph)
+        self.reducer = dp.GradBucketReducer(trainable, bucket_mb=bucket_mb, overlap=overlap and not use_graph, exchange=exchange)
         groups = {'gate': [p for n, p in named if 'gate' in n], 'rest': [p for n, p in named if 'gate' not in n]}
         groups = {k: v for k, v in groups.items() if v}
         if optimizer == 'SGD':
@@ -312,6 +313,7 @@ class TrainStep:
         self.use_graph = use_graph
         self._graphs = {}      # key -> (graph, static inputs, static outputs, touched set, gate temperature)
         self.last = None       # dict of device tensors: losses[4], loss_flop, total
+        self.census = None     # {'streams': n, 'roles': [...]} of the last eager step / capture (ops.stream_census)
         self._touched = None
 
     # ------------------------------------------------------------------------------------------------
@@ -319,6 +321,7 @@ class TrainStep:
         dec = getattr(self.model, 'decoder', None) if self.fuse_tail else None
         with direct_gradients(self.multi_stream), self._prepacked():
             ops.touched_reset()
+            ops.stream_census_reset()
             self.reducer.zero()
             if dec is not None:
                 dec.defer_tail = True       # last up-sampling + full-resolution CE as one kernel pair (csrc/tail.hip)
@@ -343,6 +346,7 @@ class TrainStep:
             self.last['loss_flop'] = lf.detach()
             ops.join_async()
             self._touched = ops.touched_ids()
+            self.census = ops.stream_census(check=True)     # raises on a fifth busy stream (ops.MAX_BUSY_STREAMS)
 
     @contextlib.contextmanager
     def _prepacked(self):
@@ -437,11 +441,9 @@ class TrainStep:
         # snapshot BEFORE the side stream forks, so the warm-up cannot race the clones
         sd = {k: v.clone() for k, v in self.model.state_dict().items()}
         opt_state = [t.clone() for t in self.opt.state_tensors()]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):       # warm-up outside capture (allocator, lazy init)
-            self._body(*static)
-        torch.cuda.current_stream().wait_stream(side)
+        # warm-up outside capture (allocator, lazy init, weight registration) on the CALLER's stream: a stream created for it
+        # would be one outside ops.stream_plan()
+        self._body(*static)
 
         def restore():
             self.model.load_state_dict(sd)       # undo the BN running-stat updates of warm-up / capture

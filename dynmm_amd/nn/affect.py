@@ -331,11 +331,7 @@ class AffectTrainStep:
             static_in = [[x.clone() for x in inputs[0]], inputs[1]]
             static_y = target.clone()
             snap = [self.flatp.flat.clone()] + [t.clone() for t in self.opt.state_tensors()]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                    # warm-up outside capture (allocator, lazy init)
-                self._body(static_in, static_y)
-            torch.cuda.current_stream().wait_stream(side)
+            self._body(static_in, static_y)                  # warm-up outside capture (allocator, lazy init)
             self.flatp.flat.copy_(snap[0])                   # undo the warm-up's parameter update
             for t, c in zip(self.opt.state_tensors(), snap[1:]):
                 t.copy_(c)

@@ -61,10 +61,10 @@ class GlobalGate(nn.Module):
 def encoder_stage_pair(model, j, r_in, d_in):
     """Stage j of both encoders, the depth one on a second HIP stream so the kernels' ramp-up /
     store-burst / tail phases of the two independent chains overlap.  Autograd replays each backward
-    node on its forward stream, so the backward gets the same concurrency."""
-    if getattr(model, '_side', None) is None:
-        model._side = torch.cuda.Stream()
-    side = model._side
+    node on its forward stream, so the backward gets the same concurrency.  The stream is THE depth-encoder
+    stream of the device (ops.side_stream(): one per process and device, not one per model — round 5's
+    per-instance torch pool stream made every model after the first run 17 % slower, profiles/r06_stream_plan.md)."""
+    side = ops.side_stream()
     main = torch.cuda.current_stream()
     capturing = torch.cuda.is_current_stream_capturing()
     # (Round 5 measured letting the depth chain run a fusion AHEAD of the RGB chain — its stream waiting for `main` at stage 1 only,
@@ -171,7 +171,6 @@ class SkipGateESANet(nn.Module):
         # points).  Autograd replays each backward node on its forward stream, so the backward gets
         # the same concurrency.  Off by default until measured.
         self.dual_stream = False
-        self._side = None
         self.last_stage_batch = None      # depth-stage batch sizes of the last compacted forward
 
     # ---- caller protocol (train.py:141,190-197,284,351; eval.py:64-68) -------------------------

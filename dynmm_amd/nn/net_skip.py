@@ -89,7 +89,6 @@ class SkipESANet(nn.Module):
         # Exact up to fp32 rounding of the straight-through one-hots; never used when gradients are recorded.
         self.compact = True
         self.last_stage_batch = None
-        self._side = None
 
     # ---- caller protocol ------------------------------------------------------------------------
     def freeze(self):

@@ -24,7 +24,9 @@ def _stream():
     if not torch.cuda.is_available():
         raise L.DynmmHipError('no HIP device is available: the DynMM hot path runs only on its HIP kernels '
                               '(there is no CPU / eager-PyTorch fallback)')
-    return torch.cuda.current_stream().cuda_stream
+    h = torch.cuda.current_stream().cuda_stream
+    _CENSUS.add(h)
+    return h
 
 
 def _p(t):
@@ -125,60 +127,157 @@ ASYNC_WGRAD = False
 WGRAD_STREAMS = 2        # weight-gradient side streams.  With the null stream and the depth-encoder stream that makes the FOUR busy
                          # streams the runtime's hardware queues hold: a third one costs 10 ms per step (profiles/r05_ab_runs.md:
                          # 74.5 against 63.7 ms; one stream: 64.6)
-_WGRAD_POOL = []
 _WGRAD_RR = [0]
 _INFLIGHT = []
 
 
+# ---- the stream plan: a PROCESS-WIDE invariant ----------------------------------------------------------------------------------
+# The optimisation step runs on FOUR busy streams per device: the caller's stream (torch's current stream), ONE depth-encoder
+# stream and WGRAD_STREAMS = 2 weight-gradient streams of the least priority.  A fifth busy stream costs the step ~10 ms whatever
+# runs on it (profiles/r05_ab_runs.md, five sightings), and round 5's per-model-instance depth stream (`torch.cuda.Stream()` = the
+# NEXT stream of torch's round-robin pool for every model built in a process) made the second, third ... model of a process run
+# 17 % slower than the first (profiles/r06_stream_plan.md holds the experiment).  So the streams are created
+# ONCE per device, through the runtime (never from torch's pool), in a fixed order, and every user — nn/net.py encoder_stage_pair,
+# the weight-gradient queues, dp.GradBucketReducer's exchange, engine.TrainStep's capture warm-up — takes them from here.
+MAX_BUSY_STREAMS = 4
+_PLANS = {}                    # device index -> _StreamPlan
 _HIP_RT = []
-_LOW_PRIORITY_HANDLES = []     # (the runtime streams behind the ExternalStream objects: never destroyed, the pool lives as long as the process)
+_CENSUS = set()                # stream handles kernels were enqueued on since stream_census_reset()
+
+
+def _hip_runtime():
+    """the HIP runtime ALREADY mapped in this process (torch's), by its path: a bare dlopen('libamdhip64.so') could bring a second
+    runtime in, whose streams mean nothing to the first.  None when that is ambiguous."""
+    if not _HIP_RT:
+        mapped = sorted(L._mapped_hip_runtimes())
+        hip = C.CDLL(mapped[0]) if len(mapped) == 1 else None
+        if hip is not None:
+            hip.hipDeviceGetStreamPriorityRange.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            hip.hipDeviceGetStreamPriorityRange.restype = C.c_int
+            hip.hipStreamCreateWithPriority.argtypes = [C.POINTER(C.c_void_p), C.c_uint, C.c_int]
+            hip.hipStreamCreateWithPriority.restype = C.c_int
+            hip.hipStreamGetPriority.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            hip.hipStreamGetPriority.restype = C.c_int
+        _HIP_RT.append(hip)
+    return _HIP_RT[0]
+
+
+def _runtime_stream(device, least_priority):
+    """A non-blocking HIP stream on `device` created through the runtime and wrapped (torch.cuda.ExternalStream): of the LEAST
+    priority the device offers (torch.cuda.Stream reaches only normal and high, priority <= 0) or of the normal one.  Falls back
+    to a torch pool stream only when the runtime cannot be reached.  Never destroyed: the plan lives as long as the process."""
+    hip = _hip_runtime()
+    with torch.cuda.device(device):
+        torch.cuda.current_stream()                 # (makes sure the device context exists)
+        if hip is None:
+            return torch.cuda.Stream(device=device), None
+        prio = 0
+        if least_priority:
+            least, greatest = C.c_int(0), C.c_int(0)
+            if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value <= 0:
+                return torch.cuda.Stream(device=device), None      # no priority below normal on this device
+            prio = least.value
+        h = C.c_void_p()
+        if hip.hipStreamCreateWithPriority(C.byref(h), 1, prio) != 0 or not h.value:      # 1 = hipStreamNonBlocking
+            return torch.cuda.Stream(device=device), None
+        return torch.cuda.ExternalStream(h.value, device=device), h
+
+
+class _StreamPlan:
+    def __init__(self, device):
+        if torch.cuda.is_current_stream_capturing():
+            raise L.DynmmHipError('the stream plan must exist before a stream capture starts (hipStreamCreate is not '
+                                  'capturable): build engine.TrainStep / call ops.stream_plan() first')
+        self.device = device
+        self.handles = []              # the runtime streams behind the ExternalStream objects (kept: never destroyed)
+        self.side = self._make(False)
+        self.wgrad = [self._make(True) for _ in range(max(1, WGRAD_STREAMS))]
+
+    def _make(self, least_priority):
+        s, h = _runtime_stream(self.device, least_priority)
+        if h is not None:
+            self.handles.append(h)
+        return s
+
+    def grow(self):
+        while len(self.wgrad) < max(1, WGRAD_STREAMS):
+            self.wgrad.append(self._make(True))
+
+    def streams(self):
+        return [self.side] + self.wgrad[:max(1, WGRAD_STREAMS)]
+
+
+def stream_plan(device=None):
+    """The side streams of `device` (default: the current one), created on first call.  engine.TrainStep and the data-parallel
+    reducer call this in their constructors, i.e. before any capture."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    plan = _PLANS.get(dev)
+    if plan is None:
+        plan = _PLANS[dev] = _StreamPlan(dev)
+    elif len(plan.wgrad) < max(1, WGRAD_STREAMS):
+        plan.grow()
+    return plan
 
 
 def low_priority_stream():
-    """A HIP stream of the LEAST priority the device offers.  torch.cuda.Stream reaches only the normal and the high priority
-    (priority <= 0), so this one is created through the runtime and wrapped (torch.cuda.ExternalStream).  Used for the
-    weight-gradient streams: their launches fill the matrix pipe behind the backward's dependent chain (input gradient ->
-    BatchNorm backward -> input gradient), whose workgroups the dispatcher now takes first — 7 alternating pairs of runs on one
-    box: -0.18 ms per step on average, never slower (round 5; the opposite, high-priority chains, cost +0.75 ms in round 3)."""
-    if not _HIP_RT:
-        # the runtime that is ALREADY mapped in this process (torch's), by its path: a bare dlopen('libamdhip64.so') could bring a
-        # second runtime in, whose streams mean nothing to the first
-        mapped = sorted(L._mapped_hip_runtimes())
-        _HIP_RT.append(C.CDLL(mapped[0]) if len(mapped) == 1 else None)
-    hip = _HIP_RT[0]
-    if hip is None:
-        return torch.cuda.Stream()
-    torch.cuda.current_stream()                     # (makes sure the device context exists)
-    least, greatest = C.c_int(0), C.c_int(0)
-    if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value <= 0:
-        return torch.cuda.Stream()                  # no priority below normal on this device
-    h = C.c_void_p()
-    if hip.hipStreamCreateWithPriority(C.byref(h), 1, least.value) != 0 or not h.value:      # 1 = hipStreamNonBlocking
-        return torch.cuda.Stream()
-    _LOW_PRIORITY_HANDLES.append(h)
-    return torch.cuda.ExternalStream(h.value)
+    """A NEW stream of the least priority the device offers (tests / experiments; the step takes its streams from stream_plan()).
+    Weight-gradient launches fill the matrix pipe behind the backward's dependent chain (input gradient -> BatchNorm backward ->
+    input gradient), whose workgroups the dispatcher takes first — 7 alternating pairs of runs on one box: -0.18 ms per step on
+    average, never slower (round 5; the opposite, high-priority chains, cost +0.75 ms in round 3)."""
+    s, h = _runtime_stream(torch.cuda.current_device(), True)
+    if h is not None:
+        stream_plan().handles.append(h)
+    return s
+
+
+def side_stream():
+    """THE depth-encoder stream of the current device (normal priority)."""
+    return stream_plan().side
 
 
 def _wgrad_stream():
-    while len(_WGRAD_POOL) < max(1, WGRAD_STREAMS):
-        _WGRAD_POOL.append(low_priority_stream())
+    pool = stream_plan().wgrad
     _WGRAD_RR[0] = (_WGRAD_RR[0] + 1) % max(1, WGRAD_STREAMS)
-    return _WGRAD_POOL[_WGRAD_RR[0]]
+    return pool[_WGRAD_RR[0]]
 
 
 def exchange_stream():
     """The stream the data-parallel gradient exchange is enqueued on (dp.GradBucketReducer): the LAST weight-gradient stream —
-    not a stream of its own, see WGRAD_STREAMS."""
-    while len(_WGRAD_POOL) < max(1, WGRAD_STREAMS):
-        _WGRAD_POOL.append(low_priority_stream())
-    return _WGRAD_POOL[-1]
+    not a stream of its own, see MAX_BUSY_STREAMS."""
+    return stream_plan().wgrad[max(1, WGRAD_STREAMS) - 1]
+
+
+def stream_census_reset():
+    _CENSUS.clear()
+
+
+def busy_streams():
+    """Handles of the streams this library's launches were enqueued on since stream_census_reset() (every launch takes its
+    stream from _stream() or from the plan)."""
+    return set(_CENSUS)
+
+
+def stream_census(check=True):
+    """{'streams': n, 'roles': [...]} of the launches since stream_census_reset(); raises when the step went beyond
+    MAX_BUSY_STREAMS (a stream outside the plan: some caller created one of its own)."""
+    plan = stream_plan()
+    names = {plan.side.cuda_stream: 'depth'}
+    for i, s in enumerate(plan.wgrad):
+        names[s.cuda_stream] = f'wgrad{i}'
+    roles = sorted(names.get(h, 'caller' if h == torch.cuda.current_stream().cuda_stream else f'other:{h:#x}') for h in _CENSUS)
+    if check and len(_CENSUS) > MAX_BUSY_STREAMS:
+        raise L.DynmmHipError(f'this step enqueued work on {len(_CENSUS)} streams ({roles}); the schedule holds '
+                              f'{MAX_BUSY_STREAMS} (ops.stream_plan): a further busy stream costs it ~10 ms')
+    return {'streams': len(_CENSUS), 'roles': roles}
 
 
 def join_async():
     flush_wgrad_groups()
     if _INFLIGHT:
         cur = torch.cuda.current_stream()
-        for s in _WGRAD_POOL:
+        for s in stream_plan().wgrad:
             cur.wait_stream(s)
     _INFLIGHT.clear()
 
@@ -248,6 +347,7 @@ def _flush_wgrad_queue(key):
     dws = [_grad_dst(item[3])[0] for item in q]
     dbs = [_grad_dst(item[4])[0] for item in q] if q[0][4] is not None else None
     nbytes = lib.dynmm_conv2d_wgrad_group_workspace_bytes(C.byref(g), n)
+    _CENSUS.add(stream.cuda_stream)
     with torch.cuda.stream(stream):
         ws = torch.empty(max(nbytes // 4, 1), device=q[0][1].device, dtype=torch.float32)
         xs = (C.c_void_p * n)(*[item[1].data_ptr() for item in q])
@@ -804,6 +904,7 @@ class _Conv2d(Function):
             nbytes = lib.dynmm_conv2d_wgrad_workspace_bytes(C.byref(g))
             if ASYNC_WGRAD and dw_ret is None and PROFILE is None:
                 ws_stream = _wgrad_stream()
+                _CENSUS.add(ws_stream.cuda_stream)
                 ws_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(ws_stream):
                     ws = torch.empty(max(nbytes // 4, 1), device=gy.device, dtype=torch.float32)

@@ -130,19 +130,29 @@ def _rccl_worker(port, q):
     m.temp, m.hard_gate = 1.0, False
     rgb, depth = synth.synth_inputs(n, h, w, seed=100, device='cuda')
     labels = [synth.synth_labels(n, h // s, w // s, seed=300 + s, device='cuda').to(torch.uint8) for s in (1, 8, 16, 32)]
-    step = engine.TrainStep(m, np.linspace(0.5, 2.0, 40), lr=0.01, loss_ratio=0.1, bucket_mb=8.0, overlap=True)
-    red = step.reducer
-    assert red.force and red.overlap           # a 1-rank reducer normally skips the collectives: forced through RCCL here
-    step._body(rgb, depth, labels)
-    launched = red.launched_in_backward
-    red.finish()
-    torch.cuda.synchronize()
-    flat = red.flat.clone()
-    # the exchange is stream-ordered on one of the step's own streams (a fifth busy stream costs the step 10 ms: dp.py)
     from dynmm_amd import ops
-    assert red._stream_ordered and red._comm_stream.cuda_stream == ops.exchange_stream().cuda_stream
-    assert red._comm_stream.cuda_stream in [s_.cuda_stream for s_ in ops._WGRAD_POOL] and not red._works
-    q.put(('ok', launched, len(red.buckets), bool(torch.isfinite(flat).all().item()), float(flat.abs().sum().item())))
+    out = []
+    for mode in ('wgrad', 'depth', 'comm'):    # dp.GradBucketReducer(exchange=...): where the all-reduces are enqueued
+        step = engine.TrainStep(m, np.linspace(0.5, 2.0, 40), lr=0.01, loss_ratio=0.1, bucket_mb=8.0, overlap=True, exchange=mode)
+        red = step.reducer
+        assert red.force and red.overlap       # a 1-rank reducer normally skips the collectives: forced through RCCL here
+        step._body(rgb, depth, labels)
+        launched = red.launched_in_backward
+        red.finish()
+        torch.cuda.synchronize()
+        flat = red.flat.clone()
+        plan = {'wgrad': ops.exchange_stream(), 'depth': ops.side_stream()}
+        if mode == 'comm':                     # the classic arrangement: asynchronous work objects from a stream of its own
+            assert not red._stream_ordered
+            assert red._comm_stream.cuda_stream not in {s_.cuda_stream for s_ in ops.stream_plan().streams()}
+        else:
+            # stream-ordered on one of the step's own streams (a fifth busy stream costs the step 10 ms: dp.py), no work objects,
+            # and the step stayed inside the four-stream plan
+            assert red._stream_ordered and red._comm_stream.cuda_stream == plan[mode].cuda_stream and not red._works
+            assert step.census['streams'] <= ops.MAX_BUSY_STREAMS, step.census
+        out.append((mode, launched, len(red.buckets), bool(torch.isfinite(flat).all().item()), float(flat.abs().sum().item())))
+        red.remove_hooks()
+    q.put(('ok', out))
     dist.destroy_process_group()
 
 
@@ -155,9 +165,12 @@ def test_bucket_allreduce_over_rccl_single_rank():
     p.join(60)
     if res[0] == 'skip':
         pytest.skip(f'RCCL process group unavailable: {res[1]}')
-    _, launched, nb, finite, mass = res
-    assert launched == nb and nb >= 4          # every bucket's all-reduce went out during backward, through RCCL
-    assert finite and mass > 0
+    masses = []
+    for mode, launched, nb, finite, mass in res[1]:
+        assert launched == nb and nb >= 4, mode          # every bucket's all-reduce went out during backward, through RCCL
+        assert finite and mass > 0, mode
+        masses.append(mass)
+    assert max(masses) - min(masses) <= 1e-5 * max(masses), masses   # the same gradients whatever stream carried the exchange
 
 
 def _eval_worker(rank, world, port, q):

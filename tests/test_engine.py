@@ -544,3 +544,58 @@ def test_legacy_flat_optimizer_checkpoints_load_into_the_right_buffers():
     sgd = engine.SGDNesterov(fp, grads, lr=1e-3)
     sgd.load_state_dict({'momentum_buffer': torch.arange(11.0) * 3, 'steps': torch.tensor([2], dtype=torch.int32)})
     assert torch.equal(sgd.buf, torch.arange(11.0) * 3) and int(sgd.steps[0]) == 2
+
+
+@pytest.mark.gpu
+def test_stream_plan_is_process_wide_three_models_in_sequence():
+    """the step's side streams are ONE plan per process and device (ops.stream_plan) — the second and third model
+    built in a process run on the same four streams as the first and take the same time (round 5: a per-instance torch pool
+    stream for the depth encoder made every later model 17 % slower at BASELINE configs[2]'s size), and a caller that brings a
+    fifth stream is refused."""
+    import time
+    from dynmm_amd import engine, ops
+    from dynmm_amd.nn.net import SkipGateESANet
+    dev = torch.device('cuda:0')
+    n, h, w = 32, 480, 640
+    g = torch.Generator().manual_seed(7)
+    rgb, depth = torch.randn(n, 3, h, w, generator=g).to(dev), torch.randn(n, 1, h, w, generator=g).to(dev)
+    labels = [torch.randint(0, 41, (n, h // s, w // s), generator=g, dtype=torch.uint8).to(dev) for s in (1, 8, 16, 32)]
+    plan = ops.stream_plan()
+    expect = {torch.cuda.current_stream().cuda_stream, plan.side.cuda_stream} | {s.cuda_stream for s in plan.wgrad[:ops.WGRAD_STREAMS]}
+    times = []
+    for i in range(3):
+        m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+        synth.fill_state_dict(m.state_dict(), seed=i)
+        m = m.to(dev).train()
+        m.temp, m.hard_gate = 1.0, bool(i == 1)             # the second one runs configs[3]'s dense hard-gate step
+        ts = engine.TrainStep(m, np.linspace(0.5, 2.0, 40), lr=1e-4, loss_ratio=1.0)
+        for _ in range(3):
+            ts(rgb, depth, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            ts(rgb, depth, labels)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 6 * 1e3)
+        assert ts.census['streams'] == ops.MAX_BUSY_STREAMS == 4, ts.census
+        assert ops.busy_streams() == expect, (ops.busy_streams(), expect)
+        assert ops.stream_plan() is plan
+        if i == 2:                                          # a stream of the caller's own beside the plan: refused, loudly
+            extra = torch.cuda.Stream()
+
+            def fifth(module, args):
+                extra.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(extra):
+                    ops.adaptive_avg_pool(args[1], 1)       # any launch of the library on a stream outside the plan
+            hook = m.register_forward_pre_hook(fifth)
+            try:
+                with pytest.raises(Exception, match='enqueued work on 5 streams'):
+                    ts._body(rgb, depth, labels)
+            finally:
+                hook.remove()
+                ops.flush_wgrad_groups()
+                torch.cuda.synchronize()
+        ts.reducer.remove_hooks()
+        del m, ts
+        torch.cuda.empty_cache()
+    assert max(times) / min(times) < 1.03, times

@@ -1134,7 +1134,8 @@ def test_stem_bn_fuse_pool_equals_unfused_ops(ops, use_se):
 
 
 def test_weight_gradient_streams_have_least_priority(ops):
-    """ops.low_priority_stream / the weight-gradient pool: streams of the least priority the device offers (created through the
+    """ops.stream_plan(): weight-gradient streams of the least priority the device offers, a depth-encoder stream of the normal one,
+    the SAME objects on every call (process-wide singletons; created through the
     runtime, wrapped as torch streams), usable like any torch stream (event ordering against the current stream)."""
     import ctypes as C
     from dynmm_amd import lib as L
@@ -1143,24 +1144,27 @@ def test_weight_gradient_streams_have_least_priority(ops):
     hip = C.CDLL(mapped[0])                     # the runtime of this process (torch's)
     least, greatest = C.c_int(0), C.c_int(0)
     assert hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0
-    old = list(ops._WGRAD_POOL)
-    ops._WGRAD_POOL.clear()
-    try:
-        streams = [ops._wgrad_stream() for _ in range(ops.WGRAD_STREAMS)]
-        assert len({s.cuda_stream for s in streams}) == ops.WGRAD_STREAMS
-        for s in streams:
-            got = C.c_int(-99)
-            assert hip.hipStreamGetPriority(C.c_void_p(s.cuda_stream), C.byref(got)) == 0
-            assert got.value == max(least.value, 0), (got.value, least.value, greatest.value)
-        a = rnd(1 << 20, seed=1).cuda()
-        s = streams[0]
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            b = a * 2.0
-        torch.cuda.current_stream().wait_stream(s)
-        assert torch.equal(b, a + a)
-    finally:
-        ops._WGRAD_POOL[:] = old
+    streams = [ops._wgrad_stream() for _ in range(ops.WGRAD_STREAMS)]
+    assert len({s.cuda_stream for s in streams}) == ops.WGRAD_STREAMS
+    for s in streams:
+        got = C.c_int(-99)
+        assert hip.hipStreamGetPriority(C.c_void_p(s.cuda_stream), C.byref(got)) == 0
+        assert got.value == max(least.value, 0), (got.value, least.value, greatest.value)
+    plan = ops.stream_plan()
+    assert ops.stream_plan() is plan and ops.side_stream() is plan.side           # singletons
+    assert {s.cuda_stream for s in streams} == {s.cuda_stream for s in plan.wgrad[:ops.WGRAD_STREAMS]}
+    assert ops.exchange_stream() is plan.wgrad[ops.WGRAD_STREAMS - 1]
+    got = C.c_int(-99)
+    assert hip.hipStreamGetPriority(C.c_void_p(plan.side.cuda_stream), C.byref(got)) == 0 and got.value == 0, got.value
+    handles = {plan.side.cuda_stream} | {s.cuda_stream for s in plan.wgrad}
+    assert len(handles) == 1 + len(plan.wgrad) and 0 not in handles and torch.cuda.current_stream().cuda_stream not in handles
+    a = rnd(1 << 20, seed=1).cuda()
+    s = streams[0]
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b = a * 2.0
+    torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(b, a + a)
 
 
 @pytest.mark.parametrize('case', [(4, 128, 24, 32, 128, (3, 1), (1, 0), True),      # three-tap kernel, vertical taps
