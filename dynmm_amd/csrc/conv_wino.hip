@@ -88,7 +88,10 @@ __device__ __forceinline__ float quad_sum(float v) {            // sum over the 
 // the direct work; since round 5 they run on the 2-D form F(2x2,3x3) of conv_wino2d.hip at 4/9, and this kernel carries none
 // of the tap bookkeeping: no zero slot in LDS, no row bits, a loader whose addresses advance by constant strides.)
 template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, int BNRED = 0>
-__global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const WinoArgs a) {
+#ifndef DYNMM_WINO_VOCC
+#define DYNMM_WINO_VOCC 3
+#endif
+__global__ void __launch_bounds__(256, MCO == 1 ? ((VERT && !S2) ? DYNMM_WINO_VOCC : 3) : 2) conv_wino_kernel(const WinoArgs a) {
     static_assert(!BNRED || (DGRAD && VERT && !S2 && MCO == 1 && TCO == 64 && !TAIL && !STATS), "BatchNorm reductions: vertical dgrad");
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
     static_assert(!STATS || (!DGRAD && !VERT && MCO == 1 && TCO == 64 && !TAIL), "statistics: the forward's small horizontal tile");
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     // MCO: 32-channel blocks per wave.  2: a wave owns 64 co x 32 pairs x 4 transforms (128 accumulator registers, two
     // workgroups per CU); 1: 32 co x 32 pairs x 4 (64 registers, three workgroups per CU: smaller tiles for the grids a
     // 8192-accumulator tile quantises badly, and a third neighbour to cover a workgroup's prologue / epilogue)
-    constexpr int BK = 8, S = 3;
+    constexpr int BK = 8, S = (VERT && !S2 && MCO == 1 && DYNMM_WINO_VOCC == 4) ? 2 : 3;
     constexpr int WCO = 32 * MCO;
     constexpr int WAVES_CO = TCO / WCO, WAVES_P = 4 / WAVES_CO, TP = 32 * WAVES_P;
     static_assert(WAVES_CO * WAVES_P == 4 && (MCO == 1 || MCO == 2), "4 waves per workgroup");
@@ -298,10 +301,9 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
     // passes the barrier (every wave has the last fragments of stage s in registers: its slot is free), requests stage s + 3
     // into that slot and reads the first fragments of stage s + 1, all under the last 8 MFMAs of stage s.
     static_assert(BK == 8, "four k-pairs per stage");
-    issue();
-    issue();
-    issue();
-    wait_vm<2 * NI>();                            // (nst >= 3: the launcher requires >= 24 reduction channels)
+#pragma unroll
+    for (int i = 0; i < S; ++i) issue();
+    wait_vm<(S - 1) * NI>();                      // (nst >= 3: the launcher requires >= 24 reduction channels)
     __syncthreads();
     int c_a = 0, c_b = 0;                         // ring offsets (floats) of the stage being consumed
     const float* Ap = As;
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(256, MCO == 1 ? 3 : 2) conv_wino_kernel(const 
         transform(1);
         DYNMM_WINO_PHASE();
         if (s + 1 < nst) {
-            if (s + 2 < nst) wait_vm<NI>();
+            if (S > 2 && s + 2 < nst) wait_vm<(S - 2) * NI>();
             else wait_vm<0>();
             __syncthreads();
             issue();

@@ -41,8 +41,12 @@ struct Wino43Args {
     int n_co_tiles, n_q_tiles;
 };
 
-__global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a) {
-    constexpr int BK = 8, S = 3, TCO = 64, TQ = 64, NT = 6;
+#ifndef DYNMM_W43_WG
+#define DYNMM_W43_WG 3
+#endif
+__global__ void __launch_bounds__(256, DYNMM_W43_WG) conv_wino43_kernel(const Wino43Args a) {
+    constexpr int WG = DYNMM_W43_WG;
+    constexpr int BK = 8, S = WG == 3 ? 2 : 3, TCO = 64, TQ = 64, NT = 6;
     constexpr int A4_STAGE = BK * TCO * 4, A2_STAGE = BK * TCO * 2;         // floats
     constexpr int PIXW = 4 * TQ + 8;
     constexpr int B_STAGE = BK * PIXW;
@@ -151,12 +155,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-    // The halo values d0 / d5 of a quad are element 3 / element 0 of the NEIGHBOURING lanes' quads: they come by a register
-    // exchange (v_mov_b32 dpp wave_shr:1 / wave_shl:1), not from LDS — as two ds_read_b32 at a 16-byte lane stride they were 4-way
-    // bank conflicts (bank = (a / 4) mod 32: 8 banks for 32 lanes), 16 LDS cycles per k-pair beside the 4 of the quad's own
-    // ds_read_b128 (round 5: conflict cycles 0.60 of the LDS-active ones).  Only the first / last lane of a wave's 32 quads has
-    // no neighbour in the wave (the other wave's quad or the tile halo): ONE ds_read_b32 per k-pair serves both, every other
-    // lane reading lane 0's address (a broadcast) — 2 LDS cycles.
+#ifndef DYNMM_W43_DPP
+#define DYNMM_W43_DPP 0
+#endif
+    // The halo values d0 / d5 of a quad are element 3 / element 0 of the NEIGHBOURING lanes' quads.  As two ds_read_b32 at a
+    // 16-byte lane stride they are 4-way bank conflicts (bank = (a / 4) mod 32: 8 banks for 32 lanes; round 5 counted 0.60 of this
+    // kernel's LDS-active cycles as conflict cycles).  DYNMM_W43_DPP = 1 fetches them by a register exchange instead (v_mov_b32
+    // dpp wave_shr:1 / wave_shl:1; the first / last lane of a wave's 32 quads, whose neighbour is the other wave's quad or the
+    // tile halo, by ONE ds_read_b32 in which every other lane reads lane 0's address): 2 LDS cycles for 16, bit-identical results —
+    // and 2 .. 9 % SLOWER at every large shape (round 6, scratch/r6/w43_time.py: 88.4 -> 90.0 us at C = 128, 92.7 -> 97.0 at 256,
+    // with mask + accum 124.9 -> 133.9 / 104.6 -> 115.0; the same exchange in the F(2,3) pair kernel: +3 .. +8 %): the LDS is 15 -
+    // 25 % busy either way, while the two DPP moves, two selects and their wait states land in the transform phase, the one
+    // stretch of a k-pair in which the wave has no MFMA queued.  What the conflicts cost is LDS cycles nobody was waiting for.
+    // Left in as a compile-time option, off.
     const bool edge_lo = l31 == 0, edge_hi = l31 == 31;
     const int e_frag = khalf * PIXW + (edge_hi ? 4 * lq + 8 : 4 * (wave_q * 32) + 3);
     float4 fa4[2];
@@ -167,12 +178,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         fa2[set] = *reinterpret_cast<const float2*>(A2p + a2_frag + 2 * q * TCO * 2);
         const float* b = Bp + b_frag + 2 * q * PIXW;
         const float4 u = *reinterpret_cast<const float4*>(b + 1);
-        fd[set][0] = Bp[e_frag + 2 * q * PIXW];      // the edge lanes' halo value (d0 of lane 0, d5 of lane 31)
         fd[set][1] = u.x; fd[set][2] = u.y; fd[set][3] = u.z; fd[set][4] = u.w;
+        if constexpr (DYNMM_W43_DPP) {
+            fd[set][0] = Bp[e_frag + 2 * q * PIXW];      // the edge lanes' halo value (d0 of lane 0, d5 of lane 31)
+        } else {
+            fd[set][0] = b[0];
+            fd[set][5] = b[5];
+        }
     };
     auto transform = [&](int set) {
         float d[6];
-        {
+        if constexpr (DYNMM_W43_DPP) {
             const float edge = fd[set][0];
             const float lo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, fd[set][4]), 0x138, 0xf, 0xf, false));   // wave_shr:1
             const float hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, fd[set][1]), 0x130, 0xf, 0xf, false));   // wave_shl:1
@@ -198,10 +214,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
 #define DYNMM_W43_PHASE() __builtin_amdgcn_sched_barrier(0)
 
     // ---------------------------------------------------------------- K loop (conv_wino.hip's)
-    issue();
-    issue();
-    issue();
-    wait_vm<2 * NI>();
+#pragma unroll
+    for (int i = 0; i < S; ++i) issue();
+    wait_vm<(S - 1) * NI>();
     __syncthreads();
     int c_a4 = 0, c_a2 = 0, c_b = 0;              // ring offsets (floats) of the stage being consumed
     const float* A4p = A4s;
@@ -230,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
         transform(1);
         DYNMM_W43_PHASE();
         if (s + 1 < nst) {
-            if (s + 2 < nst) wait_vm<NI>();
+            if (S > 2 && s + 2 < nst) wait_vm<(S - 2) * NI>();
             else wait_vm<0>();
             __syncthreads();
             issue();
@@ -260,14 +275,18 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     auto off_of = [&](int b, int e) {            // batch b: channels 8 b + 4 khalf + e, e = 0..3
         return off_base + (unsigned)(8 * b + e) * row_bytes;
     };
-    float kk[2][4][4], rr[2][4][4];               // [set][channel e][output j]
+    constexpr int NS = WG == 3 ? 1 : 2;           // epilogue operand sets: double-buffered at two workgroups per CU; at three the
+                                                  // register budget (168) has room for one and the third workgroup covers the loads
+    float kk[NS][4][4], rr[NS][4][4];             // [set][channel e][output j]
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int z = 0; z < NS; ++z)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kk[0][e][j] = kk[1][e][j] = 1.f;
-            rr[0][e][j] = rr[1][e][j] = 0.f;
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kk[z][e][j] = 1.f;
+                rr[z][e][j] = 0.f;
+            }
     auto load_batch = [&](int set, int b) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -287,8 +306,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino43_kernel(const Wino43Args a)
     if (!qvalid) return;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int set = b & 1;
-        if (b + 1 < 4 && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        const int set = NS == 2 ? (b & 1) : 0;
+        if (NS == 2 && b + 1 < 4 && (has_mask || has_res)) load_batch(set ^ 1, b + 1);
+        if (NS == 1 && b > 0 && (has_mask || has_res)) load_batch(0, b);
         float yo[4][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -461,12 +461,142 @@ class TrainStep:
         return graph, static, self.last, self._touched
 
 
+class InferStep:
+    """The inference forward (eval.py:107-115; …globalgate.py:255-322 with `test=True`) as hipGraph replays — BASELINE configs[1]
+    enqueues ~400 launches for 10 ms of kernels, so the eager forward runs at the speed of the host's Python (1160 … 1590 img/s
+    on the boxes of round 5); a replay costs one launch.
+
+    `step(rgb, depth, return_weight=False)` returns what `model(rgb, depth, test=True[, return_weight=True])` returns under
+    `torch.no_grad()` in eval mode — bit-identical (tests/test_engine.py) — as STATIC tensors: valid until the next call.
+
+    Two graphs per forward of a gated model (nn/net.py forward_front / forward_back): the front (stems, stem fusion, gate head,
+    device side of the compaction decision) and, after the ONE 16-byte host read a compacted hard-gate forward needs
+    (`stage_counts`; none when the host knows the branches: `baseline`, `branch_override`), the back for exactly those stage
+    counts.  Back graphs are captured on the `capture_after`-th sighting of a count tuple (an eager `forward_back` serves the
+    others) and kept in an LRU of MAX_GRAPHS.  Everything that feeds a capture is part of its key: input shapes, the gate flags
+    and temperature, `compact`, `dual_stream`, the injected branches — and a stamp over the version counters of every parameter
+    and buffer plus ops' mutation generation, because the folded BatchNorm factors / packed filters a capture reads are the
+    cached ones (ops.conv2d_fused_eval) and must die with the weights they were made from.
+    Eager fallbacks: `ini_stage` (branches drawn with the host RNG per call), a training-mode model, models without a
+    front / back split that take host decisions (SkipESANet's per-stage gates); a model without gates (the static ESANet) is
+    one graph."""
+
+    MAX_GRAPHS = 8
+
+    def __init__(self, model, capture_after=2):
+        self.model = model
+        self.capture_after = int(capture_after)
+        dev = next(model.parameters()).device
+        ops.stream_plan(dev)                          # the side streams exist before any capture
+        self._pool = torch.cuda.graph_pool_handle()
+        self._front = {}                              # key -> (graph, static rgb, static depth, front state | outputs)
+        self._back = {}                               # key + counts -> (graph, outputs)            (dict order = LRU order)
+        self._seen = {}
+        self._stamp = None
+        self.replays = {'front': 0, 'back': 0, 'eager_back': 0, 'eager': 0, 'captures': 0}
+        self.launch = 'eager'                         # what the last call did: 'hipGraph replay' | 'eager' | 'hipGraph front + eager back'
+
+    # ---- validity -------------------------------------------------------------------------------
+    def _weights_stamp(self):
+        m = self.model
+        return (ops._MUTATION_GEN[0],) + tuple(t._version for t in m.parameters()) + tuple(t._version for t in m.buffers())
+
+    def reset(self):
+        for g in list(self._front.values()) + list(self._back.values()):
+            g[0].reset()
+        self._front.clear()
+        self._back.clear()
+        self._seen.clear()
+
+    def _key(self, rgb, depth):
+        m = self.model
+        bo = getattr(m, 'branch_override', None)
+        return (tuple(rgb.shape), tuple(depth.shape), bool(getattr(m, 'baseline', False)), bool(getattr(m, 'hard_gate', False)),
+                float(getattr(m, 'temp', 0.0)), bool(getattr(m, 'compact', False)), bool(getattr(m, 'dual_stream', False)),
+                None if bo is None else tuple(int(v) for v in bo))
+
+    def _eager(self, rgb, depth, return_weight):
+        self.replays['eager'] += 1
+        self.launch = 'eager'
+        m = self.model
+        if hasattr(m, 'hard_gate') or hasattr(m, 'block_rule'):
+            return m(rgb, depth, True, True) if return_weight else m(rgb, depth, True)
+        return m(rgb, depth)
+
+    def _capture(self, fn):
+        """fn() once eagerly (allocator, lazy initialisation, the inference caches of ops.conv2d_fused_eval), then captured."""
+        keep = fn()
+        torch.cuda.current_stream().synchronize()
+        del keep
+        graph = torch.cuda.CUDAGraph()
+        saved, ops.CAPTURE_EVAL_CACHE = ops.CAPTURE_EVAL_CACHE, True
+        try:
+            with ops.capture_scope(), torch.cuda.graph(graph, pool=self._pool):
+                out = fn()
+        finally:
+            ops.CAPTURE_EVAL_CACHE = saved
+        self.replays['captures'] += 1
+        return graph, out
+
+    # ---- call -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, rgb, depth, return_weight=False):
+        m = self.model
+        gated = hasattr(m, 'forward_front')
+        host_decisions = getattr(m, 'ini_stage', False) or (not gated and (hasattr(m, 'hard_gate') or hasattr(m, 'block_rule')))
+        if m.training or host_decisions:
+            return self._eager(rgb, depth, return_weight)
+        stamp = self._weights_stamp()
+        if stamp != self._stamp:
+            self.reset()
+            self._stamp = stamp
+        key = self._key(rgb, depth)
+        fe = self._front.get(key)
+        if fe is None:
+            s_rgb, s_depth = rgb.clone(), depth.clone()
+            if gated:
+                graph, st = self._capture(lambda: m.forward_front(s_rgb, s_depth))
+            else:
+                graph, st = self._capture(lambda: m(s_rgb, s_depth))
+            fe = self._front[key] = (graph, s_rgb, s_depth, st)
+        graph, s_rgb, s_depth, st = fe
+        s_rgb.copy_(rgb)
+        s_depth.copy_(depth)
+        graph.replay()
+        self.replays['front'] += 1
+        self.launch = 'hipGraph replay'
+        if not gated:
+            return st
+        if getattr(m, 'save_weight_info', False):
+            m.weight_list = torch.cat((m.weight_list, st['weight'].detach().cpu()))
+        counts = m.stage_counts(st)                   # (the one host read of a compacted data-dependent forward)
+        bkey = key + (None if counts is None else tuple(counts),)
+        be = self._back.pop(bkey, None)
+        if be is None:
+            n = self._seen[bkey] = self._seen.get(bkey, 0) + 1
+            known = counts is None or st['host_branch'] is not None
+            if not known and n < self.capture_after:
+                self.replays['eager_back'] += 1
+                self.launch = 'hipGraph front + eager back'
+                return m.forward_back(st, counts, True, return_weight)
+            while len(self._back) >= self.MAX_GRAPHS:
+                self._back.pop(next(iter(self._back)))[0].reset()
+            be = self._capture(lambda: m.forward_back(st, counts, True, True))
+        self._back[bkey] = be                          # most recently used last
+        be[0].replay()
+        self.replays['back'] += 1
+        if counts is not None:
+            m.last_stage_batch = list(counts)
+        out, weight = be[1]
+        return (out, weight) if return_weight else out
+
+
 def _dist_world(group=None):
     return (dp.dist.get_rank(group), dp.dist.get_world_size(group)) if dp.dist.is_initialized() else (0, 1)
 
 
 @torch.no_grad()
-def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard=True, group=None, losses=None):
+def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard=True, group=None, losses=None, infer_step=None):
     """batches: iterable of (rgb, depth, label_orig[N,H0,W0] with 0 = void[, label[N,H,W] at the network's resolution]).
     Returns (mIoU*100, cm).
 
@@ -474,6 +604,8 @@ def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard
     batches r, r + world, ... and the 40x40 confusion matrix (int64: exact) is all-reduced once at the end — every rank
     returns the same mIoU for 1/world of the forward passes.  The module buffers (BatchNorm running statistics) are
     broadcast from rank 0 first, so the result is rank 0's model evaluated on the whole set.
+
+    `infer_step` (an InferStep of `model`): the forward is replayed as hipGraphs instead of enqueued launch by launch.
 
     `losses` (a dict) + `class_weight`: also accumulate validate()'s two validation losses (train.py:432-440;
     src/utils.py:53-97) from batches that carry the 4th element; the dict receives `sum_weighted`, `weight_sum`,
@@ -495,7 +627,7 @@ def evaluate(model, batches, num_classes=40, hard=True, class_weight=None, shard
         if i % world != rank:
             continue
         rgb, depth, label = batch[:3]
-        logits = model(rgb, depth, True)
+        logits = infer_step(rgb, depth) if infer_step is not None else model(rgb, depth, True)
         if losses is not None and cw is not None and len(batch) > 3:
             ops.validation_loss_accumulate(logits, batch[3], cw, acc4)
         ops.eval_confusion(logits, label, cm)     # resize + argmax + void mask + bincount, one kernel

@@ -37,5 +37,9 @@ class ESANet(SkipGateESANet):
             return super().forward(rgb, depth, test=True, return_weight=True)
         return super().forward(rgb, depth, test=True)
 
+    def forward_front(self, rgb, depth):
+        self.baseline = True                 # (engine.InferStep enters here, not through forward)
+        return super().forward_front(rgb, depth)
+
     def freeze(self):
         raise NotImplementedError('ESANet has no gate to keep trainable (model.freeze() belongs to the --dynamic models)')

@@ -211,9 +211,8 @@ class SkipGateESANet(nn.Module):
         return getattr(self, f'se_layer{j}').params8() if self.fuse_depth_in_rgb_encoder == 'SE-add' else None
 
     # ---- forward ------------------------------------------------------------------------------
-    def forward(self, rgb, depth, test=False, return_weight=False):
+    def _stem(self, rgb, depth):
         er, ed = self.encoder_rgb, self.encoder_depth
-        tab = self._flop_table(rgb.device)
         if self.training:
             ops.begin_step()
         if ops.stem_bn_fuse_supported((rgb.shape[2] + 1) // 2, (rgb.shape[3] + 1) // 2, er.bn1, ed.bn1):
@@ -227,7 +226,14 @@ class SkipGateESANet(nn.Module):
             r, d = ops.stem_bn_fuse_pool(r, er.bn1, d, ed.bn1, self._se(0))
         else:
             r, d = self._stem_unfused(rgb, depth)
-        return self._forward_stages(rgb, r, d, tab, test, return_weight)
+        return r, d
+
+    def forward(self, rgb, depth, test=False, return_weight=False):
+        st = self.forward_front(rgb, depth)
+        if self.save_weight_info:
+            self.weight_list = torch.cat((self.weight_list, st['weight'].detach().cpu()))
+        return self.forward_back(st, self.stage_counts(st), test, return_weight)
+
 
     def _stem_unfused(self, rgb, depth):
         er, ed = self.encoder_rgb, self.encoder_depth
@@ -243,8 +249,11 @@ class SkipGateESANet(nn.Module):
             d = ops.max_pool_3x3_s2(d_pool)
         return r, d
 
-    def _forward_stages(self, rgb, r, d, tab, test, return_weight):
-        er, ed = self.encoder_rgb, self.encoder_depth
+    def forward_front(self, rgb, depth):
+        """Stem, gate and the DEVICE side of the compaction decision — everything up to the one point where the host may have to
+        read 16 bytes (stage_counts).  No host synchronisation in here: engine.InferStep captures it as the first of two graphs."""
+        tab = self._flop_table(rgb.device)
+        r, d = self._stem(rgb, depth)
         bs = r.shape[0]
         host_branch = None                                           # branch per sample when the host already knows it
         if self.baseline:                                            # …globalgate.py:264-266
@@ -269,23 +278,38 @@ class SkipGateESANet(nn.Module):
             #  cause: a FIFTH busy stream, see ops.WGRAD_STREAMS; on an existing stream — the last weight-gradient one — 64.05 against 63.77).  Not kept.)
             pooled = self.gate_layer.features(r_gate, d_gate)
             weight, wcum, loss = ops.gate_head(pooled, self.gate_layer.fc.weight, tab, self.temp, self.hard_gate, force)
-        if self.save_weight_info:
-            self.weight_list = torch.cat((self.weight_list, weight.detach().cpu()))
-
         one_hot = self.baseline or self.ini_stage or self.hard_gate
         infer = not self.training and not torch.is_grad_enabled()
         compacted = one_hot and ((self.compact and infer) or (self.compact_train and not infer))
-        self.last_stage_batch = None
-        skips = []
-        unpermute = None
+        st = {'r': r, 'd': d, 'weight': weight, 'wcum': wcum, 'loss': loss, 'host_branch': host_branch, 'infer': infer,
+              'compacted': compacted, 'order': None, 'inv': None, 'counts_dev': None}
         if compacted:
             # K16: sort the batch by branch (descending, stable) ON THE DEVICE; the samples that still need depth
             # stage j are then the prefix of length counts[j-1] — each stage runs on a prefix view.  The host needs
             # only the 4 counts: known already for baseline / ini_stage / an injected distribution, otherwise ONE
-            # 16-byte device->host read per forward.
-            _, order, inv, counts_dev = ops.gate_decide(weight)
-            counts = [sum(1 for bch in host_branch if bch >= j) for j in (1, 2, 3, 4)] if host_branch is not None \
-                else [int(v) for v in counts_dev.tolist()]
+            # 16-byte device->host read per forward (stage_counts).
+            _, st['order'], st['inv'], st['counts_dev'] = ops.gate_decide(weight)
+        return st
+
+    def stage_counts(self, st):
+        """Samples that run depth stage 1..4 of a compacted forward (None otherwise): from the host's own knowledge of the branches
+        (baseline / ini_stage / an injected distribution) or by ONE 16-byte device->host read."""
+        if not st['compacted']:
+            return None
+        hb = st['host_branch']
+        if hb is not None:
+            return [sum(1 for bch in hb if bch >= j) for j in (1, 2, 3, 4)]
+        return [int(v) for v in st['counts_dev'].tolist()]
+
+    def forward_back(self, st, counts, test=False, return_weight=False):
+        """The four encoder stages with their fusions, context module and decoder, for a front state and its stage counts."""
+        er, ed = self.encoder_rgb, self.encoder_depth
+        r, d, weight, wcum, loss = st['r'], st['d'], st['weight'], st['wcum'], st['loss']
+        host_branch, infer, compacted, order, inv = st['host_branch'], st['infer'], st['compacted'], st['order'], st['inv']
+        self.last_stage_batch = None
+        skips = []
+        unpermute = None
+        if compacted:
             presorted = host_branch is not None and all(x >= y for x, y in zip(host_branch, host_branch[1:]))
             wc = None
             if not presorted:

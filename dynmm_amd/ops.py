@@ -991,6 +991,12 @@ def note_mutation():
     _MUTATION_GEN[0] += 1
 
 
+# A stream capture normally re-folds / re-packs its inference weights INSIDE the graph (a replay then always reads the live
+# weights).  engine.InferStep keys its graphs on the version stamp of every parameter and buffer and drops them when it moves,
+# so its captures may read the cached operands instead (True only inside InferStep._capture): ~200 launches less per replay.
+CAPTURE_EVAL_CACHE = False
+
+
 def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=1, padding=0, x2=None):
     """Inference-only: conv + folded eval-mode BatchNorm + residual + activation in ONE kernel.
     `bn` is None (plain bias) or an nn.BatchNorm2d holding running statistics."""
@@ -1012,7 +1018,7 @@ def conv2d_fused_eval(x, weight, conv_bias, bn, act=None, residual=None, stride=
     stamp = (_MUTATION_GEN[0],) + tuple((t.data_ptr(), t._version) for t in srcs if t is not None) + \
         ((float(bn.eps),) if bn is not None else ())
     hit = getattr(weight, slot, None)
-    if hit is not None and hit[0] == stamp and not torch.cuda.is_current_stream_capturing():
+    if hit is not None and hit[0] == stamp and (CAPTURE_EVAL_CACHE or not torch.cuda.is_current_stream_capturing()):
         wp, scale, shift = hit[1]
     else:
         scale = shift = None

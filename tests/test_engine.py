@@ -599,3 +599,77 @@ def test_stream_plan_is_process_wide_three_models_in_sequence():
         del m, ts
         torch.cuda.empty_cache()
     assert max(times) / min(times) < 1.03, times
+
+
+@pytest.mark.gpu
+def test_infer_step_graph_replay_equals_eager():
+    """engine.InferStep: the inference forward replayed as hipGraphs is bit-identical to the eager forward —
+    baseline (configs[1]: static fuse), soft gates, hard gates with the branches injected, and hard DATA-DEPENDENT gates with
+    compaction (front graph -> 16-byte host read -> back graph per stage-count tuple, captured on its second sighting) — follows
+    new inputs, returns the gate weights on request, and drops its captures when the weights move."""
+    from dynmm_amd import engine
+    from dynmm_amd.nn.net import SkipGateESANet
+    from dynmm_amd.nn.esanet import ESANet
+    dev = torch.device('cuda:0')
+    h, w, n = 96, 128, 6
+    m = SkipGateESANet(height=h, width=w, encoder_block='NonBottleneck1D', fuse_depth_in_rgb_encoder='SE-add')
+    synth.fill_state_dict(m.state_dict(), seed=0)
+    m = m.to(dev).eval()
+    m.dual_stream = True
+    batches = [synth.synth_inputs(n, h, w, seed=900 + i, device=dev) for i in range(3)]
+    step = engine.InferStep(m, capture_after=2)
+
+    def eager(rgb, depth):
+        with torch.no_grad():
+            out, wgt = m(rgb, depth, True, True)
+        return out.clone(), wgt.clone()
+
+    def check(tag, expect_launch=None):
+        for i, (rgb, depth) in enumerate(batches + batches[:1]):
+            ref, ref_w = eager(rgb, depth)
+            out, wgt = step(rgb, depth, return_weight=True)
+            assert torch.equal(out, ref) and torch.equal(wgt, ref_w), (tag, i, step.launch)
+            out2 = step(rgb, depth)
+            assert torch.equal(out2, ref), (tag, i, 'no weight')
+        if expect_launch is not None:
+            assert step.launch == expect_launch, (tag, step.launch, step.replays)
+
+    m.baseline, m.hard_gate, m.temp = True, False, 1.0
+    check('baseline', 'hipGraph replay')
+    m.compact = False
+    check('baseline dense', 'hipGraph replay')
+    m.compact = True
+    m.baseline = False
+    check('soft', 'hipGraph replay')
+    m.hard_gate = True
+    m.branch_override = [4, 0, 2, 3, 1, 4]
+    check('hard injected', 'hipGraph replay')
+    m.branch_override = None
+    m.temp = 0.1
+    before = dict(step.replays)
+    check('hard data-dependent')
+    assert step.replays['back'] > before['back']                  # count tuples seen twice were replayed as graphs
+    assert step.launch in ('hipGraph replay', 'hipGraph front + eager back')
+    captures = step.replays['captures']
+    check('hard data-dependent again')
+    # weights move (an optimizer step / load_state_dict): every capture is dropped and retaken from the new weights
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    synth.fill_state_dict(sd, seed=5)
+    m.load_state_dict(sd)
+    check('after load_state_dict')
+    assert step.replays['captures'] > captures
+    m.ini_stage = True                                             # host RNG per call: always eager
+    with torch.no_grad():
+        step(*batches[0])
+    assert step.launch == 'eager'
+    m.ini_stage = False
+    # the static ESANet (no gate): same machinery with baseline forced
+    e = ESANet(height=h, width=w, num_classes=40, encoder_rgb='resnet34', encoder_depth='resnet34', encoder_block='NonBottleneck1D',
+               pretrained_on_imagenet=False, fuse_depth_in_rgb_encoder='SE-add', upsampling='learned-3x3-zeropad')
+    synth.fill_state_dict(e.state_dict(), seed=1)
+    e = e.to(dev).eval()
+    es = engine.InferStep(e)
+    for rgb, depth in batches:
+        with torch.no_grad():
+            ref = e(rgb, depth).clone()
+        assert torch.equal(es(rgb, depth), ref) and es.launch == 'hipGraph replay'
