@@ -72,6 +72,10 @@ def parse():
                          'GPU-bound at batch 32 (eager == graph on one stream) and the 3-stream schedule '
                          '(RGB encoder | depth encoder | weight gradients) overlaps better un-captured')
     ap.add_argument('--single-stream', action='store_true', help='disable the depth-encoder and wgrad side streams')
+    ap.add_argument('--dp-exchange', default='wgrad', choices=['wgrad', 'depth', 'comm'],
+                    help="N > 1 over RCCL: the stream the gradient-bucket all-reduces are enqueued on (dp.GradBucketReducer): the last "
+                         "weight-gradient stream (default), the depth-encoder stream, or asynchronous collectives from a "
+                         "communication stream of their own")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4, help='batch of the thread sweep + parity sample')
     ap.add_argument('--no-cpu-full-batch', dest='cpu_full_batch', action='store_false',
@@ -494,7 +498,8 @@ def train_workload(args, device, rank, world, hard=False, branches='all4', compa
         model.branch_override = branches_for(branches, args.batch)
         model.compact_train = bool(compact)
     ts = engine.TrainStep(model, cw, lr=1e-4, momentum=0.9, weight_decay=1e-4, loss_ratio=1.0, flop_budget=0.0,
-                          use_graph=args.graph and not hard, multi_stream=not args.single_stream, overlap=True)
+                          use_graph=args.graph and not hard, multi_stream=not args.single_stream, overlap=True,
+                          exchange=args.dp_exchange)
 
     def step():
         ts(rgb, depth, labels)
@@ -511,7 +516,7 @@ def train_workload(args, device, rank, world, hard=False, branches='all4', compa
     return step, ts, model
 
 
-def fwd_workload(args, device, batch, branches='all4', compact=True):
+def fwd_workload(args, device, batch, branches='all4', compact=True, graph=False):
     model = make_model(args.config, args.height, args.width, device, args.model)
     rgb, depth, _ = make_batch(batch, args.height, args.width, device, 1234)
     model.eval()
@@ -524,20 +529,37 @@ def fwd_workload(args, device, batch, branches='all4', compact=True):
             model.ini_stage = True
             model.ini_branches = branches_for(branches, batch)
 
+    infer = engine.InferStep(model) if (graph and args.model == 'gate') else None
+
     def step():
+        if infer is not None:
+            return infer(rgb, depth)                      # hipGraph replays (engine.InferStep)
         with torch.no_grad():
             return model(rgb, depth, test=True)
+    step.infer = infer
     return step, model
 
 
-def measure_fwd(args, device, batch, branches, compact, steps, warmup, with_kernels=True):
-    step, model = fwd_workload(args, device, batch, branches, compact)
+def measure_fwd(args, device, batch, branches, compact, steps, warmup, with_kernels=True, graph=True):
+    """graph: the forward as hipGraph replays (engine.InferStep) — the deployment-side default since round 6; the eager
+    rate (one launch per kernel from Python) is reported beside it as `eager`."""
+    step, model = fwd_workload(args, device, batch, branches, compact, graph=False)
     for _ in range(2):
         step()
-    el = timed(step, steps, warmup, 1, device)
+    el_eager = timed(step, steps, warmup, 1, device)
+    el, launch = el_eager, 'eager'
+    if graph and args.model == 'gate':
+        gstep, gmodel = fwd_workload(args, device, batch, branches, compact, graph=True)
+        for _ in range(3):
+            gstep()
+        el = timed(gstep, steps, warmup, 1, device)
+        launch = gstep.infer.launch
+        del gstep, gmodel
     val = batch * steps / el
     out = {'metric': 'images/sec fwd-only, 480x640 RGB-D', 'value': round(val, 2), 'unit': 'images/s',
-           'ms_per_step': round(1000 * el / steps, 3), 'batch': batch, 'branches': branches, 'compaction': bool(compact),
+           'ms_per_step': round(1000 * el / steps, 3), 'launch': launch,
+           'eager': {'value': round(batch * steps / el_eager, 2), 'ms_per_step': round(1000 * el_eager / steps, 3)},
+           'batch': batch, 'branches': branches, 'compaction': bool(compact),
            'stage_batch': getattr(model, 'last_stage_batch', None),
            'model_tflops': round(val * GFLOP_PER_IMG_FWD[args.config] / 1e3, 2) if branches == 'all4' else None}
     if with_kernels:
@@ -736,7 +758,13 @@ def main():
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         loc = [1000.0 * float(x.item()) / k2 for x in every]
-        dp_info.update({'ms_per_step_no_collectives': round(1000.0 * el_nc / k2, 3),
+        # the four-stream plan, per rank: how many streams each rank's step enqueued on (ops.stream_census; 4 = the plan)
+        cz = torch.tensor([float((ts.census or {}).get('streams', -1))], device=device, dtype=torch.float64)
+        every_c = [torch.zeros_like(cz) for _ in range(world)]
+        dist.all_gather(every_c, cz)
+        dp_info.update({'exchange': red.exchange, 'stream_ordered_collectives': bool(red._stream_ordered),
+                        'busy_streams_per_rank': [int(x.item()) for x in every_c],
+                        'ms_per_step_no_collectives': round(1000.0 * el_nc / k2, 3),
                         'comm_exposed_ms': round(ms_per_step - 1000.0 * el_nc / k2, 3),
                         'ms_per_step_unbarriered_rank_min_mean_max': [round(min(loc), 3), round(sum(loc) / world, 3),
                                                                       round(max(loc), 3)]})
@@ -842,6 +870,8 @@ def main():
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            # N > 1: the same step with the reducer switched off, beside ms_per_step (what the exchange costs)
+            'step_without_collectives_ms': (dp_info or {}).get('ms_per_step_no_collectives'),
             'config': {'workload': workload,
                        'branches': args.branches if (args.hard or not train) else None,
                        'compaction': (args.compact if args.hard else None) if train else (not args.no_compact),
@@ -850,6 +880,7 @@ def main():
                        'height': args.height, 'width': args.width,
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
+                       'stream_census': ts.census if ts is not None else None,
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
                        'winograd': {'passes': ops.WINO, 'input_gradients': ops.WINO_DGRAD, 'weight_gradients': True},
                        'dependent_kernel_interval_us': dependent_kernel_interval_us(device),

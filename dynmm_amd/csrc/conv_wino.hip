@@ -88,10 +88,7 @@ __device__ __forceinline__ float quad_sum(float v) {            // sum over the 
 // the direct work; since round 5 they run on the 2-D form F(2x2,3x3) of conv_wino2d.hip at 4/9, and this kernel carries none
 // of the tap bookkeeping: no zero slot in LDS, no row bits, a loader whose addresses advance by constant strides.)
 template <int TCO, int MCO, bool VERT, bool DGRAD, bool S2 = false, bool TAIL = false, bool STATS = false, int BNRED = 0>
-#ifndef DYNMM_WINO_VOCC
-#define DYNMM_WINO_VOCC 3
-#endif
-__global__ void __launch_bounds__(256, MCO == 1 ? ((VERT && !S2) ? DYNMM_WINO_VOCC : 3) : 2) conv_wino_kernel(const WinoArgs a) {
+__global__ void __launch_bounds__(256, MCO == 1 ? ((VERT && !DGRAD) ? 4 : 3) : 2) conv_wino_kernel(const WinoArgs a) {
     static_assert(!BNRED || (DGRAD && VERT && !S2 && MCO == 1 && TCO == 64 && !TAIL && !STATS), "BatchNorm reductions: vertical dgrad");
     static_assert(!S2 || DGRAD, "the stride-2 form is an input gradient");
     static_assert(!STATS || (!DGRAD && !VERT && MCO == 1 && TCO == 64 && !TAIL), "statistics: the forward's small horizontal tile");
@@ -99,7 +96,15 @@ __global__ void __launch_bounds__(256, MCO == 1 ? ((VERT && !S2) ? DYNMM_WINO_VO
     // MCO: 32-channel blocks per wave.  2: a wave owns 64 co x 32 pairs x 4 transforms (128 accumulator registers, two
     // workgroups per CU); 1: 32 co x 32 pairs x 4 (64 registers, three workgroups per CU: smaller tiles for the grids a
     // 8192-accumulator tile quantises badly, and a third neighbour to cover a workgroup's prologue / epilogue)
-    constexpr int BK = 8, S = (VERT && !S2 && MCO == 1 && DYNMM_WINO_VOCC == 4) ? 2 : 3;
+    // Ring depth.  The vertical kernels stage 4 input rows per pair (8 KB per stage beside the filters' 8 KB): three slots are
+    // 48 KB = three workgroups per CU.  The vertical FORWARD (115 VGPRs) runs on a two-slot ring — 32 KB, FOUR workgroups per CU,
+    // the same single barrier per stage, the DMA of stage s + 2 issued right behind that barrier and given one stage (instead
+    // of two) to land: round 6, scratch/r6/wino_time.py: 141 -> 125 us at C = 64, 108 -> 102.5 at 128, 92.7 -> 90.8 at 256,
+    // 105.5 -> 105.1 at 512 (the epilogue of one workgroup is covered by three neighbours instead of two).  The vertical input
+    // gradients need 142 - 144 VGPRs (mask / accum / BatchNorm-reduction epilogues): at a 128-register budget they spill 17 - 26
+    // and run 3 - 16 % slower — they stay at three workgroups and three slots.  The horizontal kernels fit four with three slots.
+    constexpr int S = (VERT && !DGRAD && MCO == 1) ? 2 : 3;
+    constexpr int BK = 8;
     constexpr int WCO = 32 * MCO;
     constexpr int WAVES_CO = TCO / WCO, WAVES_P = 4 / WAVES_CO, TP = 32 * WAVES_P;
     static_assert(WAVES_CO * WAVES_P == 4 && (MCO == 1 || MCO == 2), "4 waves per workgroup");

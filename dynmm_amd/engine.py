@@ -477,7 +477,7 @@ class InferStep:
     and temperature, `compact`, `dual_stream`, the injected branches — and a stamp over the version counters of every parameter
     and buffer plus ops' mutation generation, because the folded BatchNorm factors / packed filters a capture reads are the
     cached ones (ops.conv2d_fused_eval) and must die with the weights they were made from.
-    Eager fallbacks: `ini_stage` (branches drawn with the host RNG per call), a training-mode model, models without a
+    Eager fallbacks: `ini_stage` without injected branches (drawn with the host RNG per call), a training-mode model, models without a
     front / back split that take host decisions (SkipESANet's per-stage gates); a model without gates (the static ESANet) is
     one graph."""
 
@@ -511,9 +511,11 @@ class InferStep:
     def _key(self, rgb, depth):
         m = self.model
         bo = getattr(m, 'branch_override', None)
+        if getattr(m, 'ini_stage', False):
+            bo = ('ini',) + tuple(int(v) for v in m.ini_branches)
         return (tuple(rgb.shape), tuple(depth.shape), bool(getattr(m, 'baseline', False)), bool(getattr(m, 'hard_gate', False)),
                 float(getattr(m, 'temp', 0.0)), bool(getattr(m, 'compact', False)), bool(getattr(m, 'dual_stream', False)),
-                None if bo is None else tuple(int(v) for v in bo))
+                None if bo is None else tuple(bo))
 
     def _eager(self, rgb, depth, return_weight):
         self.replays['eager'] += 1
@@ -543,7 +545,8 @@ class InferStep:
     def __call__(self, rgb, depth, return_weight=False):
         m = self.model
         gated = hasattr(m, 'forward_front')
-        host_decisions = getattr(m, 'ini_stage', False) or (not gated and (hasattr(m, 'hard_gate') or hasattr(m, 'block_rule')))
+        host_decisions = (getattr(m, 'ini_stage', False) and getattr(m, 'ini_branches', None) is None) or \
+            (not gated and (hasattr(m, 'hard_gate') or hasattr(m, 'block_rule')))
         if m.training or host_decisions:
             return self._eager(rgb, depth, return_weight)
         stamp = self._weights_stamp()

@@ -10,6 +10,8 @@ p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 GP = C.POINTER(L.ConvGeom)
 v = C.c_void_p
 TAGS = sys.argv[1:] or ['v0', 'v2']
+VERT = os.environ.get('TAPS', 'h') == 'v'
+KH, KW = (3, 1) if VERT else (1, 3)
 
 
 def load(tag):
@@ -37,28 +39,30 @@ libs = {t: load(t) for t in TAGS}
 torch.manual_seed(0)
 print('shape | pass | ' + ' | '.join(TAGS) + '   (us; alg TF/s of each)')
 for (N, Cc, H, W) in SHAPES:
-    g = L.ConvGeom(N, Cc, H, W, Cc, H, W, 1, 3, 1, 1, 0, 1, Cc)
-    x = torch.randn(N, Cc, H, W, device='cuda'); w = torch.randn(Cc, Cc, 1, 3, device='cuda') * 0.05
+    g = L.ConvGeom(N, Cc, H, W, Cc, H, W, KH, KW, 1, 1, KH // 2, KW // 2, Cc)
+    x = torch.randn(N, Cc, H, W, device='cuda'); w = torch.randn(Cc, Cc, KH, KW, device='cuda') * 0.05
     b = torch.randn(Cc, device='cuda'); res = torch.randn_like(x); mask = torch.randn_like(x)
-    nf = libs[TAGS[0]].dynmm_wino_packed_floats(Cc, Cc, 1, 3)
+    nf = libs[TAGS[0]].dynmm_wino_packed_floats(Cc, Cc, KH, KW)
     fl = 2.0 * N * H * W * 3 * Cc * Cc
-    for name in ('fwd relu', 'fwd +res', 'fwd stats', 'dgrad m+a'):
+    for name in ('fwd relu', 'fwd +res', 'fwd stats', 'dgrad pl', 'dgrad m+a'):
         ts, outs = [], []
         for t in TAGS:
             lib = libs[t]
             u = torch.empty(nf, device='cuda')
-            assert lib.dynmm_wino_pack(p(w), p(u), None, Cc, Cc, 1, 3, 1 if name.startswith('dgrad') else 0, st) == 0
+            assert lib.dynmm_wino_pack(p(w), p(u), None, Cc, Cc, KH, KW, 1 if name.startswith('dgrad') else 0, st) == 0
             y = torch.full_like(x, float('nan'))
             if name == 'fwd relu':
                 call = lambda: lib.dynmm_conv2d_wino_fwd(p(x), p(u), p(b), None, p(y), C.byref(g), 1, st)
             elif name == 'fwd +res':
                 call = lambda: lib.dynmm_conv2d_wino_fwd(p(x), p(u), p(b), p(res), p(y), C.byref(g), 1, st)
             elif name == 'fwd stats':
-                ns = lib.dynmm_conv2d_wino_fwd_stats_slots(C.byref(g))
+                ns = 0 if VERT else lib.dynmm_conv2d_wino_fwd_stats_slots(C.byref(g))
                 if ns <= 0:
                     continue
                 stats = torch.zeros(ns * 2 * Cc, device='cuda', dtype=torch.float64)
                 call = lambda: lib.dynmm_conv2d_wino_fwd_stats(p(x), p(u), p(b), p(y), p(stats), ns, C.byref(g), st)
+            elif name == 'dgrad pl':
+                call = lambda: lib.dynmm_conv2d_wino_dgrad(p(x), p(u), None, None, p(y), C.byref(g), st)
             else:
                 call = lambda: lib.dynmm_conv2d_wino_dgrad(p(x), p(u), p(mask), p(res), p(y), C.byref(g), st)
             r = call()

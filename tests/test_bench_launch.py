@@ -86,3 +86,20 @@ def test_roofline_kernel_names_match_the_pmc_summary():
     assert 'conv_wino43_dgrad<horizontal>' in rec and rec['conv_wino43_dgrad<horizontal>']['launches_per_step'] == 76
     assert 'conv_wino_dgrad<vertical>' in rec and rec['conv_wino_dgrad<vertical>']['launches_per_step'] == 76     # (BNRED 0 | 1 | 2 instances)
     assert rec['conv_wgrad_s2<co128,3x1>']['launches_per_step'] == 6
+
+
+def test_roofline_frac_is_a_fraction():
+    """`achieved` stays algorithmic FLOP / time, but `frac` is quoted against what the kernel's algorithm
+    can attain (peak / executed share) and never exceeds 1 — the round-5 line carried 1.13 for config S's F(2x2,3x3) kernel."""
+    import bench
+    # a recorded case: conv_wino2d_dgrad<3x3> at 180.09 TF/s algorithmic (BENCH r05/r06 extra.config_S), + two others
+    for label, tf in (('conv_wino2d_dgrad<co128,3x3>', 180.09), ('conv_wino43_dgrad<co128,1x3>', 165.0),
+                      ('conv_wino_dgrad<co128,3x1>', 122.5), ('conv_igemm_fwd<128x64>', 100.0)):
+        ms = 1.0
+        agg = {label: [1, ms, tf * 1e12 * ms * 1e-3, 1e8]}
+        r = bench.roofline_of(agg)
+        share = bench.executed_fraction(label)
+        assert abs(r['achieved'] - tf) < 0.01 and r['peak'] == bench.FP32_MFMA_PEAK_TFLOPS
+        assert abs(r['attainable'] - r['peak'] / share) < 0.06
+        assert 0 < r['frac'] <= 1 and abs(r['frac'] - tf * share / r['peak']) < 1e-3 and r['frac'] == r['executed_frac']
+        assert abs(r['algorithmic_frac'] - tf / r['peak']) < 1e-3
