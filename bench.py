@@ -616,6 +616,31 @@ def measure_affect(device, steps, warmup=3, batch=128, T=50):
                        'PARITY UNPINNED (MultiBench not vendored)')
     del step, model
     torch.cuda.empty_cache()
+    # BASELINE configs[4] words the workload as "3-expert transformer late-fusion + 3-way gating net" = DynMMNet
+    # (affect_dyn.py:31-104: three uni-modal transformer experts, 3-way gate): the same step on that model
+    torch.manual_seed(0)
+    m3 = A.DynMMNet(1.0, False, freeze=False).to(device)
+    step3 = A.AffectTrainStep(m3, lr=1e-5, weight_decay=1e-4, lossw=0.1, use_graph=True)
+    m3.train()
+    for _ in range(2):
+        step3(inputs, y)
+    el = timed(lambda: step3(inputs, y), steps, warmup, 1, device)
+    m3.eval()
+
+    def fwd3():
+        with torch.no_grad():
+            return m3(inputs)
+    for _ in range(2):
+        fwd3()
+    elf = timed(fwd3, steps, warmup, 1, device)
+    res['dynmmnet_3expert'] = {'train_step': {'value': round(batch * steps / el, 1), 'unit': 'samples/s',
+                                              'ms_per_step': round(1000 * el / steps, 3), 'launch': 'hipGraph replay'},
+                               'forward': {'value': round(batch * steps / elf, 1), 'unit': 'samples/s',
+                                           'ms_per_step': round(1000 * elf / steps, 3)},
+                               'workload': 'DynMMNet (affect_dyn.py:31-104): visual / audio / text transformer experts + 3-way '
+                                           'gate, experts trainable, dropout p = 0.1; PARITY UNPINNED'}
+    del step3, m3
+    torch.cuda.empty_cache()
     return res
 
 
@@ -782,6 +807,7 @@ def main():
             roofline = roofline_of(kernel_timing(step, model))
             model.dual_stream = saved
     stage_batch = getattr(model, 'last_stage_batch', None)
+    census = ts.census if ts is not None else None
     del step, ts, model
     torch.cuda.empty_cache()
 
@@ -880,7 +906,7 @@ def main():
                        'height': args.height, 'width': args.width,
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
-                       'stream_census': ts.census if ts is not None else None,
+                       'stream_census': census,
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
                        'winograd': {'passes': ops.WINO, 'input_gradients': ops.WINO_DGRAD, 'weight_gradients': True},
                        'dependent_kernel_interval_us': dependent_kernel_interval_us(device),

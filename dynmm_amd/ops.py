@@ -861,7 +861,11 @@ class _Conv2d(Function):
                 gyw = gy if gy.data_ptr() % 16 == 0 else gy.clone()
                 mask, accum = (t if (t is None or t.data_ptr() % 16 == 0) else t.clone() for t in (mask, accum))
                 bl = ctx.bn_link
+                # ((ctx.link is None) == (accum is None): when this block has an identity branch its gradient must have ARRIVED here
+                #  through the link — had it taken the autograd route instead (link.dres never set), the launch below would mask
+                #  the convolution's part only while telling the BatchNorm backward the sum is masked: ADVICE r5)
                 if (bl is not None and bl.x is not None and bl.bits is not None and ctx.wino_d == 23 and mask is None and
+                        (ctx.link is None) == (accum is None) and
                         bl.x.data_ptr() % 8 == 0 and (g.H * g.W) % 4 == 0 and
                         lib.dynmm_conv2d_wino_dgrad_bnred_supported(C.byref(g))):
                     # x = relu(BN(c) + identity), this convolution and the identity branch behind `accum` its only consumers: the
@@ -1605,6 +1609,8 @@ class _StemBNFusePool(Function):
         ws = torch.empty(lib.dynmm_se_coeff_bwd_workspace_bytes(N, Cc) // 4, **f32) if ctx.use_se else None
         L.check(lib.dynmm_se_coeff_bwd(_p(da), _p(db), _p(sr), _p(sd), parr, None, 0, _p(hr), _p(hd), _p(gr), _p(gd),
                                        dparr, _p(dsr), _p(dsd), None, 0, _p(ws), N, Cc, int(ctx.use_se), st), 'se_coeff_bwd')
+        _grads_enqueued()        # the SE parameters' gradients are complete HERE, on this stream: reported now, not by whichever
+                                 # op next calls _grads_enqueued (the deferred branch below returns without one: ADVICE r5)
         # BatchNorm backward of both stems with their incoming gradient derived on the fly from the pooled gradients
         # (dynmm_stem_bn_bwd_*): gy_rgb = a * d(fuse) + dsr/HW ; gy_depth = b * d(fuse) + dsd/HW + d(pooled depth)
         def bn_chain(k):
