@@ -794,6 +794,7 @@ def main():
                         'ms_per_step_unbarriered_rank_min_mean_max': [round(min(loc), 3), round(sum(loc) / world, 3),
                                                                       round(max(loc), 3)]})
 
+    census = ts.census if ts is not None else None        # of the timed loop's last step (the instrumented pass below is single-stream)
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
         if ts is not None:
@@ -807,7 +808,6 @@ def main():
             roofline = roofline_of(kernel_timing(step, model))
             model.dual_stream = saved
     stage_batch = getattr(model, 'last_stage_batch', None)
-    census = ts.census if ts is not None else None
     del step, ts, model
     torch.cuda.empty_cache()
 

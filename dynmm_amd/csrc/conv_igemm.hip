@@ -1152,7 +1152,10 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
         p.tk = 192;
         p.n_co_tiles = ceil_div(g->Co, p.tco);
         p.n_k_tiles = (g->KH == 3 && g->KW == 3 ? 3 : 1) * (g->Ci / 64);       // 3x3: one vertical tap per workgroup
-        p.target = target6 ? target6 : 256 * wgrad_v6_occupancy(g);
+#ifndef DYNMM_WGRAD_ROUNDS
+#define DYNMM_WGRAD_ROUNDS 1
+#endif
+        p.target = target6 ? target6 : 256 * wgrad_v6_occupancy(g) * DYNMM_WGRAD_ROUNDS;
         plan_splits(p, g, 1);
         return p;
     }

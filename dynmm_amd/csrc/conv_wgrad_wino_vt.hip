@@ -40,7 +40,11 @@ using icv = std::integral_constant<int, I>;
 template <int MCO>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradArgs a_in, const WgradGroup grp) {
     WgradArgs a = a_in;
-    constexpr int TCO = 64 * MCO, BP = 8, LD = 12, NST = 3, RPI = 21;
+#ifndef DYNMM_VT_NST
+#define DYNMM_VT_NST 3
+#endif
+    constexpr int TCO = 64 * MCO, BP = 8, LD = 12, NST = DYNMM_VT_NST, RPI = 21;
+    static_assert(NST == 2 || NST == 3, "ring depth");
     constexpr int GW = TCO / 4;                                  // dY channels requested by one wave (2 rows each)
     constexpr int G_ROWS = 2 * TCO, X_ROWS = 4 * 64;
     constexpr int G_STAGE = G_ROWS * LD, X_STAGE = X_ROWS * LD;  // floats per ring slot
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     for (int s = 0; s < NST; ++s)
         if (s < nsteps) issue(s);
     if (nsteps > 0) {
-        if (nsteps >= 3) wait_vm<2 * J>(); else if (nsteps == 2) wait_vm<J>(); else wait_vm<0>();
+        if (NST == 3 && nsteps >= 3) wait_vm<2 * J>(); else if (nsteps >= 2) wait_vm<J>(); else wait_vm<0>();
         __syncthreads();
         read_frags(icv<0>{}, 0);
     }
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
         constexpr int S = decltype(SET)::value;
         const int next = slot == NST - 1 ? 0 : slot + 1;
         if (s + 1 < nsteps) {
-            if (s + 2 < nsteps) wait_vm<J>(); else wait_vm<0>();
+            if (NST == 3 && s + 2 < nsteps) wait_vm<J>(); else wait_vm<0>();
             __syncthreads();
             if (s + NST < nsteps) issue(slot);
             read_frags(icv<1 - S>{}, next);

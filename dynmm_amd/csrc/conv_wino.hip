@@ -99,10 +99,12 @@ __global__ void __launch_bounds__(256, MCO == 1 ? ((VERT && !DGRAD) ? 4 : 3) : 2
     // Ring depth.  The vertical kernels stage 4 input rows per pair (8 KB per stage beside the filters' 8 KB): three slots are
     // 48 KB = three workgroups per CU.  The vertical FORWARD (115 VGPRs) runs on a two-slot ring — 32 KB, FOUR workgroups per CU,
     // the same single barrier per stage, the DMA of stage s + 2 issued right behind that barrier and given one stage (instead
-    // of two) to land: round 6, scratch/r6/wino_time.py: 141 -> 125 us at C = 64, 108 -> 102.5 at 128, 92.7 -> 90.8 at 256,
-    // 105.5 -> 105.1 at 512 (the epilogue of one workgroup is covered by three neighbours instead of two).  The vertical input
-    // gradients need 142 - 144 VGPRs (mask / accum / BatchNorm-reduction epilogues): at a 128-register budget they spill 17 - 26
-    // and run 3 - 16 % slower — they stay at three workgroups and three slots.  The horizontal kernels fit four with three slots.
+    // of two) to land: round 6, scratch/r6/wino_time.py in steady state (the first shape of a run is 10 % slow whatever runs
+    // it): 97.9 -> 94.7 us at C = 128 (+ residual 102.7 -> 99.0), equal at C = 64 / 256 / 512; the step is the same within
+    // 0.1 ms.  A small gain, kept because it also frees 16 KB of LDS per workgroup.  The vertical input gradients need 142 - 144
+    // VGPRs (mask / accum / BatchNorm-reduction epilogues): at a 128-register budget they spill 17 - 26 and run slower; with
+    // single-buffered epilogue operands (120 - 122 VGPRs, no spill) they are equal to the three-workgroup form within the
+    // measurement's own order bias — they stay at three workgroups and three slots.  The horizontal kernels fit four with three slots.
     constexpr int S = (VERT && !DGRAD && MCO == 1) ? 2 : 3;
     constexpr int BK = 8;
     constexpr int WCO = 32 * MCO;

@@ -32,6 +32,10 @@ def tm(fn, n=30):
 SHAPES = [(32, 64, 120, 160), (32, 128, 60, 80), (32, 256, 30, 40), (32, 512, 15, 20), (32, 128, 30, 40), (32, 128, 15, 20),
           (3, 64, 24, 36), (5, 128, 17, 20)]
 libs = {t: load(t) for t in TAGS}
+# WARM-UP: the first launches of a process run ~10 % slow (clock ramp): measured columns would carry an order bias
+_w = torch.randn(4096, 4096, device='cuda')
+for _ in range(300): _w = (_w @ _w).clamp_(-1, 1)
+torch.cuda.synchronize()
 torch.manual_seed(0)
 print('shape | epilogue | ' + ' | '.join(TAGS) + '   (us; alg TF/s of each)')
 for (N, Cc, H, W) in SHAPES:

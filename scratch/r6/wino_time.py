@@ -23,6 +23,8 @@ def load(tag):
     lib.dynmm_conv2d_wino_dgrad.argtypes = [v, v, v, v, v, GP, v]
     lib.dynmm_conv2d_wino_fwd_stats.argtypes = [v, v, v, v, v, C.c_int, GP, v]
     lib.dynmm_conv2d_wino_fwd_stats_slots.argtypes = [GP]
+    lib.dynmm_conv2d_wino_dgrad_bnred.argtypes = [v, v, v, v, v, v, v, v, v, GP, v]
+    lib.dynmm_conv2d_wino_dgrad_bnred_slots.argtypes = [GP]
     return lib
 
 
@@ -36,15 +38,21 @@ def tm(fn, n=30):
 
 SHAPES = [(32, 64, 120, 160), (32, 128, 60, 80), (32, 256, 30, 40), (32, 512, 15, 20), (32, 128, 30, 40), (3, 64, 24, 36), (5, 128, 17, 20)]
 libs = {t: load(t) for t in TAGS}
+# WARM-UP: the first launches of a process run ~10 % slow (clock ramp): measured columns would carry an order bias
+_w = torch.randn(4096, 4096, device='cuda')
+for _ in range(300): _w = (_w @ _w).clamp_(-1, 1)
+torch.cuda.synchronize()
 torch.manual_seed(0)
 print('shape | pass | ' + ' | '.join(TAGS) + '   (us; alg TF/s of each)')
 for (N, Cc, H, W) in SHAPES:
     g = L.ConvGeom(N, Cc, H, W, Cc, H, W, KH, KW, 1, 1, KH // 2, KW // 2, Cc)
     x = torch.randn(N, Cc, H, W, device='cuda'); w = torch.randn(Cc, Cc, KH, KW, device='cuda') * 0.05
     b = torch.randn(Cc, device='cuda'); res = torch.randn_like(x); mask = torch.randn_like(x)
+    mean = torch.randn(Cc, device='cuda'); invstd = torch.rand(Cc, device='cuda') + 0.5
+    gam = torch.randn(Cc, device='cuda'); bet = torch.randn(Cc, device='cuda')
     nf = libs[TAGS[0]].dynmm_wino_packed_floats(Cc, Cc, KH, KW)
     fl = 2.0 * N * H * W * 3 * Cc * Cc
-    for name in ('fwd relu', 'fwd +res', 'fwd stats', 'dgrad pl', 'dgrad m+a'):
+    for name in ('fwd relu', 'fwd +res', 'fwd stats', 'dgrad pl', 'dgrad m+a', 'dgrad bnred'):
         ts, outs = [], []
         for t in TAGS:
             lib = libs[t]
@@ -61,6 +69,12 @@ for (N, Cc, H, W) in SHAPES:
                     continue
                 stats = torch.zeros(ns * 2 * Cc, device='cuda', dtype=torch.float64)
                 call = lambda: lib.dynmm_conv2d_wino_fwd_stats(p(x), p(u), p(b), p(y), p(stats), ns, C.byref(g), st)
+            elif name == 'dgrad bnred':
+                if not VERT:
+                    continue
+                ns = lib.dynmm_conv2d_wino_dgrad_bnred_slots(C.byref(g))
+                sums = torch.zeros(ns * 2 * Cc, device='cuda', dtype=torch.float64)
+                call = lambda: lib.dynmm_conv2d_wino_dgrad_bnred(p(x), p(u), p(mask), p(mean), p(invstd), p(gam), p(bet), p(sums), p(y), C.byref(g), st)
             elif name == 'dgrad pl':
                 call = lambda: lib.dynmm_conv2d_wino_dgrad(p(x), p(u), None, None, p(y), C.byref(g), st)
             else:
