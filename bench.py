@@ -787,6 +787,12 @@ def main():
         cz = torch.tensor([float((ts.census or {}).get('streams', -1))], device=device, dtype=torch.float64)
         every_c = [torch.zeros_like(cz) for _ in range(world)]
         dist.all_gather(every_c, cz)
+        rep = ops.stream_plan(device).report
+        cl = torch.tensor([1.0 if rep.get('clean') else 0.0, float(rep.get('replaced', 0))], device=device, dtype=torch.float64)
+        every_p = [torch.zeros_like(cl) for _ in range(world)]
+        dist.all_gather(every_p, cl)
+        dp_info.update({'stream_plan_clean_per_rank': [bool(x[0].item()) for x in every_p],
+                        'stream_plan_replaced_per_rank': [int(x[1].item()) for x in every_p]})
         dp_info.update({'exchange': red.exchange, 'stream_ordered_collectives': bool(red._stream_ordered),
                         'busy_streams_per_rank': [int(x.item()) for x in every_c],
                         'ms_per_step_no_collectives': round(1000.0 * el_nc / k2, 3),
@@ -907,6 +913,7 @@ def main():
                        'parallelism': f'dp{world}', 'launch': 'hipGraph replay' if (args.graph and train and not args.hard) else 'eager',
                        'streams': 1 if args.single_stream else ((2 + ops.WGRAD_STREAMS) if train else 2),
                        'stream_census': census,
+                       'stream_plan': ops.stream_plan(device).report,      # do the plan's streams run side by side (pair probe)?
                        'optimizer_in_step': 'fused SGD-Nesterov' if train else None,
                        'winograd': {'passes': ops.WINO, 'input_gradients': ops.WINO_DGRAD, 'weight_gradients': True},
                        'dependent_kernel_interval_us': dependent_kernel_interval_us(device),

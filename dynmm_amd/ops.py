@@ -140,6 +140,7 @@ _INFLIGHT = []
 # ONCE per device, through the runtime (never from torch's pool), in a fixed order, and every user — nn/net.py encoder_stage_pair,
 # the weight-gradient queues, dp.GradBucketReducer's exchange, engine.TrainStep's capture warm-up — takes them from here.
 MAX_BUSY_STREAMS = 4
+VERIFY_STREAM_PLAN = True      # check at creation that the plan's streams run concurrently (_StreamPlan.verify)
 _PLANS = {}                    # device index -> _StreamPlan
 _HIP_RT = []
 _CENSUS = set()                # stream handles kernels were enqueued on since stream_census_reset()
@@ -192,6 +193,9 @@ class _StreamPlan:
         self.handles = []              # the runtime streams behind the ExternalStream objects (kept: never destroyed)
         self.side = self._make(False)
         self.wgrad = [self._make(True) for _ in range(max(1, WGRAD_STREAMS))]
+        self.report = {'checked': False}
+        if VERIFY_STREAM_PLAN:
+            self.verify()
 
     def _make(self, least_priority):
         s, h = _runtime_stream(self.device, least_priority)
@@ -202,6 +206,73 @@ class _StreamPlan:
     def grow(self):
         while len(self.wgrad) < max(1, WGRAD_STREAMS):
             self.wgrad.append(self._make(True))
+
+    # -- do the four streams really run side by side? ------------------------------------------------------------------------
+    # The runtime multiplexes a process's streams onto a few hardware queues in creation order, and two streams that share one
+    # serialise: the +10 ms cliff of profiles/r05_ab_runs.md / r06_stream_plan.md.  Which queue a new stream lands on depends on
+    # every stream the process created before (torch's pools, RCCL's, a data loader's) — so the plan is CHECKED, not assumed:
+    # two spin kernels (torch.cuda._sleep, one workgroup each) on a pair of streams take 1.2x one spin when the streams are
+    # independent and 2.1x when they share a queue (scratch/r6/queue_probe.py: the ratio separates the classes cleanly; a third
+    # class at 1.45 - 1.65 — neighbouring queues of one pipe — is rejected too when a cleaner stream can be had).  A stream that
+    # collides with the caller's stream or with an earlier stream of the plan is replaced by a newly created one, a bounded
+    # number of times; what was found is kept in `self.report` (bench.py prints it).
+    SPIN_CYCLES = 300000
+    CLEAN, TRIES = 1.35, 6
+
+    def _pair_ratio(self, a, b, single_ms):
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.synchronize()
+            b.synchronize()
+            e0.record(a)
+            b.wait_event(e0)
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(self.SPIN_CYCLES)
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(self.SPIN_CYCLES)
+            a.wait_stream(b)
+            e1.record(a)
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best / single_ms
+
+    def verify(self):
+        self.report = {'checked': False}
+        if not hasattr(torch.cuda, '_sleep') or torch.cuda.is_current_stream_capturing():
+            return self.report
+        with torch.cuda.device(self.device):
+            caller = torch.cuda.current_stream()
+            with torch.cuda.stream(caller):
+                torch.cuda._sleep(self.SPIN_CYCLES)                 # (first launch of the spin kernel: module load)
+            caller.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(caller)
+            with torch.cuda.stream(caller):
+                torch.cuda._sleep(self.SPIN_CYCLES)
+            e1.record(caller)
+            e1.synchronize()
+            single = max(e0.elapsed_time(e1), 1e-3)
+            replaced, worst = 0, {}
+            fixed = [('caller', caller)]
+            order = [('depth', False)] + [(f'wgrad{i}', True) for i in range(len(self.wgrad))]
+            for name, low in order:
+                for attempt in range(self.TRIES + 1):
+                    s = self.side if name == 'depth' else self.wgrad[int(name[5:])]
+                    ratios = {fn: round(self._pair_ratio(fs, s, single), 2) for fn, fs in fixed}
+                    if max(ratios.values()) <= self.CLEAN or attempt == self.TRIES:
+                        break
+                    fresh = self._make(low)                          # (the rejected stream stays alive, idle: never destroyed)
+                    if name == 'depth':
+                        self.side = fresh
+                    else:
+                        self.wgrad[int(name[5:])] = fresh
+                    replaced += 1
+                worst.update({f'{fn}|{name}': r for fn, r in ratios.items()})
+                fixed.append((name, s))
+            self.report = {'checked': True, 'spin_ms': round(single, 3), 'pair_ratio': worst, 'replaced': replaced,
+                           'clean': bool(max(worst.values()) <= self.CLEAN)}
+        return self.report
 
     def streams(self):
         return [self.side] + self.wgrad[:max(1, WGRAD_STREAMS)]

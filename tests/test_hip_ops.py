@@ -1158,6 +1158,21 @@ def test_weight_gradient_streams_have_least_priority(ops):
     assert hip.hipStreamGetPriority(C.c_void_p(plan.side.cuda_stream), C.byref(got)) == 0 and got.value == 0, got.value
     handles = {plan.side.cuda_stream} | {s.cuda_stream for s in plan.wgrad}
     assert len(handles) == 1 + len(plan.wgrad) and 0 not in handles and torch.cuda.current_stream().cuda_stream not in handles
+    # the plan was CHECKED at creation: every pair among (caller, depth, wgrad0, wgrad1) runs two spin kernels side by side
+    rep = plan.report
+    assert rep['checked'] and rep['clean'] and len(rep['pair_ratio']) == 6, rep
+    assert max(rep['pair_ratio'].values()) <= plan.CLEAN
+    # ... and the probe tells a shared queue from an independent one: a stream against ITSELF serialises (ratio ~2)
+    single = rep['spin_ms']
+    assert plan._pair_ratio(plan.side, plan.side, single) > 1.7
+    assert plan._pair_ratio(torch.cuda.current_stream(), plan.side, single) <= plan.CLEAN
+    # a plan whose depth stream collides (here: IS the caller's stream) repairs itself
+    bad = ops._StreamPlan.__new__(ops._StreamPlan)
+    bad.device, bad.handles, bad.report = plan.device, [], {}
+    bad.side, bad.wgrad = torch.cuda.current_stream(), [ops.low_priority_stream() for _ in range(ops.WGRAD_STREAMS)]
+    rep2 = bad.verify()
+    assert rep2['checked'] and rep2['replaced'] >= 1 and rep2['clean'], rep2
+    assert bad.side.cuda_stream != torch.cuda.current_stream().cuda_stream
     a = rnd(1 << 20, seed=1).cuda()
     s = streams[0]
     s.wait_stream(torch.cuda.current_stream())
