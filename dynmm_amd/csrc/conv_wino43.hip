@@ -13,8 +13,14 @@
 // the vertical taps looped, 1/2 of the direct work) run on the 2-D F(2x2,3x3) of conv_wino2d.hip (4/9) since round 5.
 //
 // Structure = conv_wino.hip's small tile: 64 co x 64 quads per workgroup, a wave owns 32 co x 32 quads x 6 transforms = 6
-// accumulator blocks (96 registers, two workgroups per CU); operands by direct global -> LDS loads into a 3-slot ring (8 channels
-// per stage), fragments of k-pair q + 1 read under the 6 MFMAs of k-pair q (across stage boundaries too), phases pinned.
+// accumulator blocks (96 registers); operands by direct global -> LDS loads into a ring (8 channels per stage), fragments of
+// k-pair q + 1 read under the 6 MFMAs of k-pair q (across stage boundaries too), phases pinned.
+// Round 6: THREE workgroups per CU (DYNMM_W43_WG = 3; round 5 ran two: 206 VGPRs, a 3-slot ring of 62 KB).  The ring has two
+// slots — the DMA of stage s + 2 is issued right behind the barrier that ends stage s and has one stage to land; one barrier per
+// stage as before — 41.5 KB; the epilogue's operands are single-buffered — 142 VGPRs.  A workgroup's epilogue is an HBM burst
+// with no matrix work (mask and residual-gradient reads, stores); with two neighbours to cover it instead of one a launch with
+// both operands takes 91.6 us instead of 126.3 at C = 128 (plain 78.1 / 81.9), 88.0 / 104.7 at C = 256, 135.7 / 183.6 at C = 64,
+// and the step 0.49 ms less (profiles/r06_ab_runs.md).
 //   * filter operand: two planes [ci][co][4] (U0..U3) and [ci][co][2] (U4, U5): one ds_read_b128 + one
 //     ds_read_b64 per k-pair;
 //   * horizontal taps: raw tile [8 channels][4 * quads + 8] pixels (16-byte quads, 4-pixel halo either side), a lane reads
