@@ -50,6 +50,9 @@ struct Wino43Args {
 #ifndef DYNMM_W43_WG
 #define DYNMM_W43_WG 3
 #endif
+#ifndef DYNMM_W43_PREFETCH
+#define DYNMM_W43_PREFETCH 1
+#endif
 __global__ void __launch_bounds__(256, DYNMM_W43_WG) conv_wino43_kernel(const Wino43Args a) {
     constexpr int WG = DYNMM_W43_WG;
     constexpr int BK = 8, S = WG == 3 ? 2 : 3, TCO = 64, TQ = 64, NT = 6;
@@ -219,6 +222,43 @@ __global__ void __launch_bounds__(256, DYNMM_W43_WG) conv_wino43_kernel(const Wi
     };
 #define DYNMM_W43_PHASE() __builtin_amdgcn_sched_barrier(0)
 
+    // ---------------------------------------------------------------- epilogue state (defined here: DYNMM_W43_PREFETCH)
+    const float* __restrict__ res_p = a.residual;
+    const float* __restrict__ mask_p = a.mask;
+    float* __restrict__ y_p = a.y;
+    const bool has_res = res_p != nullptr, has_mask = mask_p != nullptr;
+    const unsigned row_bytes = (unsigned)HW * 4u;
+    const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * 32 + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
+    auto off_of = [&](int b, int e) {            // batch b: channels 8 b + 4 khalf + e, e = 0..3
+        return off_base + (unsigned)(8 * b + e) * row_bytes;
+    };
+    constexpr int NS = WG == 3 ? 1 : 2;           // epilogue operand sets: double-buffered at two workgroups per CU; at three the
+                                                  // register budget (168) has room for one and the third workgroup covers the loads
+    float kk[NS][4][4], rr[NS][4][4];             // [set][channel e][output j]
+#pragma unroll
+    for (int z = 0; z < NS; ++z)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kk[z][e][j] = 1.f;
+                rr[z][e][j] = 0.f;
+            }
+    auto load_batch = [&](int set, int b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned off = off_of(b, e);
+            if (!qvalid) continue;
+            if (has_mask) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mask_p) + off);
+                kk[set][e][0] = v.x; kk[set][e][1] = v.y; kk[set][e][2] = v.z; kk[set][e][3] = v.w;
+            }
+            if (has_res) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(res_p) + off);
+                rr[set][e][0] = v.x; rr[set][e][1] = v.y; rr[set][e][2] = v.z; rr[set][e][3] = v.w;
+            }
+        }
+    };
     // ---------------------------------------------------------------- K loop (conv_wino.hip's)
 #pragma unroll
     for (int i = 0; i < S; ++i) issue();
@@ -231,6 +271,11 @@ __global__ void __launch_bounds__(256, DYNMM_W43_WG) conv_wino43_kernel(const Wi
     read_raw(0, 0, A4p, A2p, Bp);
     transform(0);
     for (int s = 0; s < nst; ++s) {
+#if DYNMM_W43_PREFETCH
+        // the first batch of epilogue operands is requested at the top of the LAST stage (no operand DMA is outstanding any more:
+        // the wait in front of this stage was vmcnt(0)), so that it arrives under that stage's 24 MFMAs
+        if (s == nst - 1 && (has_mask || has_res)) load_batch(0, 0);
+#endif
         DYNMM_W43_PHASE();
         read_raw(1, 1, A4p, A2p, Bp);
         DYNMM_W43_PHASE();
@@ -272,43 +317,9 @@ __global__ void __launch_bounds__(256, DYNMM_W43_WG) conv_wino43_kernel(const Wi
 #undef DYNMM_W43_PHASE
 
     // ---------------------------------------------------------------- epilogue
-    const float* __restrict__ res_p = a.residual;
-    const float* __restrict__ mask_p = a.mask;
-    float* __restrict__ y_p = a.y;
-    const bool has_res = res_p != nullptr, has_mask = mask_p != nullptr;
-    const unsigned row_bytes = (unsigned)HW * 4u;
-    const unsigned off_base = ((unsigned)(pn * a.Co + co0 + wave_co * 32 + 4 * khalf) * (unsigned)HW + (unsigned)prem) * 4u;
-    auto off_of = [&](int b, int e) {            // batch b: channels 8 b + 4 khalf + e, e = 0..3
-        return off_base + (unsigned)(8 * b + e) * row_bytes;
-    };
-    constexpr int NS = WG == 3 ? 1 : 2;           // epilogue operand sets: double-buffered at two workgroups per CU; at three the
-                                                  // register budget (168) has room for one and the third workgroup covers the loads
-    float kk[NS][4][4], rr[NS][4][4];             // [set][channel e][output j]
-#pragma unroll
-    for (int z = 0; z < NS; ++z)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kk[z][e][j] = 1.f;
-                rr[z][e][j] = 0.f;
-            }
-    auto load_batch = [&](int set, int b) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned off = off_of(b, e);
-            if (!qvalid) continue;
-            if (has_mask) {
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mask_p) + off);
-                kk[set][e][0] = v.x; kk[set][e][1] = v.y; kk[set][e][2] = v.z; kk[set][e][3] = v.w;
-            }
-            if (has_res) {
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(res_p) + off);
-                rr[set][e][0] = v.x; rr[set][e][1] = v.y; rr[set][e][2] = v.z; rr[set][e][3] = v.w;
-            }
-        }
-    };
+#if !DYNMM_W43_PREFETCH
     if (has_mask || has_res) load_batch(0, 0);
+#endif
     if (!qvalid) return;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
