@@ -127,6 +127,17 @@ class Bottleneck(nn.Module):
         return conv_bn_act(y, self.conv3, self.bn3, 'relu', residual=idt, res_link=link)
 
 
+def chain_ok(prev, blk):
+    """May `blk` treat `prev`'s output as consumed by itself alone (ResNetEncoder._stage)?  Not when a forward hook — on `prev`, a
+    pre-hook on `blk`, or a global module hook — gets to see that tensor: it may keep it in the autograd graph."""
+    import torch.nn.modules.module as M
+    if prev._forward_hooks or blk._forward_pre_hooks:
+        return False
+    if M._global_forward_hooks or M._global_forward_pre_hooks:
+        return False
+    return True
+
+
 BLOCKS = {'NonBottleneck1D': NonBottleneck1D, 'BasicBlock': BasicBlock, 'Bottleneck': Bottleneck}
 LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet50': (3, 4, 6, 3)}
 
@@ -170,8 +181,17 @@ class ResNetEncoder(nn.Module):
         return conv_bn_act(x, self.conv1, self.bn1, 'relu')
 
     def _stage(self, x, j):
-        for i, blk in enumerate(getattr(self, f'layer{j}')):
-            x = blk(x, chain=i > 0)               # (block i > 0 is the only consumer of block i - 1's output)
+        """The blocks of stage j in sequence.  THE CHAIN CONTRACT (ops.BNLink, BNRED = 2): `chain=True` tells block i that the
+        output of block i - 1 feeds block i's first convolution and identity branch AND NOTHING ELSE — block i - 1's `bn2`
+        backward then takes its ReLU-masked gradient and both reductions from block i's first input-gradient launch
+        (`out._bn_out_link`, a tensor attribute that any op between the blocks would drop = the safe direction).  A second
+        consumer of an intermediate block output (a forward hook that keeps the feature map in the graph, a feature tap) would add
+        an UNMASKED gradient to a tensor the BatchNorm backward treats as already masked: silently wrong gradients.
+        So the chain is only offered when no hook can see the intermediate tensor (`chain_ok`); `ops.BN_BWD_FUSE = False` switches
+        the whole mechanism off (every BatchNorm backward then does its own reductions)."""
+        blocks = list(getattr(self, f'layer{j}'))
+        for i, blk in enumerate(blocks):
+            x = blk(x, chain=i > 0 and chain_ok(blocks[i - 1], blk))
         return x
 
     def forward_layer1(self, x):

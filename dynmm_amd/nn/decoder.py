@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .blocks import ConvBNAct, NonBottleneck1D
+from .blocks import ConvBNAct, NonBottleneck1D, chain_ok
 
 
 class Upsample(nn.Module):
@@ -33,8 +33,10 @@ class DecoderModule(nn.Module):
 
     def forward(self, x, skip):
         y = self.conv3x3(x)
-        for i, blk in enumerate(self.decoder_blocks):
-            y = blk(y, chain=i > 0)
+        blocks = list(self.decoder_blocks)
+        for i, blk in enumerate(blocks):
+            # (the chain contract of nn/blocks.py ResNetEncoder._stage: block i is the ONLY consumer of block i - 1's output)
+            y = blk(y, chain=i > 0 and chain_ok(blocks[i - 1], blk))
         side = None
         if self.training:
             s = self.side_output

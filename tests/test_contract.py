@@ -100,3 +100,25 @@ def test_reference_import_surface():
     args.modality = 'depth'
     with pytest.raises(NotImplementedError):
         build_model(args, n_classes=40)
+
+
+def test_chain_contract_is_withdrawn_when_a_hook_can_see_the_intermediate_tensor():
+    """nn/blocks.py `chain_ok`: block i may absorb block i - 1's BatchNorm backward only when nothing else can consume
+    block i - 1's output — a forward hook on it (a feature tap) withdraws the offer."""
+    import torch
+    from dynmm_amd.nn import blocks as B
+    a, b = B.NonBottleneck1D(64, 64), B.NonBottleneck1D(64, 64)
+    assert B.chain_ok(a, b)
+    h = a.register_forward_hook(lambda m, i, o: None)
+    assert not B.chain_ok(a, b)
+    h.remove()
+    assert B.chain_ok(a, b)
+    h = b.register_forward_pre_hook(lambda m, i: None)
+    assert not B.chain_ok(a, b)
+    h.remove()
+    g = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: None)
+    try:
+        assert not B.chain_ok(a, b)
+    finally:
+        g.remove()
+    assert B.chain_ok(a, b)
