@@ -214,3 +214,41 @@ def test_encoder_stage_and_stem():
     # only stem/layer1/layer2 take part; drop the unused stages so every parameter gets a gradient
     del m.e.layer3, m.e.layer4
     run_pair(m, ref, [rnd(2, 1, 96, 128)])
+
+
+def test_feature_tap_on_an_intermediate_block_keeps_gradients_right():
+    """the chain contract (block i is the ONLY consumer of block i - 1's output) is withdrawn when a forward hook can see
+    the intermediate tensor.  A hook that keeps block 0's output in the graph (a feature tap entering the loss) must give the same
+    gradients as the same computation with the BatchNorm-backward fusion switched off altogether."""
+    from dynmm_amd import ops
+    from dynmm_amd.nn.blocks import ResNetEncoder
+    enc = ResNetEncoder('resnet34', 'NonBottleneck1D', input_channels=3).cuda().train()
+    sd = enc.state_dict()
+    synth.fill_state_dict(sd, seed=3)
+    enc.load_state_dict(sd)
+    x0 = rnd(2, 64, 24, 32, seed=5).cuda()
+    taps = []
+    hook = enc.layer1[0].register_forward_hook(lambda m, i, o: taps.append(o))
+
+    def run(fuse):
+        taps.clear()
+        saved, ops.BN_BWD_FUSE = ops.BN_BWD_FUSE, fuse
+        try:
+            for p_ in enc.parameters():
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = enc.forward_layer1(x)
+            loss = y.square().mean() + 0.5 * taps[0].square().mean()          # the tapped feature map enters the loss
+            loss.backward()
+            torch.cuda.synchronize()
+            return x.grad.clone(), {k: v.grad.clone() for k, v in enc.layer1.named_parameters()}
+        finally:
+            ops.BN_BWD_FUSE = saved
+    try:
+        gx1, gp1 = run(True)
+        gx0, gp0 = run(False)
+    finally:
+        hook.remove()
+    assert rel(gx1, gx0) < 1e-5, rel(gx1, gx0)
+    for k in gp0:
+        assert rel(gp1[k], gp0[k]) < 1e-4, (k, rel(gp1[k], gp0[k]))
