@@ -10,8 +10,11 @@
 //
 // Structure = conv_wgrad_v6.hip's: one workgroup owns a (64 | 128) co x 64 ci tile and a range of steps of the reduction;
 // a wave holds (32 | 64) co x 32 ci x 4 contractions = 4 | 8 accumulator blocks; operand rows (2 dY rows, 4 X rows per
-// channel, 8 positions per step) arrive by `global_load_lds_dwordx4` into a 3-slot ring requested two steps ahead (hand-counted
-// vmcnt), one barrier per step (16 | 32 MFMAs per wave), the fragments of step s + 1 are read under the MFMAs of step s.
+// channel, 8 positions per step) arrive by `global_load_lds_dwordx4` into a ring (hand-counted vmcnt), one barrier per step
+// (16 | 32 MFMAs per wave), the fragments of step s + 1 are read under the MFMAs of step s.  Ring depth (DYNMM_VT_NST): TWO slots
+// since round 6 — the DMA of step s + 2 is issued right behind the barrier of step s and has one step to land; 49 KB of LDS per
+// workgroup at Co % 128 == 0 instead of 74 KB (three slots, requested two steps ahead): the step 0.13 ms faster on 14 of 15
+// alternating pairs (profiles/r06_ab_runs.md).
 // LDS rows are 3 quads long (8 positions + a padding quad the loader masks off): 48-byte strides keep `ds_read_b128`
 // conflict-free (3 r mod 16 is a permutation).  Rows outside the image (row -1 of the first pair, rows H / H + 1 of the last
 // one when H is odd or even) and positions past the end of the tensor read an all-zero quad; their loads fetch a mapped
@@ -41,7 +44,7 @@ template <int MCO>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradArgs a_in, const WgradGroup grp) {
     WgradArgs a = a_in;
 #ifndef DYNMM_VT_NST
-#define DYNMM_VT_NST 3
+#define DYNMM_VT_NST 2
 #endif
     constexpr int TCO = 64 * MCO, BP = 8, LD = 12, NST = DYNMM_VT_NST, RPI = 21;
     static_assert(NST == 2 || NST == 3, "ring depth");

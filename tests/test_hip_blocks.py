@@ -250,5 +250,8 @@ def test_feature_tap_on_an_intermediate_block_keeps_gradients_right():
     finally:
         hook.remove()
     assert rel(gx1, gx0) < 1e-5, rel(gx1, gx0)
+    scale = max(v.abs().max().item() for v in gp0.values())
     for k in gp0:
-        assert rel(gp1[k], gp0[k]) < 1e-4, (k, rel(gp1[k], gp0[k]))
+        # (a bias in front of a BatchNorm has a mathematically zero gradient: 1e-10 of rounding, compared on the common scale)
+        err = (gp1[k] - gp0[k]).abs().max().item() / max(gp0[k].abs().max().item(), 1e-3 * scale)
+        assert err < 1e-4, (k, err)
