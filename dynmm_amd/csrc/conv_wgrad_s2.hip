@@ -30,7 +30,12 @@ using ic2 = std::integral_constant<int, I>;
 
 template <int MCO, bool VT, int OCC>
 __global__ void __launch_bounds__(256, OCC) conv_wgrad_s2_kernel(const WgradArgs a_in, const WgradGroup grp) {
-    constexpr int NST = 3;
+#ifndef DYNMM_S2_NST
+#define DYNMM_S2_NST 2      // two-slot operand ring since round 6 (three before): the step 0.14 ms faster on 15 of 20 alternating
+                           // runs, 17 / 25 KB of LDS less per workgroup (profiles/r06_ab_runs.md); the DMA of step s + 2 is issued right
+                           // behind the barrier of step s and has one step (32 - 48 MFMAs per wave) to land
+#endif
+    constexpr int NST = DYNMM_S2_NST;
     WgradArgs a = a_in;
     constexpr int TCO = 64 * MCO, BP = 16;
     constexpr int LDG = 20, LDX = VT ? 20 : 44;                 // row strides in floats
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_s2_kernel(const WgradArgs
     for (int s = 0; s < NST; ++s)
         if (s < nsteps) issue(s);
     if (nsteps > 0) {
-        if (nsteps >= 3) wait_vm<2 * J>(); else if (nsteps == 2) wait_vm<J>(); else wait_vm<0>();
+        if (NST == 3 && nsteps >= 3) wait_vm<2 * J>(); else if (nsteps >= 2) wait_vm<J>(); else wait_vm<0>();
         __syncthreads();
         read_frags(ic2<0>{}, 0);
     }
@@ -288,7 +293,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_s2_kernel(const WgradArgs
         constexpr int S = decltype(SET)::value;
         const int next = slot == NST - 1 ? 0 : slot + 1;
         if (s + 1 < nsteps) {
-            if (s + 2 < nsteps) wait_vm<J>(); else wait_vm<0>();
+            if (NST == 3 && s + 2 < nsteps) wait_vm<J>(); else wait_vm<0>();
             __syncthreads();
             if (s + NST < nsteps) issue(slot);
             read_frags(ic2<1 - S>{}, next);

@@ -46,6 +46,11 @@ using ic = std::integral_constant<int, I>;
 // input rows shifted by -1 / 0 / +1: one workgroup owns ONE vertical tap of its 64 input channels (k-tiles = 3 x Ci / 64), stages
 // the X rows `dr` image rows away (a quad whose row leaves the image reads the zero quad instead — the vertical padding) and
 // writes taps 3 (dr + 1) .. 3 (dr + 1) + 2 of the slab.  Same Winograd pairs, same loads, same slabs as the 1x3 launch.
+#ifndef DYNMM_V6_NST
+#define DYNMM_V6_NST 2      // two-slot operand ring since round 6 (three before): the step 0.14 ms faster on 15 of 20 alternating
+                           // runs, 17 / 25 KB of LDS less per workgroup (profiles/r06_ab_runs.md); the DMA of step s + 2 is issued right
+                           // behind the barrier of step s and has one step (32 - 48 MFMAs per wave) to land
+#endif
 template <int MCO, int NST, int OCC, bool K33 = false>
 __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs a_in, const WgradGroup grp) {
     constexpr int NACC = 4;
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     constexpr int RJX = 9;                                      //   X rows per instruction
     constexpr int NJX1 = (16 + RJX - 1) / RJX;                  //   X (16 rows per wave and tap)
     constexpr int J = NJG + NJX1;                               // loads in flight per wave and stage
-    static_assert(NST == 3, "ring depth");
+    static_assert(NST == 2 || NST == 3, "ring depth");
     static_assert(NST * J < 64, "vmcnt is a 6-bit counter");
 
     __shared__ __attribute__((aligned(16))) float Gs[NST * G_STAGE];
@@ -272,7 +277,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
     for (int s = 0; s < NST; ++s)
         if (s < nsteps) issue(s);
     if (nsteps > 0) {
-        if (nsteps >= 3) wait_vm<2 * J>(); else if (nsteps == 2) wait_vm<J>(); else wait_vm<0>();
+        if (NST == 3 && nsteps >= 3) wait_vm<2 * J>(); else if (nsteps >= 2) wait_vm<J>(); else wait_vm<0>();
         __syncthreads();
         read_frags(ic<0>{}, 0);
     }
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(256, OCC) conv_wgrad_v6_kernel(const WgradArgs
         constexpr int S = decltype(SET)::value;
         const int next = slot == NST - 1 ? 0 : slot + 1;
         if (s + 1 < nsteps) {
-            if (s + 2 < nsteps) wait_vm<J>(); else wait_vm<0>();
+            if (NST == 3 && s + 2 < nsteps) wait_vm<J>(); else wait_vm<0>();
             __syncthreads();
             if (s + NST < nsteps) issue(slot);
             read_frags(ic<1 - S>{}, next);
@@ -361,11 +366,11 @@ void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int o
     } else if (a.KH == 3 && a.KW == 1) {                   // vertical taps: pair positions (conv_wgrad_wino_vt.hip)
         launch_wgrad_wino_vt(a, grp, grid, st);
     } else if (a.KH == 3 && a.KW == 3) {            // one vertical tap per workgroup, horizontal Winograd pairs
-        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, 3, 2, true>), grid, dim3(256), 0, st, a, grp);
-        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, 3, 3, true>), grid, dim3(256), 0, st, a, grp);
+        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, DYNMM_V6_NST, 2, true>), grid, dim3(256), 0, st, a, grp);
+        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, DYNMM_V6_NST, 3, true>), grid, dim3(256), 0, st, a, grp);
     } else {                                        // horizontal taps
-        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, 3, 2, false>), grid, dim3(256), 0, st, a, grp);
-        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, 3, 3, false>), grid, dim3(256), 0, st, a, grp);
+        if (two) hipLaunchKernelGGL((conv_wgrad_v6_kernel<2, DYNMM_V6_NST, 2, false>), grid, dim3(256), 0, st, a, grp);
+        else hipLaunchKernelGGL((conv_wgrad_v6_kernel<1, DYNMM_V6_NST, 3, false>), grid, dim3(256), 0, st, a, grp);
     }
 }
 

@@ -253,5 +253,5 @@ def test_feature_tap_on_an_intermediate_block_keeps_gradients_right():
     scale = max(v.abs().max().item() for v in gp0.values())
     for k in gp0:
         # (a bias in front of a BatchNorm has a mathematically zero gradient: 1e-10 of rounding, compared on the common scale)
-        err = (gp1[k] - gp0[k]).abs().max().item() / max(gp0[k].abs().max().item(), 1e-3 * scale)
+        err = (gp1[k] - gp0[k]).abs().max().item() / max(gp0[k].abs().max().item(), 1e-2 * scale)
         assert err < 1e-4, (k, err)
