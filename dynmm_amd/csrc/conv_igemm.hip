@@ -1126,6 +1126,7 @@ void launch_wgrad_v6(const WgradArgs& a, const WgradGroup& grp, dim3 grid, int o
 // (conv_wgrad_wino_vt.hip) vertical taps in the Winograd form: the reduction runs over pair positions, 8 per step
 bool wgrad_wino_vt_on(const dynmm_conv_geom* g);
 int wgrad_wino_vt_units(const dynmm_conv_geom* g);
+int wgrad_wino_vt_bp();
 
 static void plan_splits(WgradPlan& p, const dynmm_conv_geom* g, int nprob) {
     const int units = (p.v6 && wgrad_wino_vt_on(g)) ? wgrad_wino_vt_units(g) : g->N * g->Ho * g->Wo;
@@ -1147,7 +1148,7 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
     if (allow_v6 && wgrad_v6_shape_ok(g)) {
         constexpr int target6 = 0;
         p.v6 = 1;
-        p.bp = wgrad_wino_vt_on(g) ? 8 : 16;
+        p.bp = wgrad_wino_vt_on(g) ? wgrad_wino_vt_bp() : 16;
         p.tco = wgrad_v6_tco(g);
         p.tk = 192;
         p.n_co_tiles = ceil_div(g->Co, p.tco);

@@ -1,0 +1,31 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r6p; mkdir -p $O
+timeout 900 python scratch/r6/pytest_lib.py scratch/r6/libdynmm_strips3.so tests/test_hip_ops.py tests/test_hip_blocks.py -x -q -m gpu -k "wgrad or grouped or block or encoder or decoder" > $O/pytest_strips3.log 2>&1
+tail -n 3 $O/pytest_strips3.log
+for lib in - scratch/r6/libdynmm_strips3.so; do
+  tag=$(basename $lib .so)
+  DYNMM_BENCH_SHAPES=$O/shapes_$tag.txt timeout 300 python scratch/r5/ab_lib.py $lib --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/bench_$tag.log 2>&1
+  grep "3, 1, 1, 1" $O/shapes_$tag.txt | grep wgrad | head -12
+done
+bash scratch/r6/ab_multi.sh r6p - scratch/r6/libdynmm_strips3.so
+bash scratch/r6/ab_multi.sh r6p - scratch/r6/libdynmm_strips3.so
+cd /tmp && export TMPDIR=/tmp
+for lib in - scratch/r6/libdynmm_strips3.so; do
+  tag=$(basename $lib .so)
+  for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_$tag -o p -- python $GRAFT_REPO_ROOT/scratch/r5/ab_lib.py $lib --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing --single-stream > $O/pmc_${c}_$tag.log 2>&1
+  python - <<PY
+import csv, collections
+rows = list(csv.DictReader(open('$O/pmc_${c}_$tag/p_counter_collection.csv')))
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    if 'wgrad_wino_vt' in r['Kernel_Name'] and r['Counter_Name'] == '$c':
+        k = r['Kernel_Name'][:60]
+        acc[k][0] += 1; acc[k][1] += float(r['Counter_Value'])
+for k, (n, v) in acc.items():
+    print('$tag', '$c', k, n, 'launches', round(v / n), 'KiB per launch')
+PY
+  rm -rf $O/pmc_${c}_$tag
+  done
+done
