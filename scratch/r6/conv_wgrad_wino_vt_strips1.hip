@@ -14,32 +14,28 @@
 // exact).  Bit-reproducible.
 //
 // COLUMN STRIPS (built in round 5, in the product since round 6).  A stage is 16 positions — four quads of four columns,
-// consecutive in the flattened (image, column quad) order — of ONE row pair, and consecutive stages of a strip walk DOWN the
-// image: the X rows come in row PAIRS k = (2k - 1, 2k), stage r2 uses pairs r2 and r2 + 1 and only pair r2 + 1 is new (1.0 input
-// row per output row; the round-4 kernel walked row pair by row pair, 8 columns per step, and staged all four X rows of every
-// step: 2.0).  TWO neighbouring strips are walked alternately — (r2, strip 0), (r2, strip 1), (r2 + 1, strip 0), ... — because a
-// 64-byte row piece is half a 128-byte line (see "the stage sequence" below).  Operand rows are 64-byte pieces, unpadded in LDS:
-// the loader permutes the SOURCE quads of a row (lane -> quad q ^ ((row >> 2) & 3)), which makes the readers' ds_read_b128 over
-// 32 consecutive rows conflict-free without a padding quad (a DMA lane's LDS address is fixed, its global address is not).  One
-// barrier per stage = 64 | 32 MFMAs per wave.  Zero padding (row -1, rows >= H, quads past the tensor) is a component-wise
-// register select after the read (a select between float4 OBJECTS goes through private memory, which the compiler then parks
-// in 12 KB of LDS).
+// consecutive in the flattened (image, column quad) order — of ONE row pair, and consecutive stages walk DOWN the image inside
+// that 16-column strip: the X rows come in row PAIRS k = (2k - 1, 2k), stage r2 uses pairs r2 and r2 + 1 and only pair r2 + 1 is
+// new (1.0 input row per output row; the round-4 kernel walked row pair by row pair, 8 columns per step, and staged all four X
+// rows of every step: 2.0).  Operand rows are 64-byte pieces, unpadded in LDS: the loader permutes the SOURCE quads of a row
+// (lane -> quad q ^ ((row >> 2) & 3)), which makes the readers' ds_read_b128 over 32 consecutive rows conflict-free without a
+// padding quad (a DMA lane's LDS address is fixed, its global address is not).  One barrier per stage = 64 | 32 MFMAs per wave.
+// Zero padding (row -1, rows >= H, quads past the tensor) is a component-wise register select after the read (a select between
+// float4 OBJECTS goes through private memory, which the compiler then parks in 12 KB of LDS).
 //
-// History of the form.  Round 5 measured a first version — separate "halo" items for the first pair of a strip, uniform items,
-// TWO items in flight, 80 KB per workgroup — faster in isolation and 0.3 ms SLOWER in the step, and shelved it.  Round 6 (what the
-// weight-gradient launches keep in flight costs the backward's dependent chain beside them: the 2-slot rings of
-// conv_wgrad_v6.hip / conv_wgrad_s2.hip): ONE stage in flight — every wait is vmcnt(0) —, a stage that starts a strip pair (or
-// this workgroup's range) simply requests the three pairs it and its successor need.  Measured (profiles/r06_ab_runs.md):
-//   * the 3x1 weight gradients 428 -> 395 us per grouped launch at C = 256 (141 -> 153 TF/s algorithmic), 444 -> 394 at C = 128,
-//     576 -> 459 at C = 64 (105 -> 132), 455 -> 426 at C = 512 — the horizontal kernel's rates;
-//   * the step -0.21 ms (8 of 10 alternating pairs) for the one-in-flight strips against the pair kernel, and another -0.28 ms
-//     (9 of 10) for walking two strips alternately; round 5's two-in-flight form, same day, same box: +0.45 ms;
-//   * FETCH_SIZE per launch (raw KiB, `rocprofv3 --pmc FETCH_SIZE`): pair kernel 328 927 (Co % 128 == 0) / 1 150 075 (C = 64);
-//     one strip after the other 444 490 / 1 230 932 — MORE: the other half of every 128-byte line belongs to the neighbouring
-//     strip, H2 stages away, and was fetched again; two strips alternately **296 550 / 620 141**.  With the x2 correction of
-//     16-byte-per-lane streams that is 1 295 MB per launch against ~1 258 MB algorithmic at C = 64 (1.03x; round 5: 1.85x) and
-//     652 MB against ~360 MB at Co % 128 == 0 (1.81x, unchanged: there the dY tile of a workgroup is shared with Ci / 64 - 1 other
-//     workgroups and the X tile with Co / 128 - 1 — the over-fetch left is tile re-use across workgroups, not rows or lines).
+// Round 5 measured its first form — separate "halo" items for the first pair of a strip, uniform items, TWO items in flight, a
+// 3-slot dY ring and a 4-slot X ring = 80 KB per workgroup — faster in isolation and 0.3 ms SLOWER in the step, and shelved it.
+// Round 6 (the weight-gradient launches run beside the backward's dependent chain, and what they keep in flight costs that
+// chain: the 2-slot rings of conv_wgrad_v6.hip / conv_wgrad_s2.hip): ONE stage in flight — every wait is vmcnt(0) —, a stage that
+// starts a strip (or this workgroup's range) simply requests both of its pairs, 2 dY slots + 4 X-pair slots = 64 | 48 KB.
+// Measured (profiles/r06_ab_runs.md): the 3x1 weight gradients 428 -> 389 us per grouped launch at C = 256 (141 -> 155 TF/s
+// algorithmic), 444 -> 393 at C = 128, 576 -> 467 at C = 64 (105 -> 129), 455 -> 423 at C = 512 — the horizontal kernel's rates —
+// and the step 0.21 ms faster on 8 of 10 alternating pairs (round 5's two-in-flight form, same day, same box: +0.45 ms).
+// What did NOT improve is the fabric-side byte count: FETCH_SIZE 329 -> 444 MiB per launch (raw) — a 64-byte piece is half a
+// 128-byte line and the other half belongs to the neighbouring strip, H2 stages away, so the lines are fetched twice, where the
+// pair kernel's 32-byte pieces shared their line with the next three steps.  The over-fetch the round-5 review asked to close
+// (1.83x the algorithmic bytes) moved from the X rows (each fetched for two row pairs) to the line granularity (everything
+// fetched twice) and is not closed; a 32-column strip would close it and needs 128 KB of LDS per workgroup.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -58,13 +54,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     constexpr int TCO = 64 * MCO, ROWF = 16;
     constexpr int G_ROWS = 2 * TCO, X_ROWS = 2 * 64;
     constexpr int G_SLOT = G_ROWS * ROWF, X_SLOT = X_ROWS * ROWF;   // floats
-    // ONE stage ahead.  dY: 2 slots.  X pairs: the stage being read holds two (two requests apart), the stage in flight brings
-    // one — or three when it starts a strip pair: ring positions q - 1, q + 1 live and q + 2 .. q + 4 arriving must be distinct
-    // modulo the ring size, which 6 is the smallest to satisfy (4 and 5 collide).
-    constexpr int NGS = 2, NXS = 6;
+    constexpr int NGS = 2, NXS = 4;                                 // round 6: ONE stage ahead (2 dY slots; X pairs: 2 live + up to 2 new)
     constexpr int JG = G_ROWS / 64, JX = X_ROWS / 64;               // wave instructions per row set (16 rows x 64 bytes each)
     constexpr int J = JG + JX;
-    static_assert(J + 2 * JX < 64, "vmcnt is a 6-bit counter");
+    static_assert(J + JX < 64, "vmcnt is a 6-bit counter");
 
     __shared__ __attribute__((aligned(16))) float Gs[NGS * G_SLOT];
     __shared__ __attribute__((aligned(16))) float Xs[NXS * X_SLOT];
@@ -93,37 +86,20 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     const int H2 = (H + 1) / 2;
     const int WQ = W / 4;
     const int QC = a.N * WQ;                                       // column quads of the tensor
-    const int groups = (QC + 3) / 4;                               // 16-column strips
-    const int gpairs = (groups + 1) / 2;                           // strips walked two at a time (see the stage sequence)
-    const int total_stages = gpairs * H2 * 2;
+    const int groups = (QC + 3) / 4;
+    const int total_stages = groups * H2;
     const int sb = split * a.steps_per_split;
     const int se = min(total_stages, sb + a.steps_per_split);
 
     // ---------------------------------------------------------------- the stage sequence (round 6)
-    // Stage s = (strip pair g2, row pair r2, half h): strip g = 2 g2 + h at row pair r2; the two strips of a pair are walked
-    // ALTERNATELY down the image — (r2, 0), (r2, 1), (r2 + 1, 0), ... — because a 64-byte row piece is half a 128-byte line whose
-    // other half belongs to the neighbouring strip: taken a stage apart the line is fetched once (one strip after the other,
-    // H2 stages apart, the fabric moved every line twice: FETCH_SIZE 444 MiB per launch against 329 for the pair kernel).
-    // X operand of a stage: row pairs k = r2 and r2 + 1 (rows 2k - 1, 2k) of ITS strip; pair r2 is what the same strip's
-    // previous stage requested as its pair r2 + 1, TWO requests back in the X ring.  The first stage of a strip pair or of this
-    // workgroup's range requests three pairs in this order — its own pair r2, the pair the NEXT stage (the other strip) will need
-    // as its older one, its own pair r2 + 1 — so that "older pair = two requests back" holds from the first stage on.
-    // One stage is in flight; every wait is vmcnt(0).
-    struct Seq { int s, g2, r2, h; };
-    auto seq_init = [&](Seq& q) {
-        q.s = sb;
-        q.g2 = sb / (2 * H2);
-        const int rem = sb - q.g2 * 2 * H2;
-        q.r2 = rem >> 1;
-        q.h = rem & 1;
-    };
-    auto seq_next = [&](Seq& q) {
-        ++q.s;
-        if (q.h == 0) { q.h = 1; return; }
-        q.h = 0;
-        if (++q.r2 == H2) { q.r2 = 0; ++q.g2; }
-    };
-    auto seq_first = [&](const Seq& q) { return q.s == sb || (q.r2 == 0 && q.h == 0); };
+    // Stage s = (strip g, row pair r2).  Its X operand is the row pairs k = r2 and r2 + 1 (rows 2k - 1, 2k); pair r2 is the
+    // previous stage's pair r2 + 1 and already in LDS — except for the FIRST stage of a strip or of this workgroup's range, whose
+    // request also brings pair r2 (round 5 had a separate "halo" item for it, uniform items and two items in flight; now one
+    // stage is in flight, every wait is vmcnt(0), and a stage that starts a strip is simply a longer request).
+    struct Seq { int s, g, r2; };
+    auto seq_init = [&](Seq& q) { q.s = sb; q.g = sb / H2; q.r2 = sb - q.g * H2; };
+    auto seq_next = [&](Seq& q) { ++q.s; if (++q.r2 == H2) { q.r2 = 0; ++q.g; } };
+    auto seq_first = [&](const Seq& q) { return q.s == sb || q.r2 == 0; };
 
     // ---------------------------------------------------------------- loader
     // instruction i of a wave covers LDS rows [16 (wave * J? + i) ...): dY rows first (JG per wave), then X rows (JX per wave);
@@ -141,47 +117,41 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     const unsigned lds_x = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)Xs);
     Seq lq;
     seq_init(lq);
-    int l_g2 = -1;
-    unsigned l_col[2][J];                                          // byte offset of (image, channel plane, column) per half and instruction
+    int l_g = -1;
+    unsigned l_col[J];                                             // byte offset of (image, channel plane, column) per instruction
     int l_stage = 0, l_xw = 0;                                     // stages requested; X pairs requested (ring position)
     auto issue = [&]() __attribute__((always_inline)) {
         if (lq.s >= se) return;
-        if (lq.g2 != l_g2) {                                        // a new strip pair: this lane's column quads in both strips
-            l_g2 = lq.g2;
+        if (lq.g != l_g) {                                          // a new strip: this lane's column quads
+            l_g = lq.g;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int i = 0; i < J; ++i) {
-                    int qc = 4 * (2 * l_g2 + hh) + l_sq[i];
-                    qc = qc < QC ? qc : QC - 1;                     // (a quad past the tensor: mapped, never used)
-                    const int n = qc / WQ, wq = qc - n * WQ;
-                    const int C = i < JG ? a.Co : a.Ci;
-                    l_col[hh][i] = ((unsigned)(n * C + l_ch[i]) * (unsigned)HW + (unsigned)(4 * wq)) * 4u;
-                }
+            for (int i = 0; i < J; ++i) {
+                int qc = 4 * l_g + l_sq[i];
+                qc = qc < QC ? qc : QC - 1;                         // (a quad past the tensor: mapped, never used)
+                const int n = qc / WQ, wq = qc - n * WQ;
+                const int C = i < JG ? a.Co : a.Ci;
+                l_col[i] = ((unsigned)(n * C + l_ch[i]) * (unsigned)HW + (unsigned)(4 * wq)) * 4u;
+            }
         }
-        const bool h1 = lq.h != 0;
         const unsigned gdst = lds_g + (unsigned)(((l_stage % NGS) * G_SLOT + wave * JG * 16 * ROWF) * 4);
 #pragma unroll
         for (int i = 0; i < JG; ++i) {
             int row = 2 * lq.r2 + l_row[i];
             row = row > H - 1 ? H - 1 : row;                        // (outside the image: a mapped row, zeroed at the read)
-            dma16(a.dy, (h1 ? l_col[1][i] : l_col[0][i]) + (unsigned)(row * W) * 4u, gdst + (unsigned)(i * 1024));
+            dma16(a.dy, l_col[i] + (unsigned)(row * W) * 4u, gdst + (unsigned)(i * 1024));
         }
-        auto load_pair = [&](int kx, bool half1) __attribute__((always_inline)) {     // X rows 2 kx - 1, 2 kx of strip 2 g2 + half
+        auto load_pair = [&](int kx) __attribute__((always_inline)) {     // X rows 2 kx - 1, 2 kx of this lane's channels
             const unsigned xdst = lds_x + (unsigned)(((l_xw % NXS) * X_SLOT + wave * JX * 16 * ROWF) * 4);
 #pragma unroll
             for (int i = JG; i < J; ++i) {
                 int row = 2 * kx - 1 + l_row[i];
                 row = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
-                dma16(a.x, (half1 ? l_col[1][i] : l_col[0][i]) + (unsigned)(row * W) * 4u, xdst + (unsigned)((i - JG) * 1024));
+                dma16(a.x, l_col[i] + (unsigned)(row * W) * 4u, xdst + (unsigned)((i - JG) * 1024));
             }
             ++l_xw;
         };
-        if (seq_first(lq)) {
-            load_pair(lq.r2, h1);                                   // its own older pair
-            load_pair(h1 ? lq.r2 + 1 : lq.r2, !h1);                 // the next stage's (other strip's) older pair
-        }
-        load_pair(lq.r2 + 1, h1);
+        if (seq_first(lq)) load_pair(lq.r2);                        // (first stage of a strip / of this workgroup's range only)
+        load_pair(lq.r2 + 1);
         ++l_stage;
         seq_next(lq);
     };
@@ -222,14 +192,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     auto sel4 = [](bool c, const float4& v) __attribute__((always_inline)) { return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f); };
     Seq rq;                                       // the reader's stage
     seq_init(rq);
-    int r_stage = 0, r_xw = 2;                    // its index in this workgroup's range; ring position of its pair r2 + 1
+    int r_stage = 0, r_xw = 1;                    // its index in this workgroup's range; ring position of its pair r2 + 1
     auto read_frags = [&](auto SET, int hs) __attribute__((always_inline)) {
         constexpr int S = decltype(SET)::value;
         const float* gs = Gs + (r_stage % NGS) * G_SLOT;
         const float* x1 = Xs + (r_xw % NXS) * X_SLOT;                         // pair r2 + 1
-        const float* x0 = Xs + ((r_xw + NXS - 2) % NXS) * X_SLOT;             // pair r2: two requests back
+        const float* x0 = Xs + ((r_xw + NXS - 1) % NXS) * X_SLOT;             // pair r2 (requested just before it)
         const int q = 2 * hs + khalf;
-        const bool in = 4 * (2 * rq.g2 + rq.h) + q < QC;
+        const bool in = 4 * rq.g + q < QC;
         const bool row1 = in && 2 * rq.r2 + 1 < H;
 #pragma unroll
         for (int mi = 0; mi < MCO; ++mi) {
@@ -250,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
             float s0 = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (4 * (2 * rq.g2 + rq.h) + c < QC) {
+                if (4 * rq.g + c < QC) {
                     const float4 u = *reinterpret_cast<const float4*>(gs + b_R0 * ROWF + 4 * (c ^ ((b_R0 >> 2) & 3)));
                     s0 += (u.x + u.y) + (u.z + u.w);
                     if (2 * rq.r2 + 1 < H) {
@@ -286,7 +256,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     auto advance = [&]() __attribute__((always_inline)) {
         seq_next(rq);
         ++r_stage;
-        r_xw += seq_first(rq) ? 3 : 1;
+        r_xw += seq_first(rq) ? 2 : 1;
         wait_vm<0>();
         __syncthreads();
         issue();
@@ -297,13 +267,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_vt_kernel(const WgradA
     if (n_stages > 0) {
         issue();                                    // stage sb (a first stage: both pairs)
         issue();                                    // stage sb + 1 stays in flight under stage sb
-        // wait for stage sb only: what is in flight behind it is stage sb + 1 = J instructions, J + 2 JX when it starts a strip pair
+        // wait for stage sb only: what is in flight behind it is stage sb + 1 = J instructions, J + JX when it starts a strip
         {
             Seq nx;
             seq_init(nx);
             seq_next(nx);
             if (n_stages < 2) wait_vm<0>();
-            else if (nx.r2 == 0 && nx.h == 0) wait_vm<J + 2 * JX>();
+            else if (nx.r2 == 0) wait_vm<J + JX>();
             else wait_vm<J>();
         }
         __syncthreads();
@@ -349,7 +319,7 @@ bool wgrad_wino_vt_on(const dynmm_conv_geom* g) {
 int wgrad_wino_vt_bp() { return 16; }                       // plan units per step: one stage = 16 positions
 
 // reduction units for the plan: 16 positions per stage, stages = column-quad groups x row pairs
-int wgrad_wino_vt_units(const dynmm_conv_geom* g) { return ((((g->N * (g->W / 4) + 3) / 4) + 1) / 2) * 2 * ((g->H + 1) / 2) * 16; }
+int wgrad_wino_vt_units(const dynmm_conv_geom* g) { return ((g->N * (g->W / 4) + 3) / 4) * ((g->H + 1) / 2) * 16; }
 
 void launch_wgrad_wino_vt(const WgradArgs& a, const WgradGroup& grp, dim3 grid, hipStream_t st) {
     if (a.Co % 128 == 0) hipLaunchKernelGGL((conv_wgrad_wino_vt_kernel<2>), grid, dim3(256), 0, st, a, grp);
