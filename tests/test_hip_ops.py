@@ -498,6 +498,13 @@ def test_gate_head(ops, temp, hard):
     assert rel(w, w_ref) < 1e-5 and rel(wc, wc_ref) < 1e-5 and abs(l.item() - l_ref.item()) < 1e-5
     if hard:
         assert torch.equal(w.argmax(1).cpu(), w_ref.argmax(1))
+        # the hard weights are the reference's ARITHMETIC, not exact one-hots: `y_hard - y.detach() + y`
+        # (...globalgate.py:27-28) is (1 - y) + y at the arg-max and (0 - y) + y elsewhere, which `end_weight` counts with `== 1`
+        # (...globalgate.py:241): the same bit pattern from the kernel's own soft weights y
+        y, _, _ = ops.gate_head(pooled.cuda(), fc.cuda(), tab.cuda(), temp, False)
+        onehot = torch.zeros_like(y).scatter_(1, y.argmax(1, keepdim=True), 1.0)
+        assert torch.equal(w.detach(), (onehot - y) + y)
+        assert int((w.detach() == 1).sum()) == int(((onehot - y) + y == 1).sum())
     ((w * gw.cuda()).sum() + (wc * gc.cuda()).sum() + l * gl.cuda()).backward()
     assert rel(pg.grad, pr.grad) < 2e-4
     assert rel(fg.grad, fr.grad) < 2e-4
