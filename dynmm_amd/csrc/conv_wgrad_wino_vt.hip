@@ -38,8 +38,13 @@
 //     one strip after the other 444 490 / 1 230 932 — MORE: the other half of every 128-byte line belongs to the neighbouring
 //     strip, H2 stages away, and was fetched again; two strips alternately **296 550 / 620 141**.  With the x2 correction of
 //     16-byte-per-lane streams that is 1 295 MB per launch against ~1 258 MB algorithmic at C = 64 (1.03x; round 5: 1.85x) and
-//     652 MB against ~360 MB at Co % 128 == 0 (1.81x, unchanged: there the dY tile of a workgroup is shared with Ci / 64 - 1 other
-//     workgroups and the X tile with Co / 128 - 1 — the over-fetch left is tile re-use across workgroups, not rows or lines).
+//     652 MB against ~360 MB at Co % 128 == 0 (1.81x).  What is left there is ALIGNMENT, per shape (one convolution per launch:
+//     scratch/r6/wgrad_pmc_shapes.sh): 1.03x at W = 160 (640-byte rows: every strip pair is one 128-byte line), 1.50x at W = 80
+//     (320-byte rows: odd rows start 64 bytes into a line, their strip pairs straddle two lines whose other halves belong to
+//     the neighbouring pairs, H2 x 2 stages away: (1 + 2) / 2), 2.03x at W = 40 (160-byte rows: three of four row alignments
+//     straddle), 1.35x at W = 20 (the tensors nearly fit the L2s).  Ruled out by experiment: the bias-gradient work of the
+//     ci-tile-0 workgroups (without a bias 1.48 / 2.03), workgroups of a split running in lockstep (started 4 / 8 us apart: 1.49 /
+//     1.57) — the horizontal kernel, which streams whole rows, is at 1.06 - 1.14 on every shape with the same tile decode.
 #include <stdlib.h>
 
 #include <type_traits>
