@@ -529,7 +529,7 @@ def fwd_workload(args, device, batch, branches='all4', compact=True, graph=False
             model.ini_stage = True
             model.ini_branches = branches_for(branches, batch)
 
-    infer = engine.InferStep(model) if (graph and args.model == 'gate') else None
+    infer = engine.InferStep(model, policy='auto') if (graph and args.model == 'gate') else None
 
     def step():
         if infer is not None:
@@ -547,17 +547,19 @@ def measure_fwd(args, device, batch, branches, compact, steps, warmup, with_kern
     for _ in range(2):
         step()
     el_eager = timed(step, steps, warmup, 1, device)
-    el, launch = el_eager, 'eager'
+    el, launch, auto = el_eager, 'eager', None
     if graph and args.model == 'gate':
         gstep, gmodel = fwd_workload(args, device, batch, branches, compact, graph=True)
         for _ in range(3):
             gstep()
         el = timed(gstep, steps, warmup, 1, device)
         launch = gstep.infer.launch
+        auto = getattr(gstep.infer, 'auto_timing', None)
         del gstep, gmodel
     val = batch * steps / el
     out = {'metric': 'images/sec fwd-only, 480x640 RGB-D', 'value': round(val, 2), 'unit': 'images/s',
-           'ms_per_step': round(1000 * el / steps, 3), 'launch': launch,
+           'ms_per_step': round(1000 * el / steps, 3), 'launch': launch, 'launch_policy': 'auto (the faster of hipGraph replay and eager launches on this host)',
+           'auto_timing': auto if (graph and args.model == 'gate') else None,
            'eager': {'value': round(batch * steps / el_eager, 2), 'ms_per_step': round(1000 * el_eager / steps, 3)},
            'batch': batch, 'branches': branches, 'compaction': bool(compact),
            'stage_batch': getattr(model, 'last_stage_batch', None),

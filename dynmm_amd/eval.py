@@ -33,7 +33,7 @@ def run(args, model, valid_loader, device=None, use_graph=True):
     if hasattr(model, 'start_weight'):
         model.start_weight()
     model.hard_gate, model.ini_stage, model.baseline = args.hard, args.ini, args.baseline
-    step = engine.InferStep(model) if use_graph else None
+    step = engine.InferStep(model, policy='auto') if use_graph else None      # (replay or eager launches: whichever this host runs faster)
     results = []
     for r in range(args.num_runs):
         set_seed(r)                                              # eval.py: per-run seed -> reproducible noise runs

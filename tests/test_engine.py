@@ -658,6 +658,15 @@ def test_infer_step_graph_replay_equals_eager():
     m.load_state_dict(sd)
     check('after load_state_dict')
     assert step.replays['captures'] > captures
+    # policy='auto': the faster of replay and eager launches is measured once per key and kept; results stay identical
+    m.baseline, m.hard_gate = True, False
+    auto = engine.InferStep(m, policy='auto')
+    for rgb, depth in batches + batches:
+        ref, _ = eager(rgb, depth)
+        assert torch.equal(auto(rgb, depth), ref)
+    assert list(auto._choice.values()) and set(auto._choice.values()) <= {'replay', 'eager'} and auto.auto_timing['replay_ms'] > 0
+    assert auto.launch == ('eager' if list(auto._choice.values())[0] == 'eager' else 'hipGraph replay')
+    m.baseline, m.hard_gate = False, True
     m.ini_stage = True                                             # host RNG per call: always eager
     with torch.no_grad():
         step(*batches[0])
