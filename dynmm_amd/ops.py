@@ -216,7 +216,7 @@ class _StreamPlan:
     # class at 1.45 - 1.65 — neighbouring queues of one pipe — is rejected too when a cleaner stream can be had).  A stream that
     # collides with the caller's stream or with an earlier stream of the plan is replaced by a newly created one, a bounded
     # number of times; what was found is kept in `self.report` (bench.py prints it).
-    SPIN_CYCLES = 300000
+    SPIN_CYCLES = 1000000               # ~0.5 ms per spin: long against the ~20 us of launch overhead both measurements carry
     CLEAN, TRIES = 1.35, 6
 
     def _pair_ratio(self, a, b, single_ms):
