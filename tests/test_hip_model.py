@@ -18,6 +18,7 @@ TRAIN_OUT_TOL = 1e-3    # train-mode outputs incl. 3x4 side maps: batch-stat BN 
 # Whole-model fp32 gradients: two comparisons.
 #  (1) test_model_gradients_vs_fp64_oracle_at_equal_decisions — the parity gate proper: against the fp64 oracle with the HIP pass's
 #      ReLU / arg-max decisions imposed at its near-ties, every per-parameter gradient norm to EQUAL_DECISION_NORM_TOL = 0.02, every
+EQUAL_DECISION_COS_TOL = 0.999      # per gradient tensor, same construction (measured: see the test's printout)
 #      fixture and mode (train_hard included).
 #  (2) against the reference's own fp32 gradients in the fixtures (its decisions, its summation order): bars CALIBRATED in
 #      tests/golden/grad_noise.npz (tests/golden/make_grad_noise.py: how far the fp32 CPU oracle itself moves between thread
@@ -234,6 +235,17 @@ def test_model_gradients_vs_fp64_oracle_at_equal_decisions(golden_dir, cfg, h, w
     print(f'{cfg} {hh}x{ww} {mode}: {census["imposed"]} ReLU + {gate.imposed} gate decisions imposed of {census["sites"]} traced '
           f'activations; worst gradient-norm deviation {dev.max():.4f} ({names[worst]})')
     assert dev.max() < EQUAL_DECISION_NORM_TOL, [(names[i], got[i], ref[i]) for i in np.argsort(-dev)[:8]]
+    # ... and on every gradient TENSOR's direction (a sign / permutation bug confined to one small tensor leaves its
+    # norm alone): cosine with the fp64 gradient, for every parameter whose gradient is not rounding noise
+    cos = {}
+    for k, r in zip(names, ref):
+        if r < 1e-3 * ref.max() or hp[k].grad is None:
+            continue
+        a_, b_ = hp[k].grad.detach().double().cpu().flatten(), params[k].grad.flatten()
+        cos[k] = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()).clamp_min(1e-300))
+    wk = min(cos, key=cos.get)
+    print(f'   lowest gradient-tensor cosine {cos[wk]:.6f} ({wk}) over {len(cos)} tensors')
+    assert cos[wk] > EQUAL_DECISION_COS_TOL, sorted(cos.items(), key=lambda kv: kv[1])[:8]
 
 
 def _oracle_train_step(cfg, rgb, depth, dtype, seed, temp):
