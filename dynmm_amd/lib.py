@@ -147,6 +147,8 @@ SIGNATURES = {
     'dynmm_dropout_apply': (c_i, [c_f, c_f, c_sz, _DP, c_f]),
     'dynmm_layernorm_drop_fwd': (c_i, [c_f] * 7 + [c_i, c_i, c_i, c_fl, _DP, c_f]),
     'dynmm_layernorm_drop_bwd': (c_i, [c_f] * 10 + [c_i, c_i, c_i, _DP, c_f]),
+    'dynmm_layernorm_bwd_workspace_bytes': (c_sz, [c_i, c_i, c_i]),
+    'dynmm_layernorm_drop_bwd_ws': (c_i, [c_f] * 10 + [c_i, c_i, c_i, _DP, c_f, c_sz, c_f]),
     'dynmm_layernorm_parts_fwd': (c_i, [c_f, c_i] + [c_f] * 8 + [c_i, c_i, c_i, c_fl, _DP, c_f]),
     'dynmm_ffn_supported': (c_i, [c_i] * 4),
     'dynmm_ffn_nsplit': (c_i, [c_i] * 4),

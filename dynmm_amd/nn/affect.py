@@ -27,6 +27,7 @@ on both sides); `.eval()` switches it off as in torch.
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .. import ops_seq as S
 
 FEATURES = {'visual': 35, 'audio': 74, 'text': 300}      # CMU-MOSEI (affect/count_flop.py:52)
@@ -36,6 +37,7 @@ FEATURES = {'visual': 35, 'audio': 74, 'text': 300}      # CMU-MOSEI (affect/cou
 # Autograd replays a node on its forward stream, so the backward is concurrent too; a captured step keeps the branches as
 # parallel paths of the hipGraph.
 BRANCH_STREAMS = True     # (module attribute; False: one stream)
+LINK_RESIDUAL = True      # (module attribute; False: autograd sums the two gradients of a layer's input)
 _POOL, _ALL = [], []
 
 
@@ -97,10 +99,14 @@ def encoder_layer(h, layer, heads):
         site = layer._dynmm_sites = S.new_sites(4)
     p_att = float(sa.dropout) if train else 0.0
     p1, pf, p2 = ((float(m.p) if train else 0.0) for m in (layer.dropout1, layer.dropout, layer.dropout2))
-    qkv = S.linear_bdt(h, sa.in_proj_weight, sa.in_proj_bias)
+    # h feeds in_proj and norm1's residual input: norm1's backward (which runs first) leaves the residual branch's gradient with
+    # the link and in_proj's input-gradient epilogue adds it (no accumulation pass by autograd)
+    link = ops.GradLink() if LINK_RESIDUAL else None
+    qkv = S.linear_bdt(h, sa.in_proj_weight, sa.in_proj_bias, link=link)
     a = S.mha_core(qkv, heads, drop=(p_att, site, 'attn'))
     o = S.linear_bdt(a, sa.out_proj.weight, sa.out_proj.bias)
-    h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h, drop=(p1, site + 1, 'dropout1'))
+    h1 = S.layernorm_bdt(o, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, residual=h, drop=(p1, site + 1, 'dropout1'),
+                         res_link=link)
     if S.ffn_fused_ok(h1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias):
         # linear1 -> ReLU -> dropout -> linear2 -> dropout2 -> + h1 -> norm2: two launches (csrc/seq_ffn.hip)
         return S.ffn_block(h1, layer, (pf, site + 2, 'dropout'), (p2, site + 3, 'dropout2'))

@@ -15,10 +15,12 @@ from . import ops
 from .ops import _chk, _grad_dst, _grads_enqueued, _lib, _p, _ptr_array, _stream
 
 
-def linear_bdt(x, weight, bias=None, act=None, defer_mask=False, mask_input=False):
+def linear_bdt(x, weight, bias=None, act=None, defer_mask=False, mask_input=False, link=None):
     """act(W x + b) over the channel axis of x [B, Ci, T] (or [B, Ci]): weight [Co, Ci] (nn.Linear,
     in_proj_weight) or [Co, Ci, 1] (nn.Conv1d).  defer_mask / mask_input: the ReLU backward of a `defer_mask` layer is
-    applied in the input-gradient epilogue of its single consumer (`mask_input`), as in the conv blocks."""
+    applied in the input-gradient epilogue of its single consumer (`mask_input`), as in the conv blocks.  link: ops.GradLink
+    through which x's OTHER consumer (the residual input of the layer's LayerNorm) hands its gradient to this op's
+    input-gradient epilogue."""
     squeeze = x.dim() == 2
     x4 = x.reshape(x.shape[0], x.shape[1], 1, -1) if not squeeze else x.reshape(x.shape[0], x.shape[1], 1, 1)
     shape4 = (weight.shape[0], weight.shape[1], 1, 1)
@@ -28,7 +30,7 @@ def linear_bdt(x, weight, bias=None, act=None, defer_mask=False, mask_input=Fals
     w4 = _Alias.apply(weight, shape4) if train_w else weight.detach().view(shape4)
     fuse = torch.is_grad_enabled() and x.requires_grad
     y = ops.conv2d(x4, w4, bias, 1, 0, act, defer_mask=defer_mask and fuse, mask_input=mask_input and fuse,
-                   w_owner=weight if train_w else None)
+                   link=link if fuse else None, w_owner=weight if train_w else None)
     return y.reshape(y.shape[0], y.shape[1]) if squeeze else y.reshape(y.shape[0], y.shape[1], -1)
 
 
@@ -114,6 +116,10 @@ class _Alias(Function):
     @staticmethod
     def forward(ctx, w, shape):
         ctx.shape = tuple(w.shape)
+        # under the in-place gradient protocol the convolution returns no gradient for the alias: without this autograd would
+        # materialise a zero tensor for it and ADD it to the parameter's .grad (round 6 census of the MOSEI step: 61 zeros + 61
+        # add_ launches per step)
+        ctx.set_materialize_grads(False)
         return w.view(shape)
 
     @staticmethod
@@ -121,10 +127,19 @@ class _Alias(Function):
         return (None if g is None else g.reshape(ctx.shape)), None
 
 
+def _ln_ws(lib, like, B, D, T, params):
+    """(workspace, bytes) of the LayerNorm backward's per-workgroup parameter sums; (None, 0) without parameter gradients."""
+    if not params:
+        return None, 0
+    nb = lib.dynmm_layernorm_bwd_workspace_bytes(B, D, T)
+    return torch.empty(nb // 4, device=like.device, dtype=torch.float32), nb
+
+
 class _LayerNormBDT(Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, drop=None):
+    def forward(ctx, x, res, gamma, beta, eps, drop=None, res_link=None):
         lib = _lib()
+        ctx.res_link = res_link
         x, res, gamma, beta = _chk(x, 'x'), _chk(res, 'res'), _chk(gamma, 'gamma'), _chk(beta, 'beta')
         B, D, T = x.shape
         y = torch.empty_like(x)
@@ -153,16 +168,26 @@ class _LayerNormBDT(Function):
         if ctx.needs_input_grad[2]:
             dg, dg_ret = _grad_dst(ctx.g_param)
             db, db_ret = _grad_dst(ctx.b_param)
-        L.check(lib.dynmm_layernorm_drop_bwd(_p(g), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres), _p(dg),
-                                             _p(db), B, D, T, _drop_arg(ctx.drop), _stream()), 'layernorm_bwd')
+        ws, nb = _ln_ws(lib, g, B, D, T, dg is not None)
+        L.check(lib.dynmm_layernorm_drop_bwd_ws(_p(g), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres), _p(dg),
+                                                _p(db), B, D, T, _drop_arg(ctx.drop), _p(ws), nb, _stream()), 'layernorm_bwd')
         _grads_enqueued()
-        return ((dx if dropping else dres) if need_x else None), (dres if need_res else None), dg_ret, db_ret, None, None
+        if need_res and ctx.res_link is not None:
+            # the residual input's other consumer adds this gradient in its own input-gradient epilogue (ops.GradLink): no
+            # accumulation pass by autograd
+            ctx.res_link.dres = dres.reshape(B, D, 1, T)
+            need_res = False
+        return ((dx if dropping else dres) if need_x else None), (dres if need_res else None), dg_ret, db_ret, None, None, None
 
 
-def layernorm_bdt(x, gamma, beta, eps=1e-5, residual=None, drop=None):
-    """LayerNorm over D of (dropout(x) + residual), x [B, D, T]; drop = (p, site, name) or None."""
+def layernorm_bdt(x, gamma, beta, eps=1e-5, residual=None, drop=None, res_link=None):
+    """LayerNorm over D of (dropout(x) + residual), x [B, D, T]; drop = (p, site, name) or None.  res_link: an ops.GradLink
+    shared with the linear_bdt that also consumes `residual` and whose output this layer's x descends from (so its backward
+    runs after this one): the residual branch's gradient is added there instead of by autograd."""
     d = Drop(drop[0], drop[1], drop[2], x.shape, x.device) if drop is not None and drop[0] > 0 else None
-    return _LayerNormBDT.apply(x, residual, gamma, beta, eps, d)
+    if not (res_link is not None and residual is not None and torch.is_grad_enabled() and residual.requires_grad):
+        res_link = None
+    return _LayerNormBDT.apply(x, residual, gamma, beta, eps, d, res_link)
 
 
 FFN_FUSED = True         # (module attribute: tests compare with the unfused feed-forward)
@@ -242,9 +267,10 @@ class _FFNBlock(Function):
         if ctx.needs_input_grad[5]:
             dg, dg_ret = _grad_dst(pgamma)
             db, db_ret = _grad_dst(pbeta)
-        L.check(lib.dynmm_layernorm_drop_bwd(_p(g), _p(xsum), _p(h), _p(gamma), _p(mean), _p(rstd),
-                                             _p(dout) if dropping2 else None, _p(dres), _p(dg), _p(db), B, D, T,
-                                             _drop_arg(ctx.drop2), st), 'layernorm_bwd')
+        ws, nb = _ln_ws(lib, g, B, D, T, dg is not None)
+        L.check(lib.dynmm_layernorm_drop_bwd_ws(_p(g), _p(xsum), _p(h), _p(gamma), _p(mean), _p(rstd),
+                                                _p(dout) if dropping2 else None, _p(dres), _p(dg), _p(db), B, D, T,
+                                                _drop_arg(ctx.drop2), _p(ws), nb, st), 'layernorm_bwd')
         _grads_enqueued()
         dhid = torch.empty_like(hidden)
         pf = ctx.drop_f.p if ctx.drop_f is not None else 0.0

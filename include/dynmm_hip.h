@@ -537,6 +537,13 @@ int dynmm_layernorm_drop_fwd(const float* x, const float* res, const float* gamm
 int dynmm_layernorm_drop_bwd(const float* g, const float* x, const float* res, const float* gamma, const float* mean,
                              const float* rstd, float* dx, float* dres, float* dgamma, float* dbeta, int B, int D, int T,
                              const dynmm_dropout* drop, void* stream);
+/* The same backward with a workspace (dynmm_layernorm_bwd_workspace_bytes): dgamma / dbeta come out of the input-gradient
+ * pass as per-workgroup sums plus one ordered reduction, instead of a second pass over g, x and res.  workspace NULL = the
+ * entry above. */
+size_t dynmm_layernorm_bwd_workspace_bytes(int B, int D, int T);
+int dynmm_layernorm_drop_bwd_ws(const float* g, const float* x, const float* res, const float* gamma, const float* mean,
+                                const float* rstd, float* dx, float* dres, float* dgamma, float* dbeta, int B, int D, int T,
+                                const dynmm_dropout* drop, float* workspace, size_t workspace_bytes, void* stream);
 /* The same forward for an x that arrives as `nparts` partial sums ([nparts][B, D, T], added in slab order) plus an optional
  * per-channel bias `xbias` — what dynmm_ffn_fwd leaves behind; `xsum` [B, D, T] receives the assembled x (the `x` of
  * dynmm_layernorm_drop_bwd). */

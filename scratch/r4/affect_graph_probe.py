@@ -11,6 +11,7 @@ batch = int(sys.argv[1])
 mode = sys.argv[2] if len(sys.argv) > 2 else 'train'
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device('cuda', 0)
+A.BRANCH_STREAMS = os.environ.get('STREAMS', '1') == '1'
 torch.manual_seed(0)
 model = A.DynMMNetV2(1.0, False, freeze=False).to(dev)
 g = torch.Generator().manual_seed(7)
