@@ -1182,10 +1182,8 @@ static WgradPlan plan_wgrad(const dynmm_conv_geom* g, bool allow_v6 = true) {
 // added in a fixed order (no atomics => bit-reproducible weight gradients).
 // Workgroups >= nb1 reduce an optional second region (the bias-gradient slabs) in the same launch.
 template <int V>
-__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                           float* __restrict__ out, int n, int nslabs,
-                                                           const float* __restrict__ slabs2,
-                                                           float* __restrict__ out2, int n2, int nb1) {
+__device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslabs,
+                                                  const float* __restrict__ slabs2, float* __restrict__ out2, int n2, int nb1) {
     __shared__ float part[4][64][V];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     int bx = blockIdx.x;
@@ -1211,6 +1209,37 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < V; ++j) r[j] = ((part[0][tx][j] + part[1][tx][j]) + part[2][tx][j]) + part[3][tx][j];
         vstore<V>(out + i, r);
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs,
+                                                           float* __restrict__ out, int n, int nslabs,
+                                                           const float* __restrict__ slabs2,
+                                                           float* __restrict__ out2, int n2, int nb1) {
+    reduce_slabs_body<V>(slabs, out, n, nslabs, slabs2, out2, n2, nb1);
+}
+
+// the same for the problems of a grouped weight-gradient launch (equal shapes): blockIdx.y selects the problem — one launch
+// instead of one per problem (the ModalityDynMM step: 89 of its 114 reduction launches)
+template <int V>
+__global__ void __launch_bounds__(256) reduce_slabs_group_kernel(ReduceGroup rg, int n, int nslabs, int n2, int nb1) {
+    const int q = blockIdx.y;
+    reduce_slabs_body<V>(rg.slabs[q], rg.out[q], n, nslabs, rg.slabs2[q], rg.out2[q], n2, nb1);
+}
+
+static void launch_reduce_slabs_group(const ReduceGroup& rg, int n, int nslabs, int n2, hipStream_t st) {
+    bool v4 = (n % 4 == 0) && (n2 % 4 == 0);
+    for (int i = 0; i < rg.nprob; ++i) {
+        v4 = v4 && ((reinterpret_cast<uintptr_t>(rg.slabs[i]) | reinterpret_cast<uintptr_t>(rg.out[i])) & 15u) == 0;
+        if (n2) v4 = v4 && ((reinterpret_cast<uintptr_t>(rg.slabs2[i]) | reinterpret_cast<uintptr_t>(rg.out2[i])) & 15u) == 0;
+    }
+    if (v4) {
+        const int nb1 = ceil_div(n / 4, 64), nb2 = n2 ? ceil_div(n2 / 4, 64) : 0;
+        hipLaunchKernelGGL(reduce_slabs_group_kernel<4>, dim3(nb1 + nb2, rg.nprob), dim3(256), 0, st, rg, n, nslabs, n2, nb1);
+    } else {
+        const int nb1 = ceil_div(n, 64), nb2 = n2 ? ceil_div(n2, 64) : 0;
+        hipLaunchKernelGGL(reduce_slabs_group_kernel<1>, dim3(nb1 + nb2, rg.nprob), dim3(256), 0, st, rg, n, nslabs, n2, nb1);
     }
 }
 
@@ -1675,12 +1704,16 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
         const bool fast = (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
         launch_wgrad_generic(a, grp, p, grid, false, fast, st);
         DYNMM_LAUNCH_CHECK();
+        ReduceGroup rgp{};
+        rgp.nprob = n;
         for (int i = 0; i < n; ++i) {
-            launch_reduce_slabs((const float*)grp.out[i], dws[i], g->Co * a.K, p.splits, st,
-                                has_bias ? (const float*)grp.out_bias[i] : nullptr, has_bias ? dbiases[i] : nullptr,
-                                has_bias ? g->Co : 0);
-            DYNMM_LAUNCH_CHECK();
+            rgp.slabs[i] = grp.out[i];
+            rgp.out[i] = dws[i];
+            rgp.slabs2[i] = has_bias ? grp.out_bias[i] : nullptr;
+            rgp.out2[i] = has_bias ? dbiases[i] : nullptr;
         }
+        launch_reduce_slabs_group(rgp, g->Co * a.K, p.splits, has_bias ? g->Co : 0, st);
+        DYNMM_LAUNCH_CHECK();
         return DYNMM_OK;
     }
     a.k_major_out = 1;

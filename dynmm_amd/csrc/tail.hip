@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(256) up2ce_fwd_kernel(const float* __restrict_
         for (int b = 0; b < 4; ++b) {
             const int oh = 2 * g.i0 + a, ow = 2 * g.j0 + b, o = a * 4 + b;
             ok[o] = oh < H2 && ow < W2;
-            tt[o] = ok[o] ? (int)tn[(size_t)oh * W2 + ow] - 1 : -1;
+            // (unconditional load on a clamped address: sixteen loads in flight instead of sixteen predicated round trips)
+            const int traw = (int)tn[(size_t)min(oh, H2 - 1) * W2 + min(ow, W2 - 1)];
+            tt[o] = ok[o] ? traw - 1 : -1;
             m[o] = -INFINITY;
             s[o] = 0.f;
             xt[o] = 0.f;
@@ -212,6 +214,9 @@ __global__ void __launch_bounds__(256) up2ce_fwd_kernel(const float* __restrict_
     }
     float ls = 0.f, ws = 0.f;
     float* ln = lse + (size_t)g.n * 4 * HW;
+    float wq[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) wq[o] = cw[min(max(tt[o], 0), C - 1)];      // class weights requested together
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -221,9 +226,8 @@ __global__ void __launch_bounds__(256) up2ce_fwd_kernel(const float* __restrict_
                 const float e = m[o] + logf(s[o]);
                 ln[(size_t)(2 * g.i0 + a) * W2 + 2 * g.j0 + b] = e;
                 if (tt[o] >= 0 && tt[o] < C) {
-                    const float wq = cw[tt[o]];
-                    ls += wq * (e - xt[o]);
-                    ws += wq;
+                    ls += wq[o] * (e - xt[o]);
+                    ws += wq[o];
                 }
             }
         }
@@ -268,11 +272,18 @@ __global__ void __launch_bounds__(256) up2ce_bwd_kernel(const float* __restrict_
         for (int b = 0; b < 6; ++b) {
             const int oh = 2 * g.i0 + a - 1, ow = 2 * g.j0 + b - 1, o = a * 6 + b;
             const bool in = oh >= 0 && oh < H2 && ow >= 0 && ow < W2;
-            const size_t at = in ? (size_t)oh * W2 + ow : 0;
-            const int t = in ? (int)tn[at] : 0;
-            const float kk = (t >= 1 && t <= C) ? cw[t - 1] * gs : 0.f;
+            // unconditional loads on clamped addresses, values selected afterwards: the frame's 36 targets, 36 log-sum-exps and
+            // 36 class weights are three batches of loads in flight instead of 108 predicated, dependent round trips
+            const size_t at = (size_t)min(max(oh, 0), H2 - 1) * W2 + min(max(ow, 0), W2 - 1);
+            // (masks and arithmetic on the loaded values rather than selects around them: the compiler sinks a load whose only
+            //  use sits in one arm of a select back under that arm's branch)
+            const int t = (int)tn[at] & -(int)in;
+            const float lv = ln[at];
+            const float cv = cw[min(max(t - 1, 0), C - 1)];
+            const float kk = cv * gs * ((t >= 1 && t <= C) ? 1.f : 0.f);
             const bool has = kk > 0.f;
-            le[o] = has ? ln[at] - logf(kk) : 1e30f;
+            const float cand = lv - logf(has ? kk : 1.f);
+            le[o] = has ? cand : 1e30f;
             tcp[o >> 2] |= has ? (unsigned)t << (8 * (o & 3)) : 0u;
         }
     const float* xn = x + (size_t)g.n * C * HW;
