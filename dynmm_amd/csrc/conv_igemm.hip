@@ -1479,6 +1479,15 @@ extern "C" int dynmm_conv2d_dgrad(const float* dy, const float* wp_dgrad, const 
     return launch_igemm<true>(a, (hipStream_t)stream);
 }
 
+// conv_wgrad_kernel<..., FAST>: the loader treats a thread's x rows in groups of eight (64 consecutive k) that share one filter
+// tap and one validity bit.  True when taps change at multiples of 64 (Ci % 64 == 0) — and for EVERY Ci when there is a single
+// tap (1x1): rows k >= K of a partly filled group then read a mapped address and feed accumulator columns that are never stored
+// (a GEMM column depends on its own operand row only).  Round 6: the Linear layers of ModalityDynMM (Ci = 120 / 60 / 10) ran the
+// per-row loader at a third of the FAST rate.
+static bool wgrad_fast_rows_ok(const dynmm_conv_geom* g) {
+    return (g->Ci % 64 == 0) || (g->KH == 1 && g->KW == 1);
+}
+
 static void launch_wgrad_generic(const WgradArgs& a, const WgradGroup& grp, const WgradPlan& p, dim3 grid, bool dual,
                                  bool fast, hipStream_t st) {
 #define DYNMM_WGRAD_LAUNCH(TCO, TK, WCO, WK)                                                          \
@@ -1569,7 +1578,7 @@ extern "C" int dynmm_conv2d_wgrad(const float* x, const float* x2, const float* 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(p.n_co_tiles * p.n_k_tiles * p.splits));
     const bool dual = x2 != nullptr;
-    const bool fast = !dual && (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
+    const bool fast = !dual && wgrad_fast_rows_ok(g) && g->H >= g->KH && g->W >= g->KW;
     a.magic_wo = (g->Wo >= 2 && (unsigned long long)g->Ho * g->Wo * g->Wo < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)g->Wo) + 1u : 0u;
     const bool v4 = !p.v6 && !dual && p.tco == 128 && p.tk == 128 && (g->Ci % 64 == 0) && g->SW == 1 &&
                     (g->KW == 1 || g->KW == 3) && g->PW == g->KW / 2 && g->W == g->Wo && (g->W % 4 == 0) &&
@@ -1701,7 +1710,7 @@ extern "C" int dynmm_conv2d_wgrad_group(int n, const float* const* xs, const flo
     if (kind == 1) {
         // generic tiles: plain [Co][Ci][KH][KW] slabs, summed by reduce_slabs_kernel (one launch per problem)
         a.k_major_out = 0;
-        const bool fast = (g->Ci % 64 == 0) && g->H >= g->KH && g->W >= g->KW;
+        const bool fast = wgrad_fast_rows_ok(g) && g->H >= g->KH && g->W >= g->KW;
         launch_wgrad_generic(a, grp, p, grid, false, fast, st);
         DYNMM_LAUNCH_CHECK();
         ReduceGroup rgp{};

@@ -4,6 +4,9 @@ import torch
 from dynmm_amd import lib as L
 from dynmm_amd.ops import _p
 
+import os
+if os.environ.get("DYNMM_LIB"):
+    L.LIB_PATH = os.environ["DYNMM_LIB"]
 lib = L.load()
 N, C, H, W = 32, 40, 240, 320
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5

@@ -1196,7 +1196,11 @@ def test_weight_gradient_streams_have_least_priority(ops):
                                   (4, 128, 24, 32, 128, (3, 3), (1, 1), False),       # 3x3 on the three-tap kernel (tap rows as k-tiles)
                                   (3, 64, 15, 20, 64, (3, 3), (1, 1), True),           # ... 64-row tile, bias, ragged M = 900
                                   (3, 128, 30, 40, 256, (3, 1), (1, 0), True, (2, 1)),  # stride-2 kernel (conv_wgrad_s2.hip), vertical taps
-                                  (3, 128, 15, 40, 128, (1, 3), (0, 1), True, (1, 2))]) # ... horizontal taps, ragged M = 900
+                                  (3, 128, 15, 40, 128, (1, 3), (0, 1), True, (1, 2)),  # ... horizontal taps, ragged M = 900
+                                  (64, 120, 1, 50, 2048, (1, 1), (0, 0), True),      # Linear 120 -> 2048 over [B, D, T]: 1x1 with Ci % 64 != 0 on the
+                                  (64, 60, 1, 50, 180, (1, 1), (0, 0), True),        # grouped-row loader (one tap: any Ci), one reduction launch
+                                  (96, 10, 1, 50, 30, (1, 1), (0, 0), True),         # ... per group; K = 10 < one row group
+                                  (50, 2048, 1, 50, 120, (1, 1), (0, 0), True)])     # Linear 2048 -> 120
 def test_grouped_weight_gradients(ops, case):
     """dynmm_conv2d_wgrad_group through the C ABI: 3 same-geometry convolutions in one launch against fp64 torch (and
     the bias gradients that ride along), bit-identical between two calls, and the n = 1 / not-groupable fallbacks."""
