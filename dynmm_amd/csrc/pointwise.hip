@@ -698,33 +698,56 @@ __global__ void __launch_bounds__(256) upsample_bwd_w_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // tr (optional) = [4][C] {scale_r, shift_r, scale_d, shift_d}: the inputs are BatchNorm+ReLU outputs that were never
 // written — relu(fma(x, scale, shift)) is applied on load (norm.hip: bn_apply_kernel's expression)
-template <int V>
+// U chunks of 256 * V elements per tensor are requested before any is added.  Measured in isolation (scratch/r6/gap2_time.py,
+// batch 32): the large planes ran at the fabric's rate before and after (47 us for 315 MB at 64 x 120x160 = 6.6 TB/s), the short
+// ones gain a microsecond (15.2 -> 14.1 us at 256 x 30x40, 14.4 -> 13.1 at 512 x 15x20).  The summation order of a lane is
+// unchanged (chunks in ascending order): bit-identical results.
+template <int V, bool DUAL, bool TR>
 __global__ void __launch_bounds__(256) gap2_kernel(const float* __restrict__ xr,
                                                    const float* __restrict__ xd,
                                                    float* __restrict__ sr, float* __restrict__ sd,
                                                    int HW, const float* __restrict__ tr, int C) {
+    constexpr int U = 4;
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * HW;
-    const int ch = tr ? (int)(blockIdx.x % C) : 0;
-    const float scr = tr ? tr[ch] : 1.f, shr = tr ? tr[C + ch] : 0.f;
-    const float scd = tr ? tr[2 * C + ch] : 1.f, shd = tr ? tr[3 * C + ch] : 0.f;
+    const int ch = TR ? (int)(blockIdx.x % C) : 0;
+    const float scr = TR ? tr[ch] : 1.f, shr = TR ? tr[C + ch] : 0.f;
+    const float scd = TR ? tr[2 * C + ch] : 1.f, shd = TR ? tr[3 * C + ch] : 0.f;
+    const float* pr = xr + base;
+    const float* pd = DUAL ? xd + base : pr;
     float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x * V; i < HW; i += 256 * V) {
+    int i = threadIdx.x * V;
+    for (; i + (U - 1) * 256 * V < HW; i += U * 256 * V) {        // U full chunks for this lane
+        float v[U][V], w[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vload<V>(pr + i + u * 256 * V, v[u]);
+            if (DUAL) vload<V>(pd + i + u * 256 * V, w[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                a += TR ? fmaxf(fmaf(v[u][j], scr, shr), 0.f) : v[u][j];
+                if (DUAL) b += TR ? fmaxf(fmaf(w[u][j], scd, shd), 0.f) : w[u][j];
+            }
+    }
+    for (; i < HW; i += 256 * V) {
         float v[V];
-        vload<V>(xr + base + i, v);
+        vload<V>(pr + i, v);
 #pragma unroll
-        for (int j = 0; j < V; ++j) a += tr ? fmaxf(fmaf(v[j], scr, shr), 0.f) : v[j];
-        if (xd) {
-            vload<V>(xd + base + i, v);
+        for (int j = 0; j < V; ++j) a += TR ? fmaxf(fmaf(v[j], scr, shr), 0.f) : v[j];
+        if (DUAL) {
+            vload<V>(pd + i, v);
 #pragma unroll
-            for (int j = 0; j < V; ++j) b += tr ? fmaxf(fmaf(v[j], scd, shd), 0.f) : v[j];
+            for (int j = 0; j < V; ++j) b += TR ? fmaxf(fmaf(v[j], scd, shd), 0.f) : v[j];
         }
     }
     const float ta = block_reduce_sum_256<float>(a, red);
     const float tb = block_reduce_sum_256<float>(b, red);
     if (threadIdx.x == 0) {
         sr[blockIdx.x] = ta / (float)HW;
-        if (xd) sd[blockIdx.x] = tb / (float)HW;
+        if (DUAL) sd[blockIdx.x] = tb / (float)HW;
     }
 }
 
@@ -1052,10 +1075,20 @@ static int gap2_launch(const float* xr, const float* xd, float* sr, float* sd, i
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     if (!xr || !sr || NC <= 0 || HW <= 0) return DYNMM_EINVAL;
     if (xd && !sd) return DYNMM_EINVAL;
+#define DYNMM_GAP2(V, DUAL, TR) hipLaunchKernelGGL((gap2_kernel<V, DUAL, TR>), dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW, tr, C)
+#define DYNMM_GAP2_V(V)                                    \
+    do {                                                   \
+        if (xd && tr) DYNMM_GAP2(V, true, true);           \
+        else if (xd) DYNMM_GAP2(V, true, false);           \
+        else if (tr) DYNMM_GAP2(V, false, true);           \
+        else DYNMM_GAP2(V, false, false);                  \
+    } while (0)
     if (can_vec4(HW, {xr, xd}))
-        hipLaunchKernelGGL(gap2_kernel<4>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW, tr, C);
+        DYNMM_GAP2_V(4);
     else
-        hipLaunchKernelGGL(gap2_kernel<1>, dim3(NC), dim3(256), 0, ST, xr, xd, sr, sd, HW, tr, C);
+        DYNMM_GAP2_V(1);
+#undef DYNMM_GAP2_V
+#undef DYNMM_GAP2
     DYNMM_LAUNCH_CHECK();
     return DYNMM_OK;
 }
