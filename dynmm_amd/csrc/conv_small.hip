@@ -222,8 +222,12 @@ __global__ void __launch_bounds__(256, 1) conv_co8_wgrad_kernel(const Co8WgradAr
 
     // Lanes without a live output pixel (rows past Ho in the last pass, the column group past Wo) read tile positions no piece
     // of this pass wrote, against dy = 0: the tiles start as zeros, so such a position holds zeros or an earlier piece's finite
-    // values — never an uninitialised bit pattern that could be a NaN.
-    for (int i = t; i < 2 * tile_floats; i += 256) tiles[i] = 0.f;
+    // values — never an uninitialised bit pattern that could be a NaN.  The windows of the dead column groups reach up to
+    // 146 - W floats PAST the second tile, i.e. into `red` (W = 16: 130 floats, W = 80: 66): `red` starts as zeros too (round 6 — a
+    // NaN pattern left in LDS by an earlier kernel made 0 * NaN a NaN in a dead lane's accumulator and, through the 16-lane row
+    // sums, in the result: one failure of test_gate_conv_weight_gradient_on_the_vector_alus[case2] in the first seconds of a
+    // fresh box, never reproduced in 25 repetitions); later it holds the previous channel's finite sums.
+    for (int i = t; i < 2 * tile_floats + 16 * (NACC + 8); i += 256) dyn_lds[i] = 0.f;
     __syncthreads();
     request(0);
     for (int q = 0; q < total; ++q) {
