@@ -24,6 +24,8 @@ stream of its own (ops.manual_seed; torch's generator cannot be reproduced bit f
 on both sides); `.eval()` switches it off as in torch.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -295,6 +297,8 @@ class AffectTrainStep:
         self.opt = engine.Adam(self.flatp, self.flat_g, lr, weight_decay=weight_decay, decoupled=True)   # AdamW
         self.lossw, self.clip_val = float(lossw), float(clip_val)
         self.last = None
+        depth = max([len(m.layers) for m in model.modules() if isinstance(m, nn.TransformerEncoder)] or [1])
+        self.wgrad_group = int(os.environ.get('DYNMM_AFFECT_WGRAD_GROUP', min(8, depth)))      # (8 = the library's group limit)
         # The step is ~700 small launches (5-layer transformers on 50-token sequences): launch-bound when issued
         # eagerly, so it can be replayed as ONE hipGraph (lr / step counter are device scalars; temp, hard_gate and
         # the batch shape are frozen into a capture, which is re-made when they change).
@@ -311,6 +315,10 @@ class AffectTrainStep:
         self.flat_g.zero_()
         S.advance_dropout_step(self.flat_g.device)   # new dropout masks every step (also under hipGraph replay)
         prev, ops.PREPACK = ops.PREPACK, self.prepack
+        # a transformer is num_layers same-shape layers on one stream: its linear1 / linear2 / in_proj / out_proj weight gradients go
+        # out as ONE grouped launch each (the library's default group of 4 left every fifth layer to a launch of its own, split
+        # 16 ways over the pixel range to fill the chip)
+        prev_group, ops.WGRAD_GROUP = ops.WGRAD_GROUP, max(ops.WGRAD_GROUP, self.wgrad_group)
         self.prepack.pack()
         try:
             with engine.direct_gradients(False):     # kernels write parameter gradients straight into flat_g
@@ -321,6 +329,7 @@ class AffectTrainStep:
         finally:
             self.prepack.invalidate()                # the optimizer below rewrites the weights
             ops.PREPACK = prev
+            ops.WGRAD_GROUP = prev_group
         nc = S.clip_grad_norm(self.flat_g, self.clip_val)
         self.opt.grad_scale_dev = nc[1:2]
         self.opt.step(None, self.last['total'])
