@@ -17,22 +17,12 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // one modality: s[C] (LDS) -> h[Hd] (LDS, also saved) -> g[C] (saved)
 __device__ void se_mlp_fwd(const float* s, const float* W1, const float* b1, const float* W2,
                            const float* b2, float* h_lds, float* h_out, float* g_out, int C, int Hd) {
-    // one WAVE per hidden unit, lanes along the C inputs (coalesced rows of W1, fixed butterfly): with one LANE per unit, Hd <= 32
-    // lanes of the workgroup walked C = 64 ... 512 dependent loads each while the rest idled — 18-37 us per launch between every
-    // pair of encoder stages (round 6)
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        for (int j = wv; j < Hd; j += nw) {
-            float acc = 0.f;
-            for (int c = lane; c < C; c += 64) acc += W1[j * C + c] * s[c];
-            acc = wave_reduce_sum<float>(acc);
-            if (lane == 0) {
-                acc += b1[j];
-                acc = acc > 0.f ? acc : 0.f;
-                h_lds[j] = acc;
-                h_out[j] = acc;
-            }
-        }
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        float acc = b1[j];
+        for (int c = 0; c < C; ++c) acc += W1[j * C + c] * s[c];
+        acc = acc > 0.f ? acc : 0.f;
+        h_lds[j] = acc;
+        h_out[j] = acc;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -84,18 +74,12 @@ __device__ void se_mlp_bwd(const float* dg, const float* h, const float* g, cons
         dz2_out[c] = dz;
     }
     __syncthreads();
-    {   // one wave per hidden unit, lanes along C (see se_mlp_fwd)
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        for (int j = wv; j < Hd; j += nw) {
-            float acc = 0.f;
-            for (int c = lane; c < C; c += 64) acc += W2[c * Hd + j] * dz2_lds[c];
-            acc = wave_reduce_sum<float>(acc);
-            if (lane == 0) {
-                acc = h[j] > 0.f ? acc : 0.f;
-                dh_lds[j] = acc;
-                dh_out[j] = acc;
-            }
-        }
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += W2[c * Hd + j] * dz2_lds[c];
+        acc = h[j] > 0.f ? acc : 0.f;
+        dh_lds[j] = acc;
+        dh_out[j] = acc;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {

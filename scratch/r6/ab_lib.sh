@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1
 mkdir -p $O
 B="--steps 12 --warmup 3 --no-cpu-baseline --no-extra --no-kernel-timing"
-for rep in 1 2 3 4 5 6; do
+for rep in $(seq 1 ${AB_PAIRS:-6}); do
 for cfg in $2 -; do
   v=$(timeout 300 python scratch/r5/ab_lib.py $cfg $B 2>$O/ab_err.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
   echo "$cfg : $v ms" | tee -a $O/ab.log
