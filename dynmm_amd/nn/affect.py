@@ -24,8 +24,6 @@ stream of its own (ops.manual_seed; torch's generator cannot be reproduced bit f
 on both sides); `.eval()` switches it off as in torch.
 """
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -298,7 +296,7 @@ class AffectTrainStep:
         self.lossw, self.clip_val = float(lossw), float(clip_val)
         self.last = None
         depth = max([len(m.layers) for m in model.modules() if isinstance(m, nn.TransformerEncoder)] or [1])
-        self.wgrad_group = int(os.environ.get('DYNMM_AFFECT_WGRAD_GROUP', min(8, depth)))      # (8 = the library's group limit)
+        self.wgrad_group = min(8, depth)                       # (attribute: A/B against the library's default; 8 = its group limit)
         # The step is ~700 small launches (5-layer transformers on 50-token sequences): launch-bound when issued
         # eagerly, so it can be replayed as ONE hipGraph (lr / step counter are device scalars; temp, hard_gate and
         # the batch shape are frozen into a capture, which is re-made when they change).

@@ -19,6 +19,8 @@ xs = [torch.randn(batch, 50, f, generator=g).to(dev) for f in (35, 74, 300)]
 inputs = [xs, [torch.full((batch,), 50, dtype=torch.long)] * 3]
 y = torch.randn(batch, 1, generator=g).to(dev)
 step = A.AffectTrainStep(model, lr=1e-5, weight_decay=1e-4, lossw=0.1, use_graph=os.environ.get('GRAPH', '1') == '1')
+if os.environ.get('WGRAD_GROUP'):
+    step.wgrad_group = int(os.environ['WGRAD_GROUP'])       # (A/B: 4 = the library's default group)
 model.train(mode == 'train')
 for _ in range(3):
     out = step(inputs, y)
