@@ -17,7 +17,12 @@ namespace dynmm {
 constexpr int kTailMaxC = 64;
 constexpr int kCoefLd = 20;       // 16 pre-summed taps + bias, rows padded to 16 bytes (ds_read_b128 broadcasts)
 
-// coef[c][ar][wr][ac][wc] (16 per channel) + bias: built once per workgroup in LDS
+// coef[c][tail_ci(ar, wr, ac, wc)] (16 per channel) + bias: built once per workgroup in LDS.  The two column parities of a tap
+// sit next to each other, ac = 1 first: frame outputs 2k (ac = 1) and 2k + 1 (ac = 0) read the SAME 2x2 input window, so their
+// logits and their contributions to dx are ONE packed operation each (v_pk_fma_f32: two fp32 FMAs per lane and issue slot) with
+// an 8-byte LDS read of the coefficient pair (round 6; the backward is bound by its vector issue slots).
+typedef float tail_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ constexpr int tail_ci(int ar, int wr, int ac, int wc) { return ((ar * 2 + wr) * 2 + wc) * 2 + (1 - ac); }
 __device__ __forceinline__ void tail_build_coef(const float* __restrict__ wgt, const float* __restrict__ bias,
                                                 float (*coef)[kCoefLd], int C) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -43,7 +48,7 @@ __device__ __forceinline__ void tail_build_coef(const float* __restrict__ wgt, c
                                 if (qin) s += k[r * 3 + q];
                             }
                         }
-                        coef[c][((ar * 2 + wr) * 2 + ac) * 2 + wc] = s;
+                        coef[c][tail_ci(ar, wr, ac, wc)] = s;
                     }
         coef[c][16] = bias ? bias[c] : 0.f;
     }
@@ -134,8 +139,8 @@ __device__ __forceinline__ void tail_read_patch(const float* __restrict__ tile, 
 // logit of frame output (a, b); a, b are compile-time after unrolling
 __device__ __forceinline__ float tail_logit(const float* __restrict__ cf, const float (&v)[4][4], int a, int b) {
     const int ar = (a + 1) & 1, ac = (b + 1) & 1, r0 = a >> 1, c0 = b >> 1;
-    const float* e = cf + ar * 8 + ac * 2;       // [ar][wr][ac][wc]: wr stride 4, wc stride 1
-    return cf[16] + e[0] * v[r0][c0] + e[1] * v[r0][c0 + 1] + e[4] * v[r0 + 1][c0] + e[5] * v[r0 + 1][c0 + 1];
+    return cf[16] + cf[tail_ci(ar, 0, ac, 0)] * v[r0][c0] + cf[tail_ci(ar, 0, ac, 1)] * v[r0][c0 + 1] +
+           cf[tail_ci(ar, 1, ac, 0)] * v[r0 + 1][c0] + cf[tail_ci(ar, 1, ac, 1)] * v[r0 + 1][c0 + 1];
 }
 
 // sum over the 64 lanes in DPP adds (no LDS traffic); the total lands in lane 63
@@ -303,7 +308,14 @@ __global__ void __launch_bounds__(256) up2ce_bwd_kernel(const float* __restrict_
             const float* cf = coef[c];
             const float kc = cw[c] * gs;          // k of the outputs whose target is this channel
             const unsigned cc = (unsigned)(c + 1);
-            float dxa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            // frame columns in pairs (2k, 2k + 1): one window, the coefficient pairs P[(ar, wr, wc)] = (ac = 1, ac = 0)
+            const tail_f2* P = reinterpret_cast<const tail_f2*>(cf);
+            const float bias = cf[16];
+            tail_f2 dxa2[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dxa2[p][q] = tail_f2{0.f, 0.f};
             float acc[10];
 #pragma unroll
             for (int q = 0; q < 10; ++q) acc[q] = 0.f;
@@ -311,31 +323,49 @@ __global__ void __launch_bounds__(256) up2ce_bwd_kernel(const float* __restrict_
             for (int a = 0; a < 6; ++a) {
                 const int ar = (a + 1) & 1, r0 = a >> 1;
 #pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    const int ac = (b + 1) & 1, cb = b >> 1, o = a * 6 + b;
-                    const float l = tail_logit(cf, cur, a, b);
-                    const float hot = ((tcp[o >> 2] >> (8 * (o & 3))) & 0xffu) == cc ? kc : 0.f;
-                    const float dl = __expf(l - le[o]) - hot;
-                    // the window's pixels that belong to the block: patch (r0 + wr, cb + wc) = block pixel (.. - 1)
+                for (int k = 0; k < 3; ++k) {
+                    const int o0 = a * 6 + 2 * k, o1 = o0 + 1;
+                    // the same chain as tail_logit, two outputs at a time
+                    tail_f2 l2 = tail_f2{bias, bias};
+                    l2 += P[(ar * 2 + 0) * 2 + 0] * cur[r0][k];
+                    l2 += P[(ar * 2 + 0) * 2 + 1] * cur[r0][k + 1];
+                    l2 += P[(ar * 2 + 1) * 2 + 0] * cur[r0 + 1][k];
+                    l2 += P[(ar * 2 + 1) * 2 + 1] * cur[r0 + 1][k + 1];
+                    const float hot0 = ((tcp[o0 >> 2] >> (8 * (o0 & 3))) & 0xffu) == cc ? kc : 0.f;
+                    const float hot1 = ((tcp[o1 >> 2] >> (8 * (o1 & 3))) & 0xffu) == cc ? kc : 0.f;
+                    const tail_f2 ex = l2 - tail_f2{le[o0], le[o1]};
+                    const tail_f2 dl2 = tail_f2{__expf(ex.x), __expf(ex.y)} - tail_f2{hot0, hot1};
+                    // the window's pixels that belong to the block: patch (r0 + wr, k + wc) = block pixel (.. - 1)
 #pragma unroll
                     for (int wr = 0; wr < 2; ++wr)
 #pragma unroll
                         for (int wc = 0; wc < 2; ++wc) {
-                            const int p = r0 + wr - 1, q = cb + wc - 1;
-                            if (p >= 0 && p < 2 && q >= 0 && q < 2)
-                                dxa[p][q] = fmaf(dl, cf[((ar * 2 + wr) * 2 + ac) * 2 + wc], dxa[p][q]);
+                            const int p = r0 + wr - 1, q = k + wc - 1;
+                            if (p >= 0 && p < 2 && q >= 0 && q < 2) dxa2[p][q] += dl2 * P[(ar * 2 + wr) * 2 + wc];
                         }
-                    if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {          // the lane's own outputs
-                        acc[9] += dl;
-                        // tap (r, q) of output (a, b) reads up-sampled row 2*i0 + a + r - 2 = patch row (a + r) >> 1
 #pragma unroll
-                        for (int r = 0; r < 3; ++r)
+                    for (int h = 0; h < 2; ++h) {                // the lane's own outputs
+                        const int b = 2 * k + h;
+                        const float dl = h == 0 ? dl2.x : dl2.y;
+                        if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
+                            acc[9] += dl;
+                            // tap (r, q) of output (a, b) reads up-sampled row 2*i0 + a + r - 2 = patch row (a + r) >> 1
+                            // (these 144 FMAs stay scalar: their operand pairs are not register-aligned — packing them was
+                            //  built and bought nothing, the pairs cost as many moves as they save issue slots)
 #pragma unroll
-                            for (int q = 0; q < 3; ++q)
-                                acc[r * 3 + q] = fmaf(dl, cur[(a + r) >> 1][(b + q) >> 1], acc[r * 3 + q]);
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int q = 0; q < 3; ++q)
+                                    acc[r * 3 + q] = fmaf(dl, cur[(a + r) >> 1][(b + q) >> 1], acc[r * 3 + q]);
+                        }
                     }
                 }
             }
+            float dxa[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dxa[p][q] = dxa2[p][q].x + dxa2[p][q].y;
             float* dc = dx + ((size_t)g.n * C + c) * HW;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
