@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, 'dynmm_amd', 'csrc')
 
 
-def scan(asm):
+def scan(asm, floor=4):
     res, name, ev = {}, None, None
     for line in open(asm):
         m = re.match(r'^(_Z\w+):', line)
@@ -38,21 +38,27 @@ def scan(asm):
     for k, ev in res.items():
         s = ''.join(ev)
         n = len(re.findall(r'(?<!L)LW', s)) + (1 if s.startswith('LW') else 0)
-        if n >= 4:
+        if n >= floor:
             out.append((n, s.count('L'), k))
     return sorted(out, reverse=True)
 
 
+def compile_and_scan(hip_file, floor=0):
+    """[(lone-wait loads, loads, mangled kernel name)] of one kernel file (compiles it for gfx950; no GPU needed)"""
+    stem = os.path.splitext(os.path.basename(hip_file))[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', f'-I{ROOT}/include', f'-I{CSRC}',
+                        '-Wno-inline-asm', '--save-temps=obj', '-c', os.path.abspath(hip_file), '-o', os.path.join(tmp, stem + '.o')],
+                       cwd=tmp, check=True, stderr=subprocess.DEVNULL)
+        return scan(os.path.join(tmp, f'{stem}-hip-amdgcn-amd-amdhsa-gfx950.s'), floor)
+
+
 def main():
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, '*.hip')))
-    with tempfile.TemporaryDirectory() as tmp:
-        for f in files:
-            stem = os.path.splitext(os.path.basename(f))[0]
-            subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', f'-I{ROOT}/include', f'-I{CSRC}',
-                            '-Wno-inline-asm', '--save-temps=obj', '-c', os.path.abspath(f), '-o', os.path.join(tmp, stem + '.o')],
-                           cwd=tmp, check=True, stderr=subprocess.DEVNULL)
-            for n, nl, k in scan(os.path.join(tmp, f'{stem}-hip-amdgcn-amd-amdhsa-gfx950.s')):
-                print(f'{n:3d} of {nl:3d} loads wait alone   {stem:20s} {k[:120]}')
+    for f in files:
+        stem = os.path.splitext(os.path.basename(f))[0]
+        for n, nl, k in compile_and_scan(f, 4):
+            print(f'{n:3d} of {nl:3d} loads wait alone   {stem:20s} {k[:120]}')
 
 
 if __name__ == '__main__':
